@@ -1,0 +1,196 @@
+"""Generate tests/golden/*.npz.  RUNS ONLY IN THE BUILD CONTAINER (needs /root/reference).
+
+Part A imports the reference's own modules (afldm.af_libs.ideal_lpf,
+afldm.shift_utils.shifters, afldm.shift_utils.metrics) and records their outputs on
+seeded inputs: these fixtures PIN the oracle's alias-free pieces.
+Part B records outputs of the oracle itself (the diffusers restatement has no reference
+implementation to import) so the GPU box, which has neither /root/reference nor the time to
+run big CPU jobs, can compare against committed arrays.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python -m oracle.gen_golden
+The reference Python never travels; only these arrays + this script are committed.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _import_reference():
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    # numba is absent here; shifters -> flow_utils -> flow_utils_np needs only the decorator name
+    if "numba" not in sys.modules:
+        nb = types.ModuleType("numba")
+        nb.njit = lambda *a, **k: (a[0] if a and callable(a[0]) else (lambda f: f))
+        nb.jit = nb.njit
+        nb.prange = range
+        sys.modules["numba"] = nb
+    from afldm.af_libs import ideal_lpf as ref_lpf
+    from afldm.shift_utils import metrics as ref_metrics
+    try:
+        from afldm.shift_utils import shifters as ref_shift
+    except Exception as e:  # pragma: no cover
+        print("WARNING: reference shifters not importable:", e)
+        ref_shift = None
+    return ref_lpf, ref_metrics, ref_shift
+
+
+def part_a():
+    ref_lpf, ref_metrics, ref_shift = _import_reference()
+    g = {}
+    # G1 masks
+    for N in (2, 4, 6, 8, 10, 16, 32, 64, 256):
+        for cname, c in (("h", 0.5), ("e", 0.125)):
+            if int((N * c) // 2) == 0 and N % 4 == 0:
+                continue        # the reference itself raises IndexError here (ideal_lpf.py:20-21)
+            r2 = ref_lpf.create_lpf_rect(N, c).numpy()
+            q2 = ref_lpf.create_recon_rect(N, c).numpy()
+            # bin 0 of the 1-D mask is always 1, so row 0 of the outer product IS the 1-D mask;
+            # the full 2-D masks are stored for small N only
+            g[f"lpf_rect_{N}_{cname}"] = r2 if N <= 16 else r2[0]
+            g[f"recon_rect_{N}_{cname}"] = q2 if N <= 16 else q2[0]
+    np.savez_compressed(os.path.join(OUT, "g1_masks.npz"), **g)
+
+    # G2 filters / G3 warped-nonlinearity body
+    g = {}
+    torch.manual_seed(100)
+    lpf = ref_lpf.LPF_RFFT(0.5)
+    up2 = ref_lpf.UpsampleRFFT(2)
+    up8 = ref_lpf.UpsampleRFFT(8)
+    for N in (2, 4, 8, 16, 32):
+        x = torch.randn(2, 3, N, N)
+        g[f"x_{N}"] = x.numpy()
+        g[f"lpf_{N}"] = lpf(x.clone()).numpy()
+        g[f"up2_{N}"] = up2(x.clone()).numpy()
+        if N <= 16:
+            g[f"up8_{N}"] = up8(x.clone()).numpy()
+        g[f"subpix_{N}"] = ref_lpf.subpixel_shift(x.clone(), up=2, shift_x=1, shift_y=1).numpy()
+        xw = torch.randn(2, 6, N, N)
+        y = ref_lpf.LPF_RFFT(0.5)(F.silu(ref_lpf.UpsampleRFFT(2)(xw.clone())))[:, :, ::2, ::2]
+        g[f"wx_{N}"] = xw.numpy()
+        g[f"wy_{N}"] = y.numpy()
+    np.savez_compressed(os.path.join(OUT, "g2_filters.npz"), **g)
+
+    # G4 AF-down / AF-up bodies around a seeded conv
+    g = {}
+    torch.manual_seed(101)
+    for N, C in ((8, 8), (16, 4)):
+        conv = torch.nn.Conv2d(C, C, 3, 1, 1)
+        x = torch.randn(2, C, N, N)
+        with torch.no_grad():
+            d = ref_lpf.LPF_RFFT()(conv(x))[:, :, ::2, ::2]
+            u = conv(ref_lpf.UpsampleRFFT()(x))
+        g[f"x_{N}"] = x.numpy()
+        g[f"w_{N}"] = conv.weight.detach().numpy()
+        g[f"b_{N}"] = conv.bias.detach().numpy()
+        g[f"down_{N}"] = d.numpy()
+        g[f"up_{N}"] = u.numpy()
+    np.savez_compressed(os.path.join(OUT, "g4_af_resample.npz"), **g)
+
+    # G5 shifters + metrics
+    g = {}
+    torch.manual_seed(102)
+    lat = torch.randn(1, 4, 32, 32)
+    img = torch.randn(1, 3, 64, 64)
+    g["lat"] = lat.numpy()
+    g["img"] = img.numpy()
+    if ref_shift is not None:
+        for k, tj in enumerate((0.125, 0.5, 1.0, 2.0)):
+            for mode in ("ideal", "ideal_crop"):
+                sh = ref_shift.ImageShifter(mode, 8)
+                w, m = sh.shift(lat, 0, tj)
+                g[f"{mode}_{k}"] = w.numpy()
+                g[f"{mode}_mask_{k}"] = m.numpy()
+            w, m = ref_shift.ImageShifter().shift(img, 0, tj * 8)
+            g[f"bilinear_{k}"] = w.numpy()
+            g[f"bilinear_mask_{k}"] = m.numpy()
+        w, m = ref_shift.ImageShifter("ideal_crop", 8).shift(lat, 0.375, -0.625)
+        g["ideal_crop_2d"] = w.numpy()
+        g["ideal_crop_2d_mask"] = m.numpy()
+        for k, (ti, tj) in enumerate(((1.5, -2.25), (-0.5, 0.0), (0.0, 3.0))):
+            g[f"valid_mask_{k}"] = ref_shift.gen_valid_mask((1, 1, 8, 8), ti, tj).numpy()
+    a, b = torch.randn(2, 3, 8, 8), torch.randn(2, 3, 8, 8)
+    m = (torch.rand(2, 1, 8, 8) > 0.3).float().expand(2, 3, 8, 8).contiguous()
+    g["ma"], g["mb"], g["mm"] = a.numpy(), b.numpy(), m.numpy()
+    g["mask_mse"] = ref_metrics.mask_mse(a, b, m).numpy()
+    g["mask_psnr"] = ref_metrics.mask_psnr(a, b, m).numpy()
+    g["psnr"] = ref_metrics.psnr(a, b).numpy()
+    np.savez_compressed(os.path.join(OUT, "g5_shift_metrics.npz"), **g)
+
+
+def part_b():
+    """Oracle-generated vectors (diffusers restatement + pinned AF filters)."""
+    from . import configs, ddim, pipeline, unet
+    torch.set_num_threads(8)
+    cfg = configs.tiny_unet()
+    sd = unet.randomize_norm_affine(unet.init_unet_params(cfg, seed=0, conv_out_scale=0.1))
+    gen = torch.Generator().manual_seed(1234)
+    x = torch.randn(2, 4, 16, 16, generator=gen)
+    g = {"x": x.numpy()}
+    for af in (True, False):
+        taps = {}
+        y = unet.unet_forward(sd, cfg, x, 501, af=af, taps=taps)
+        tag = "af" if af else "vanilla"
+        g[f"y_{tag}"] = y.numpy()
+        for k in ("emb", "conv_in", "down_blocks.0.resnets.0", "down_blocks.0.attentions.0",
+                  "down_blocks.0.downsamplers.0", "mid_block.resnets.1",
+                  "up_blocks.0.upsamplers.0", "up_blocks.2.attentions.1"):
+            g[f"tap_{tag}:{k}"] = taps[k].numpy()
+    lat, traj = pipeline.ddim_sample(sd, cfg, x, 50, af=True, return_traj=True)
+    g["ddim50_final"] = lat.numpy()
+    g["ddim50_step3"] = traj[2].numpy()
+    base, res = pipeline.shift_equivariance(sd, cfg, x[:1], [0.375, 1.0], 4, ratio=8)
+    g["equiv_base"] = base.numpy()
+    for k, r in enumerate(res):
+        g[f"equiv_lat_{k}"] = r["latent"].numpy()
+        g[f"equiv_mse_{k}"] = np.float64(r["mse"])
+    np.savez_compressed(os.path.join(OUT, "g6_tiny_unet.npz"), **g)
+
+    # FFHQ-size single forward, B=1 (input/output + a few taps subsampled) and a CFA LOAD step
+    cfg = configs.FFHQ_UNET
+    sd = unet.init_unet_params(cfg, seed=0, conv_out_scale=0.1)
+    x = torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(1234))
+    taps = {}
+    y = unet.unet_forward(sd, cfg, x, 981, af=True, taps=taps)
+    g = {"x": x.numpy(), "y_t981": y.numpy()}
+    for k in ("emb", "conv_in", "down_blocks.0.attentions.1", "down_blocks.3.downsamplers.0",
+              "mid_block.resnets.1", "up_blocks.1.attentions.2", "up_blocks.3.upsamplers.0"):
+        g[f"tap:{k}"] = taps[k].numpy()[:, :64]
+    cache = unet.AttnCache()
+    cache.state, cache.timestep = unet.AttnCache.STORE, 981
+    unet.unet_forward(sd, cfg, x, 981, af=True, cache=cache)
+    cache.state = unet.AttnCache.LOAD
+    from .shift import shift_ideal
+    xs, _ = shift_ideal(x, 0.0, 0.375, 8, crop=True)
+    g["x_shift"] = xs.numpy()
+    g["y_load_t981"] = unet.unet_forward(sd, cfg, xs, 981, af=True, cache=cache).numpy()
+    np.savez_compressed(os.path.join(OUT, "g6_ffhq_unet.npz"), **g)
+
+    # G7 scheduler / embedding known answers
+    s = ddim.DDIM()
+    s.set_timesteps(50)
+    g = {"timesteps": s.timesteps.numpy(), "alphas_cumprod": s.alphas_cumprod.numpy()}
+    one, half = torch.tensor(1.0), torch.tensor(0.5)
+    g["step_981"] = s.step(half, 981, one).numpy()
+    g["step_1"] = s.step(half, 1, one).numpy()
+    g["temb_981"] = unet.timestep_embedding(torch.tensor([981]), 192).numpy()
+    np.savez_compressed(os.path.join(OUT, "g7_scheduler.npz"), **g)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("a", "all"):
+        part_a()
+    if which in ("b", "all"):
+        part_b()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

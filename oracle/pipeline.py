@@ -1,0 +1,70 @@
+"""Oracle: DDIM sampling loop and the fractional-shift equivariance harness.
+Restated from reference afldm/pipelines/ldm_pipeline.py:80-112 (sampling) and
+scripts/shift_ldm_ffhq.py:85-151 (STORE pass, shifted LOAD passes), latent-space only
+(the VAE is an §8(f) 'next' row).  Test infrastructure."""
+import time
+
+import torch
+
+from .ddim import DDIM
+from .shift import mask_mse, shift_ideal
+from .unet import AttnCache, unet_forward
+
+
+@torch.no_grad()
+def ddim_sample(sd, cfg, latents, num_inference_steps=50, af=True, cache=None, ddim_cfg=None,
+                return_traj=False):
+    """MyLDMPipeline.__call__(latents=..., output_type='latent') (ldm_pipeline.py:80-112)."""
+    sched = DDIM(ddim_cfg)
+    latents = latents * sched.init_noise_sigma
+    sched.set_timesteps(num_inference_steps)
+    traj = []
+    for t in sched.timesteps:
+        if cache is not None:
+            cache.timestep = int(t)
+        eps = unet_forward(sd, cfg, sched.scale_model_input(latents, t), t, af=af, cache=cache)
+        latents = sched.step(eps, t, latents, eta=0.0)
+        if return_traj:
+            traj.append(latents.clone())
+    return (latents, traj) if return_traj else latents
+
+
+@torch.no_grad()
+def shift_equivariance(sd, cfg, init_latent, offsets, num_inference_steps=50, ratio=8, af=True,
+                       cross_frame=True):
+    """Latent-space core of shift_ldm (shift_ldm_ffhq.py:124-151): one STORE pass on the
+    unshifted latent, then for each offset tj a LOAD pass on the ideal_crop-shifted latent.
+    Returns the unshifted result, and per offset (denoised_shifted, mask, mask_mse vs the
+    ideal-shifted unshifted result)."""
+    cache = AttnCache() if cross_frame else None
+    if cache is not None:
+        cache.state = AttnCache.STORE
+    base = ddim_sample(sd, cfg, init_latent, num_inference_steps, af=af, cache=cache)
+    if cache is not None:
+        cache.state = AttnCache.LOAD
+    out = []
+    for tj in offsets:
+        shifted, mask = shift_ideal(init_latent, 0.0, tj, ratio, crop=True)
+        den = ddim_sample(sd, cfg, shifted, num_inference_steps, af=af, cache=cache)
+        ref, _ = shift_ideal(base, 0.0, tj, ratio, crop=True)
+        out.append(dict(tj=float(tj), latent=den, mask=mask,
+                        mse=float(mask_mse(den, ref, mask))))
+    return base, out
+
+
+def time_denoise_steps(sd, cfg, batch=1, steps=2, threads=None, seed=1234):
+    """cpu_baseline leg of bench.py: seconds per UNet+scheduler step on the host cores."""
+    if threads:
+        torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(seed)
+    lat = torch.randn(batch, cfg["in_channels"], cfg["sample_size"], cfg["sample_size"], generator=g)
+    sched = DDIM()
+    sched.set_timesteps(50)
+    ts = sched.timesteps[:steps + 1]
+    eps = unet_forward(sd, cfg, lat, ts[0])        # warm-up (FFT plans, oneDNN primitives)
+    t0 = time.perf_counter()
+    for t in ts[1:]:
+        eps = unet_forward(sd, cfg, lat, t)
+        lat = sched.step(eps, t, lat)
+    dt = time.perf_counter() - t0
+    return dt / steps

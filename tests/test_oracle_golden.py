@@ -1,0 +1,135 @@
+"""The oracle's alias-free pieces vs fixtures recorded from the IMPORTED reference
+(oracle/gen_golden.py part A), plus known-answer values for the scheduler / masks
+(SURVEY.md Appendix B/C).  CPU only."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ddim, ideal_filters as idf, shift, unet
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_masks_vs_reference(golden):
+    g = golden("g1_masks.npz")
+    n = 0
+    for key in g.files:
+        kind, _, N, c = key.split("_")
+        N = int(N)
+        cutoff = 0.5 if c == "h" else 0.125
+        fn1 = idf.lpf_rect_1d if kind == "lpf" else idf.recon_rect_1d
+        fn2 = idf.lpf_rect_2d if kind == "lpf" else idf.recon_rect_2d
+        ref = g[key]
+        mine = fn2(N, cutoff).numpy() if ref.ndim == 2 else fn1(N, cutoff).numpy()
+        assert np.array_equal(mine, ref), key
+        n += 1
+    assert n >= 28
+
+
+def test_mask_known_answers():
+    # SURVEY.md Appendix B
+    assert idf.lpf_rect_1d(4).tolist() == [1, 0, 0, 0]
+    assert idf.recon_rect_1d(4).tolist() == [1, .5, 0, .5]
+    assert idf.lpf_rect_1d(8).tolist() == [1, 1, 0, 0, 0, 0, 0, 1]
+    assert idf.recon_rect_1d(8).tolist() == [1, 1, .5, 0, 0, 0, .5, 1]
+    assert idf.lpf_rect_1d(6).tolist() == idf.recon_rect_1d(6).tolist() == [1, 1, 0, 0, 0, 1]
+    assert float(idf.lpf_rect_1d(32).sum()) == 15 and float(idf.recon_rect_1d(32).sum()) == 16
+    assert float(idf.lpf_rect_1d(64).sum()) == 31 and float(idf.recon_rect_1d(64).sum()) == 32
+    r = idf.recon_rect_1d(256, 1 / 8)
+    assert float(r.sum()) == 32 and r[16] == .5 and r[240] == .5 and r[15] == 1 and r[17] == 0
+
+
+@pytest.mark.parametrize("N", [2, 4, 8, 16, 32])
+def test_filters_bitexact_vs_reference(golden, N):
+    g = golden("g2_filters.npz")
+    x = t(g[f"x_{N}"])
+    assert torch.equal(idf.lpf_rfft(x.clone()), t(g[f"lpf_{N}"]))
+    assert torch.equal(idf.upsample_rfft(x.clone(), 2), t(g[f"up2_{N}"]))
+    if N <= 16:
+        assert torch.equal(idf.upsample_rfft(x.clone(), 8), t(g[f"up8_{N}"]))
+    assert torch.equal(idf.subpixel_shift(x.clone(), 2, 1, 1), t(g[f"subpix_{N}"]))
+    assert torch.equal(idf.warped_nonlinearity(t(g[f"wx_{N}"])), t(g[f"wy_{N}"]))
+
+
+@pytest.mark.parametrize("N", [2, 4, 8, 16, 32])
+def test_dense_matrix_form_equals_fft_form(golden, N):
+    """U X U^T and D silu(.) D^T (fp64 matrices) == the reference FFT path to fp32 rounding.
+    This is the identity the HIP kernels are built on."""
+    g = golden("g2_filters.npz")
+    x = g[f"x_{N}"].astype(np.float64)
+    U = idf.up_matrix(N, 2)
+    assert np.allclose(U[::2], np.eye(N), atol=1e-12)          # even phases = identity
+    assert np.allclose(U.sum(1), 1, atol=1e-12)
+    up = np.einsum("ah,nchw,bw->ncab", U, x, U)
+    assert np.abs(up - g[f"up2_{N}"]).max() < 2e-5
+    D = idf.down_matrix(2 * N)
+    assert np.allclose(D.sum(1), 1, atol=1e-12)
+    wx = g[f"wx_{N}"].astype(np.float64)
+    z = np.einsum("ah,nchw,bw->ncab", U, wx, U)
+    z = z / (1 + np.exp(-z))
+    y = np.einsum("ah,nchw,bw->ncab", D, z, D)
+    assert np.abs(y - g[f"wy_{N}"]).max() < 2e-5
+    if N >= 4:
+        Dn = idf.down_matrix(N)
+        lp = np.einsum("ah,nchw,bw->ncab", Dn, x, Dn)
+        assert np.abs(lp - g[f"lpf_{N}"][:, :, ::2, ::2]).max() < 2e-5
+    if N <= 16:
+        U8 = idf.up_matrix(N, 8)
+        assert np.abs(np.einsum("ah,nchw,bw->ncab", U8, x, U8) - g[f"up8_{N}"]).max() < 5e-5
+
+
+def test_n2_plane_degenerates_to_mean(golden):
+    g = golden("g2_filters.npz")
+    y = g["wy_2"]
+    assert np.abs(y - y.mean(axis=(2, 3), keepdims=True)).max() < 1e-6
+
+
+@pytest.mark.parametrize("N", [8, 16])
+def test_af_resample_vs_reference(golden, N):
+    g = golden("g4_af_resample.npz")
+    x, w, b = t(g[f"x_{N}"]), t(g[f"w_{N}"]), t(g[f"b_{N}"])
+    assert torch.allclose(idf.af_downsample(x, w, b, padding=1), t(g[f"down_{N}"]), atol=1e-6)
+    assert torch.allclose(idf.af_upsample(x, w, b), t(g[f"up_{N}"]), atol=1e-6)
+
+
+def test_shifters_and_metrics_vs_reference(golden):
+    g = golden("g5_shift_metrics.npz")
+    lat, img = t(g["lat"]), t(g["img"])
+    for k, tj in enumerate((0.125, 0.5, 1.0, 2.0)):
+        for mode in ("ideal", "ideal_crop"):
+            w, m = shift.shift_ideal(lat, 0, tj, 8, crop=(mode == "ideal_crop"))
+            assert torch.equal(w, t(g[f"{mode}_{k}"])), (mode, tj)
+            assert torch.equal(m, t(g[f"{mode}_mask_{k}"]))
+        w, m = shift.shift_bilinear(img, 0, tj * 8)
+        assert torch.allclose(w, t(g[f"bilinear_{k}"]), atol=1e-6)
+        assert torch.equal(m, t(g[f"bilinear_mask_{k}"]))
+    w, m = shift.shift_ideal(lat, 0.375, -0.625, 8, crop=True)
+    assert torch.equal(w, t(g["ideal_crop_2d"])) and torch.equal(m, t(g["ideal_crop_2d_mask"]))
+    for k, (ti, tj) in enumerate(((1.5, -2.25), (-0.5, 0.0), (0.0, 3.0))):
+        assert torch.equal(shift.gen_valid_mask((1, 1, 8, 8), ti, tj), t(g[f"valid_mask_{k}"]))
+    a, b, m = t(g["ma"]), t(g["mb"]), t(g["mm"])
+    assert torch.equal(shift.mask_mse(a, b, m), t(g["mask_mse"]))
+    assert torch.equal(shift.mask_psnr(a, b, m), t(g["mask_psnr"]))
+    assert torch.equal(shift.psnr(a, b), t(g["psnr"]))
+
+
+def test_scheduler_known_answers():
+    # SURVEY.md Appendix C (fp32)
+    s = ddim.DDIM()
+    s.set_timesteps(50)
+    ts = s.timesteps.tolist()
+    assert ts[:3] == [981, 961, 941] and ts[-3:] == [41, 21, 1] and len(ts) == 50
+    ac = s.alphas_cumprod
+    for idx, val in ((0, 0.998499990), (1, 0.996994436), (21, 0.965732038),
+                     (981, 0.000201956), (999, 0.000142304)):
+        assert abs(float(ac[idx]) - val) < 5e-9 + 2e-6 * val, (idx, float(ac[idx]))
+    one, half = torch.tensor(1.0), torch.tensor(0.5)
+    assert abs(float(s.step(half, 981, one)) - 1.1040677) < 2e-6
+    assert abs(float(s.step(half, 1, one)) - 0.9926875) < 2e-6
+    e = unet.timestep_embedding(torch.tensor([981]), 192)[0]
+    assert abs(float(e[0]) - 0.6799572) < 1e-5       # cos[0]
+    assert abs(float(e[95]) - 0.9941760) < 1e-5      # cos[95]
+    assert abs(float(e[96]) - 0.7332518) < 1e-5      # sin[0]
