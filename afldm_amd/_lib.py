@@ -1,0 +1,90 @@
+"""ctypes binding of libafldm_hip.so (declarations mirror include/afldm_hip.h).
+
+The library is the ONLY compute path of afldm_amd: if it cannot be loaded, importing this
+module raises — there is no CPU fallback."""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_size_t, c_void_p
+
+import torch  # noqa: F401  (imported first so torch's libamdhip64.so.7 is the one HIP runtime in-process)
+
+F32, BF16 = 0, 1
+DTYPE_CODE = {torch.float32: F32, torch.bfloat16: BF16}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libafldm_hip.so")
+
+
+class ConvArgs(Structure):
+    _fields_ = [
+        ("x1", c_void_p), ("x2", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("temb", c_void_p),
+        ("residual", c_void_p), ("y", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+        ("C1", c_int), ("C2", c_int), ("B", c_int), ("H", c_int), ("W", c_int), ("Cout", c_int),
+        ("KS", c_int), ("temb_stride", c_int), ("res_ld", c_int), ("y_ld", c_int),
+        ("out_mode", c_int), ("dtype", c_int),
+    ]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: run `python -m afldm_amd.build` (hipcc, gfx950). "
+            "afldm_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    vp, ip, fp = c_void_p, c_int, c_float
+    sigs = {
+        "afldm_version": ([], c_int),
+        "afldm_last_error": ([], c_char_p),
+        "afldm_device_info": ([c_char_p, ip], c_int),
+        "afldm_filter_matrix": ([ip, ip, ip, POINTER(c_float)], c_int),
+        "afldm_nchw_to_nhwc": ([vp, vp, ip, ip, ip, ip, ip, vp], c_int),
+        "afldm_nhwc_to_nchw": ([vp, vp, ip, ip, ip, ip, ip, vp], c_int),
+        "afldm_pack_weight": ([vp, vp, ip, ip, ip, ip, ip, vp], c_int),
+        "afldm_cast": ([vp, ip, vp, ip, c_size_t, vp], c_int),
+        "afldm_timestep_embedding": ([vp, vp, ip, ip, ip, fp, ip, vp], c_int),
+        "afldm_silu": ([vp, vp, c_size_t, ip, vp], c_int),
+        "afldm_gn_stats": ([vp, ip, vp, ip, vp, ip, ip, ip, fp, ip, vp], c_int),
+        "afldm_gn_apply": ([vp, ip, vp, ip, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp], c_int),
+        "afldm_af_act": ([vp, ip, vp, ip, vp, vp, vp, ip, vp, vp, vp, ip, ip, ip, vp], c_int),
+        "afldm_af_up2": ([vp, vp, vp, vp, ip, ip, ip, ip, vp], c_int),
+        "afldm_af_lpf_down2": ([vp, vp, vp, vp, ip, ip, ip, ip, vp], c_int),
+        "afldm_conv2d": ([POINTER(ConvArgs), vp], c_int),
+        "afldm_conv2d_workspace": ([POINTER(ConvArgs)], c_size_t),
+        "afldm_attention": ([vp, ip, vp, ip, vp, vp, ip, ip, ip, ip, ip, ip, ip, fp, ip, vp], c_int),
+        "afldm_ddim_step": ([vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, vp], c_int),
+        "afldm_select_timestep": ([vp, vp, vp, vp], c_int),
+    }
+    for name, (argtypes, restype) in sigs.items():
+        fn = getattr(lib, name)      # AttributeError here = header/library mismatch
+        fn.argtypes = argtypes
+        fn.restype = restype
+    return lib, sorted(sigs)
+
+
+lib, EXPORTS = _load()
+
+
+class AfldmError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib.afldm_last_error()
+        raise AfldmError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def filter_matrix(kind: int, N: int, up: int = 2) -> torch.Tensor:
+    """Host fp32 matrix: kind 0 -> U [up*N, N]; kind 1 -> D [N/2, N]."""
+    rows, cols = (up * N, N) if kind == 0 else (N // 2, N)
+    buf = (c_float * (rows * cols))()
+    check(lib.afldm_filter_matrix(kind, N, up, buf), "afldm_filter_matrix")
+    return torch.frombuffer(buf, dtype=torch.float32).clone().reshape(rows, cols)
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,149 @@
+// common.hpp — shared device/host helpers for libafldm_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/afldm_hip.h"
+
+namespace afldm {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// ----------------------------------------------------------------------------- errors
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define AFLDM_REQUIRE(cond, code, ...) \
+  do {                                 \
+    if (!(cond)) {                     \
+      afldm::set_error(__VA_ARGS__);   \
+      return (code);                   \
+    }                                  \
+  } while (0)
+
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16, name)            \
+  do {                                                          \
+    if ((dtype) == AFLDM_F32) {                                 \
+      CALL_F32;                                                 \
+    } else if ((dtype) == AFLDM_BF16) {                         \
+      CALL_BF16;                                                \
+    } else {                                                    \
+      afldm::set_error("%s: unknown dtype %d", name, (int)(dtype));    \
+      return AFLDM_EDTYPE;                                      \
+    }                                                           \
+  } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ----------------------------------------------------------------------------- scalar conversions
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+template <typename T>
+__device__ __forceinline__ T from_f32(float v);
+template <>
+__device__ __forceinline__ float from_f32<float>(float v) {
+  return v;
+}
+template <>
+__device__ __forceinline__ bf16 from_f32<bf16>(float v) {
+  return (bf16)v;  // round-to-nearest-even (v_cvt_pk_bf16_f32 on gfx950)
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// ----------------------------------------------------------------------------- 16-byte fragments
+// A "chunk" is 16 bytes of a K-contiguous row: 4 fp32 or 8 bf16.  Both MFMA flavours below take
+// one chunk per lane for A and one for B:
+//   lane l = (i = l & 15, g = l >> 4)   A-chunk = A[i][k-set(g)],  B-chunk = B[k-set(g)][j = l & 15]
+//   D (f32x4) on lane (j = l & 15, g):  D[i = 4 g + r][j],  r = 0..3      (same for both dtypes)
+// f32 : v_mfma_f32_16x16x4_f32 x4, k-set(g) = {4g..4g+3}      -> one chunk pair covers K = 16
+// bf16: v_mfma_f32_16x16x32_bf16,  k-set(g) = {8g..8g+7}      -> one chunk pair covers K = 32
+// (the hardware pairs element e of A's lane-group g with element e of B's lane-group g, so any
+//  K permutation applied identically to both operands is legal — used by the "chain" trick.)
+template <typename T>
+struct Mma;
+
+template <>
+struct Mma<float> {
+  typedef f32x4 Chunk;
+  static constexpr int EPC = 4;   // elements per chunk
+  static constexpr int KPF = 16;  // K covered by one chunk pair
+  static __device__ __forceinline__ void mma(f32x4& acc, const Chunk& a, const Chunk& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
+  }
+  static __device__ __forceinline__ Chunk zero() { return Chunk{0.f, 0.f, 0.f, 0.f}; }
+};
+
+template <>
+struct Mma<bf16> {
+  typedef bf16x8 Chunk;
+  static constexpr int EPC = 8;
+  static constexpr int KPF = 32;
+  static __device__ __forceinline__ void mma(f32x4& acc, const Chunk& a, const Chunk& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+  }
+  static __device__ __forceinline__ Chunk zero() {
+    Chunk z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = (bf16)0.0f;
+    return z;
+  }
+};
+
+// 16-byte vector load/store through a generic pointer (global or LDS); p must be 16-B aligned.
+template <typename V>
+__device__ __forceinline__ V ld16(const void* p) {
+  return *reinterpret_cast<const V*>(p);
+}
+template <typename V>
+__device__ __forceinline__ void st16(void* p, const V& v) {
+  *reinterpret_cast<V*>(p) = v;
+}
+
+// Pack 4 fp32 values as 4 consecutive T elements and store (8 B for bf16, 16 B for fp32).
+template <typename T>
+__device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
+}
+template <>
+__device__ __forceinline__ void store4<bf16>(bf16* p, float a, float b, float c, float d) {
+  bf16x4 v;
+  v[0] = (bf16)a; v[1] = (bf16)b; v[2] = (bf16)c; v[3] = (bf16)d;
+  *reinterpret_cast<bf16x4*>(p) = v;
+}
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, float& a, float& b, float& c, float& d);
+template <>
+__device__ __forceinline__ void load4<float>(const float* p, float& a, float& b, float& c, float& d) {
+  f32x4 v = *reinterpret_cast<const f32x4*>(p);
+  a = v[0]; b = v[1]; c = v[2]; d = v[3];
+}
+template <>
+__device__ __forceinline__ void load4<bf16>(const bf16* p, float& a, float& b, float& c, float& d) {
+  bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  a = (float)v[0]; b = (float)v[1]; c = (float)v[2]; d = (float)v[3];
+}
+
+// XCD-aware work-item remap (guide T1, bijective form): consecutive work items land on the
+// same XCD (private L2) instead of round-robin across the 8 XCDs.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int NX = 8;
+  int xcd = bid % NX, q = nwg / NX, r = nwg % NX;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + bid / NX;
+}
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace afldm

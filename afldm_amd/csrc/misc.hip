@@ -1,0 +1,208 @@
+// misc.hip — layout/dtype plumbing, timestep embedding, SiLU, DDIM update.  All HBM-bound
+// elementwise kernels: coalesced accesses, grid-stride loops, no LDS.
+#include "common.hpp"
+
+namespace afldm {
+
+static inline int ew_grid(size_t n, int block = 256) {
+  size_t g = (n + block - 1) / block;
+  size_t cap = 256 * 8;  // 256 CUs x 8 blocks, grid-stride beyond (guide G11)
+  return (int)(g < cap ? (g ? g : 1) : cap);
+}
+
+// ----------------------------------------------------------------------------- NCHW <-> NHWC
+// One workgroup transposes a [C][64-pixel] slab through LDS so both sides stay coalesced
+// when C is large; for C <= 8 (the 4-channel latents) the direct form below is already fine.
+template <typename T>
+__global__ void k_nchw_to_nhwc(const float* __restrict__ src, T* __restrict__ dst, int B, int C, int HW) {
+  size_t n = (size_t)B * C * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    size_t p = i / C;  // b*HW + pix
+    int pix = (int)(p % HW);
+    int b = (int)(p / HW);
+    dst[i] = from_f32<T>(src[((size_t)b * C + c) * HW + pix]);
+  }
+}
+template <typename T>
+__global__ void k_nhwc_to_nchw(const T* __restrict__ src, float* __restrict__ dst, int B, int C, int HW) {
+  size_t n = (size_t)B * C * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    int pix = (int)(i % HW);
+    size_t p = i / HW;  // b*C + c
+    int c = (int)(p % C);
+    int b = (int)(p / C);
+    dst[i] = to_f32(src[((size_t)b * HW + pix) * C + c]);
+  }
+}
+
+// OIHW fp32 -> OHWI T
+template <typename T>
+__global__ void k_pack_weight(const float* __restrict__ src, T* __restrict__ dst, int O, int I, int KK) {
+  size_t n = (size_t)O * I * KK;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    int ci = (int)(i % I);
+    size_t r = i / I;
+    int kk = (int)(r % KK);
+    int o = (int)(r / KK);
+    dst[i] = from_f32<T>(src[((size_t)o * I + ci) * KK + kk]);
+  }
+}
+
+template <typename S, typename D>
+__global__ void k_cast(const S* __restrict__ src, D* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = from_f32<D>(to_f32(src[i]));
+}
+
+// ----------------------------------------------------------------------------- timestep embedding
+template <typename T>
+__global__ void k_timestep_embedding(const float* __restrict__ t, T* __restrict__ out, int rows, int dim,
+                                     int flip, float freq_shift) {
+  int half = dim / 2;
+  int n = rows * half;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int r = i / half, k = i % half;
+    // exponent = -ln(10000) * k / (half - freq_shift); emb = exp(exponent)  (fp32, like torch)
+    float e = -9.210340371976184f * (float)k;
+    e = e / ((float)half - freq_shift);
+    float w = expf(e);
+    float a = t[r] * w;
+    float s = sinf(a), c = cosf(a);
+    T* o = out + (size_t)r * dim;
+    if (flip) {
+      o[k] = from_f32<T>(c);
+      o[half + k] = from_f32<T>(s);
+    } else {
+      o[k] = from_f32<T>(s);
+      o[half + k] = from_f32<T>(c);
+    }
+  }
+}
+
+template <typename T>
+__global__ void k_silu(const T* __restrict__ x, T* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = from_f32<T>(silu_f(to_f32(x[i])));
+}
+
+// ----------------------------------------------------------------------------- DDIM
+template <typename T>
+__global__ void k_ddim_step(const float* __restrict__ x, const T* __restrict__ eps, float* __restrict__ xprev,
+                            const float* __restrict__ coef, int* __restrict__ step_idx, int advance, int B,
+                            int C, int HW) {
+  const int s = *step_idx;
+  const float sa_t = coef[4 * s + 0], sb_t = coef[4 * s + 1], sa_p = coef[4 * s + 2], sb_p = coef[4 * s + 3];
+  size_t n = (size_t)B * C * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    int pix = (int)(i % HW);
+    size_t p = i / HW;
+    int c = (int)(p % C);
+    int b = (int)(p / C);
+    float e = to_f32(eps[((size_t)b * HW + pix) * C + c]);
+    float xv = x[i];
+    float x0 = (xv - sb_t * e) / sa_t;
+    xprev[i] = sa_p * x0 + sb_p * e;
+  }
+}
+// separate tiny kernel so that every block of k_ddim_step reads the same (old) index
+__global__ void k_advance(int* step_idx) { *step_idx += 1; }
+
+__global__ void k_select_timestep(const float* tvals, const int* step_idx, float* t_out) { t_out[0] = tvals[*step_idx]; }
+
+}  // namespace afldm
+
+using namespace afldm;
+
+extern "C" int afldm_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int dtype,
+                                  afldm_stream_t stream) {
+  AFLDM_REQUIRE(src && dst, AFLDM_ENULL, "afldm_nchw_to_nhwc: NULL pointer");
+  AFLDM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, AFLDM_ESHAPE, "afldm_nchw_to_nhwc: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  size_t n = (size_t)B * C * H * W;
+  DISPATCH_T(dtype, (k_nchw_to_nhwc<float><<<ew_grid(n), 256, 0, st>>>(src, (float*)dst, B, C, H * W)),
+             (k_nchw_to_nhwc<bf16><<<ew_grid(n), 256, 0, st>>>(src, (bf16*)dst, B, C, H * W)), "afldm_nchw_to_nhwc");
+  return check_launch("afldm_nchw_to_nhwc");
+}
+
+extern "C" int afldm_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int dtype,
+                                  afldm_stream_t stream) {
+  AFLDM_REQUIRE(src && dst, AFLDM_ENULL, "afldm_nhwc_to_nchw: NULL pointer");
+  AFLDM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, AFLDM_ESHAPE, "afldm_nhwc_to_nchw: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  size_t n = (size_t)B * C * H * W;
+  DISPATCH_T(dtype, (k_nhwc_to_nchw<float><<<ew_grid(n), 256, 0, st>>>((const float*)src, dst, B, C, H * W)),
+             (k_nhwc_to_nchw<bf16><<<ew_grid(n), 256, 0, st>>>((const bf16*)src, dst, B, C, H * W)), "afldm_nhwc_to_nchw");
+  return check_launch("afldm_nhwc_to_nchw");
+}
+
+extern "C" int afldm_pack_weight(const float* src, void* dst, int O, int I, int KH, int KW, int dtype,
+                                 afldm_stream_t stream) {
+  AFLDM_REQUIRE(src && dst, AFLDM_ENULL, "afldm_pack_weight: NULL pointer");
+  AFLDM_REQUIRE(O > 0 && I > 0 && KH > 0 && KW > 0, AFLDM_ESHAPE, "afldm_pack_weight: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  size_t n = (size_t)O * I * KH * KW;
+  DISPATCH_T(dtype, (k_pack_weight<float><<<ew_grid(n), 256, 0, st>>>(src, (float*)dst, O, I, KH * KW)),
+             (k_pack_weight<bf16><<<ew_grid(n), 256, 0, st>>>(src, (bf16*)dst, O, I, KH * KW)), "afldm_pack_weight");
+  return check_launch("afldm_pack_weight");
+}
+
+extern "C" int afldm_cast(const void* src, int sd, void* dst, int dd, size_t n, afldm_stream_t stream) {
+  AFLDM_REQUIRE(src && dst, AFLDM_ENULL, "afldm_cast: NULL pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) return AFLDM_OK;
+  if (sd == AFLDM_F32 && dd == AFLDM_F32)
+    k_cast<float, float><<<ew_grid(n), 256, 0, st>>>((const float*)src, (float*)dst, n);
+  else if (sd == AFLDM_F32 && dd == AFLDM_BF16)
+    k_cast<float, bf16><<<ew_grid(n), 256, 0, st>>>((const float*)src, (bf16*)dst, n);
+  else if (sd == AFLDM_BF16 && dd == AFLDM_F32)
+    k_cast<bf16, float><<<ew_grid(n), 256, 0, st>>>((const bf16*)src, (float*)dst, n);
+  else if (sd == AFLDM_BF16 && dd == AFLDM_BF16)
+    k_cast<bf16, bf16><<<ew_grid(n), 256, 0, st>>>((const bf16*)src, (bf16*)dst, n);
+  else {
+    set_error("afldm_cast: unknown dtype %d/%d", sd, dd);
+    return AFLDM_EDTYPE;
+  }
+  return check_launch("afldm_cast");
+}
+
+extern "C" int afldm_timestep_embedding(const float* t, void* out, int rows, int dim, int flip, float freq_shift,
+                                        int dtype, afldm_stream_t stream) {
+  AFLDM_REQUIRE(t && out, AFLDM_ENULL, "afldm_timestep_embedding: NULL pointer");
+  AFLDM_REQUIRE(rows > 0 && dim > 0 && dim % 2 == 0, AFLDM_ESHAPE, "afldm_timestep_embedding: dim %d must be even", dim);
+  hipStream_t st = (hipStream_t)stream;
+  size_t n = (size_t)rows * dim / 2;
+  DISPATCH_T(dtype, (k_timestep_embedding<float><<<ew_grid(n), 256, 0, st>>>(t, (float*)out, rows, dim, flip, freq_shift)),
+             (k_timestep_embedding<bf16><<<ew_grid(n), 256, 0, st>>>(t, (bf16*)out, rows, dim, flip, freq_shift)),
+             "afldm_timestep_embedding");
+  return check_launch("afldm_timestep_embedding");
+}
+
+extern "C" int afldm_silu(const void* x, void* y, size_t n, int dtype, afldm_stream_t stream) {
+  AFLDM_REQUIRE(x && y, AFLDM_ENULL, "afldm_silu: NULL pointer");
+  if (n == 0) return AFLDM_OK;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, (k_silu<float><<<ew_grid(n), 256, 0, st>>>((const float*)x, (float*)y, n)),
+             (k_silu<bf16><<<ew_grid(n), 256, 0, st>>>((const bf16*)x, (bf16*)y, n)), "afldm_silu");
+  return check_launch("afldm_silu");
+}
+
+extern "C" int afldm_ddim_step(const float* x, const void* eps, float* x_prev, const float* coef, int* step_idx,
+                               int advance, int B, int C, int H, int W, int dtype, afldm_stream_t stream) {
+  AFLDM_REQUIRE(x && eps && x_prev && coef && step_idx, AFLDM_ENULL, "afldm_ddim_step: NULL pointer");
+  AFLDM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, AFLDM_ESHAPE, "afldm_ddim_step: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  size_t n = (size_t)B * C * H * W;
+  DISPATCH_T(dtype,
+             (k_ddim_step<float><<<ew_grid(n), 256, 0, st>>>(x, (const float*)eps, x_prev, coef, step_idx, advance, B, C, H * W)),
+             (k_ddim_step<bf16><<<ew_grid(n), 256, 0, st>>>(x, (const bf16*)eps, x_prev, coef, step_idx, advance, B, C, H * W)),
+             "afldm_ddim_step");
+  if (advance) k_advance<<<1, 1, 0, st>>>(step_idx);
+  return check_launch("afldm_ddim_step");
+}
+
+extern "C" int afldm_select_timestep(const float* tvals, const int* step_idx, float* t_out, afldm_stream_t stream) {
+  AFLDM_REQUIRE(tvals && step_idx && t_out, AFLDM_ENULL, "afldm_select_timestep: NULL pointer");
+  k_select_timestep<<<1, 1, 0, (hipStream_t)stream>>>(tvals, step_idx, t_out);
+  return check_launch("afldm_select_timestep");
+}

@@ -1,0 +1,274 @@
+"""Tensor-level wrappers over the C ABI (include/afldm_hip.h).  PyTorch here is only the owner
+of device memory and streams; every op below is one or two HIP kernel launches from
+libafldm_hip.so on torch's current stream.  All activations are NHWC ([B, H, W, C]) or
+token-major ([B, T, C]) contiguous CUDA tensors in fp32 or bf16.  CPU tensors raise."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvArgs, DTYPE_CODE, check, lib, ptr, stream_ptr
+
+_FILTER_CACHE = {}
+
+
+def _dev(t, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(f"afldm_amd: {name} must live on an MI355X (cuda) device; there is no CPU path")
+    if not t.is_contiguous():
+        raise RuntimeError(f"afldm_amd: {name} must be contiguous")
+    return t
+
+
+def _code(t):
+    try:
+        return DTYPE_CODE[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"afldm_amd: dtype {t.dtype} unsupported (fp32 / bf16 only)")
+
+
+def filter_matrices(N, device):
+    """(U [2N,N], D [N,2N]) device fp32 matrices for a plane of size N (cached per device)."""
+    key = ("act", N, str(device))
+    if key not in _FILTER_CACHE:
+        U = _lib.filter_matrix(0, N, 2).to(device)
+        D = _lib.filter_matrix(1, 2 * N).to(device)
+        _FILTER_CACHE[key] = (U, D)
+    return _FILTER_CACHE[key]
+
+
+def down_matrix(N, device):
+    """D [N/2, N] for AliasFreeDownsample2D on an N x N plane."""
+    key = ("down", N, str(device))
+    if key not in _FILTER_CACHE:
+        _FILTER_CACHE[key] = _lib.filter_matrix(1, N).to(device)
+    return _FILTER_CACHE[key]
+
+
+def up_matrix(N, up, device):
+    key = ("up", N, up, str(device))
+    if key not in _FILTER_CACHE:
+        _FILTER_CACHE[key] = _lib.filter_matrix(0, N, up).to(device)
+    return _FILTER_CACHE[key]
+
+
+# ----------------------------------------------------------------------------- layout
+def to_nhwc(x, dtype=torch.float32, out=None):
+    """NCHW fp32 -> NHWC dtype."""
+    _dev(x, "x")
+    assert x.dtype == torch.float32 and x.ndim == 4
+    B, C, H, W = x.shape
+    if out is None:
+        out = torch.empty((B, H, W, C), dtype=dtype, device=x.device)
+    check(lib.afldm_nchw_to_nhwc(ptr(x), ptr(out), B, C, H, W, _code(out), stream_ptr()), "nchw_to_nhwc")
+    return out
+
+
+def to_nchw(x, out=None):
+    """NHWC dtype -> NCHW fp32."""
+    _dev(x, "x")
+    B, H, W, C = x.shape
+    if out is None:
+        out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    check(lib.afldm_nhwc_to_nchw(ptr(x), ptr(out), B, C, H, W, _code(x), stream_ptr()), "nhwc_to_nchw")
+    return out
+
+
+def pack_weight(w, dtype):
+    """OIHW (or [O, I]) fp32 parameter -> OHWI dtype."""
+    _dev(w, "weight")
+    w = w.detach().to(torch.float32).contiguous()
+    if w.ndim == 2:
+        O, I = w.shape
+        KH = KW = 1
+    else:
+        O, I, KH, KW = w.shape
+    out = torch.empty((O, KH, KW, I), dtype=dtype, device=w.device)
+    check(lib.afldm_pack_weight(ptr(w), ptr(out), O, I, KH, KW, _code(out), stream_ptr()), "pack_weight")
+    return out
+
+
+# ----------------------------------------------------------------------------- small ops
+def timestep_embedding(t, dim, flip_sin_to_cos=True, freq_shift=0.0, dtype=torch.float32, out=None):
+    _dev(t, "t")
+    assert t.dtype == torch.float32 and t.ndim == 1
+    rows = t.shape[0]
+    if out is None:
+        out = torch.empty((rows, dim), dtype=dtype, device=t.device)
+    check(lib.afldm_timestep_embedding(ptr(t), ptr(out), rows, dim, int(flip_sin_to_cos), float(freq_shift),
+                                       _code(out), stream_ptr()), "timestep_embedding")
+    return out
+
+
+def silu(x, out=None):
+    _dev(x, "x")
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.afldm_silu(ptr(x), ptr(out), x.numel(), _code(x), stream_ptr()), "silu")
+    return out
+
+
+def _cat_args(x1, x2):
+    _dev(x1, "x1")
+    C1 = x1.shape[-1]
+    if x2 is None:
+        return C1, None, 0
+    _dev(x2, "x2")
+    assert x2.shape[:-1] == x1.shape[:-1] and x2.dtype == x1.dtype
+    return C1, x2, x2.shape[-1]
+
+
+def gn_stats(x1, G, eps, x2=None, out=None):
+    C1, x2, C2 = _cat_args(x1, x2)
+    B = x1.shape[0]
+    HW = x1.numel() // (B * C1)
+    if out is None:
+        out = torch.empty((B, G, 2), dtype=torch.float32, device=x1.device)
+    check(lib.afldm_gn_stats(ptr(x1), C1, ptr(x2), C2, ptr(out), B, HW, G, float(eps), _code(x1), stream_ptr()),
+          "gn_stats")
+    return out
+
+
+def gn_apply(x1, stats, gamma, beta, G, act=0, x2=None, out=None):
+    C1, x2, C2 = _cat_args(x1, x2)
+    B = x1.shape[0]
+    HW = x1.numel() // (B * C1)
+    if out is None:
+        out = torch.empty(tuple(x1.shape[:-1]) + (C1 + C2,), dtype=x1.dtype, device=x1.device)
+    check(lib.afldm_gn_apply(ptr(x1), C1, ptr(x2), C2, ptr(stats), ptr(gamma), ptr(beta), ptr(out), B, HW, G,
+                             int(act), _code(x1), stream_ptr()), "gn_apply")
+    return out
+
+
+# ----------------------------------------------------------------------------- alias-free ops
+def af_act(x1, x2=None, stats=None, gamma=None, beta=None, G=0, out=None):
+    """[GroupNorm-apply ->] WarpedNonlinearity(SiLU) on an NHWC tensor (virtual concat x1|x2)."""
+    C1, x2, C2 = _cat_args(x1, x2)
+    B, N, N2, _ = x1.shape
+    assert N == N2, "the reference's ideal filters assume square planes (ideal_lpf.py:80)"
+    U, D = filter_matrices(N, x1.device)
+    if out is None:
+        out = torch.empty((B, N, N, C1 + C2), dtype=x1.dtype, device=x1.device)
+    check(lib.afldm_af_act(ptr(x1), C1, ptr(x2), C2, ptr(stats), ptr(gamma), ptr(beta), int(G), ptr(U), ptr(D),
+                           ptr(out), B, N, _code(x1), stream_ptr()), "af_act")
+    return out
+
+
+def af_up2(x, out=None, workspace=None):
+    _dev(x, "x")
+    B, N, N2, C = x.shape
+    assert N == N2
+    U = up_matrix(N, 2, x.device)
+    if out is None:
+        out = torch.empty((B, 2 * N, 2 * N, C), dtype=x.dtype, device=x.device)
+    if workspace is None:
+        workspace = torch.empty(B * 2 * N * N * C, dtype=torch.float32, device=x.device)
+    assert workspace.numel() >= B * 2 * N * N * C
+    check(lib.afldm_af_up2(ptr(x), ptr(U), ptr(out), ptr(workspace), B, N, C, _code(x), stream_ptr()), "af_up2")
+    return out
+
+
+def af_lpf_down2(x, out=None, workspace=None):
+    _dev(x, "x")
+    B, N, N2, C = x.shape
+    assert N == N2
+    D = down_matrix(N, x.device)
+    if out is None:
+        out = torch.empty((B, N // 2, N // 2, C), dtype=x.dtype, device=x.device)
+    if workspace is None:
+        workspace = torch.empty(B * (N // 2) * N * C, dtype=torch.float32, device=x.device)
+    assert workspace.numel() >= B * (N // 2) * N * C
+    check(lib.afldm_af_lpf_down2(ptr(x), ptr(D), ptr(out), ptr(workspace), B, N, C, _code(x), stream_ptr()),
+          "af_lpf_down2")
+    return out
+
+
+# ----------------------------------------------------------------------------- conv / linear
+def conv_args(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, out=None, out_mode=0,
+              workspace=None, y_ld=None):
+    """Build the afldm_conv_args struct (keeps references to the tensors alive in `.keep`)."""
+    C1, x2, C2 = _cat_args(x1, x2)
+    _dev(w, "w")
+    Cout, KS = w.shape[0], w.shape[1]
+    assert w.shape[3] == C1 + C2, f"weight Cin {w.shape[3]} != {C1}+{C2}"
+    if x1.ndim == 4:
+        B, H, W_ = x1.shape[:3]
+    else:                      # [rows, C] or [B, T, C]: a linear layer
+        B, H, W_ = x1.numel() // C1, 1, 1
+    a = ConvArgs()
+    a.x1, a.x2, a.w, a.bias = ptr(x1), ptr(x2), ptr(w), ptr(bias)
+    a.temb, a.residual, a.y = ptr(temb), ptr(residual), ptr(out)
+    a.workspace = ptr(workspace)
+    a.workspace_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
+    a.C1, a.C2, a.B, a.H, a.W, a.Cout, a.KS = C1, C2, B, H, W_, Cout, KS
+    a.temb_stride = int(temb_stride)
+    a.res_ld = Cout if residual is None else residual.shape[-1]
+    a.y_ld = Cout if y_ld is None else int(y_ld)
+    a.out_mode = int(out_mode)
+    a.dtype = _code(x1)
+    a.keep = (x1, x2, w, bias, temb, residual, out, workspace)
+    return a
+
+
+def conv2d(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, out=None, out_mode=0,
+           workspace=None):
+    """stride-1 'same' conv (KS in {1,3}) / linear on NHWC input with packed OHWI weights.
+    out_mode 1 returns the channel-major [B, Cout, H*W] tensor (V^T for attention)."""
+    Cout = w.shape[0]
+    if out is None:
+        if out_mode == 0:
+            out = torch.empty(tuple(x1.shape[:-1]) + (Cout,), dtype=x1.dtype, device=x1.device)
+        else:
+            B = x1.shape[0]
+            out = torch.empty((B, Cout, x1.numel() // (B * x1.shape[-1])), dtype=x1.dtype, device=x1.device)
+    a = conv_args(x1, w, bias, x2, temb, temb_stride, residual, out, out_mode, workspace)
+    if out_mode == 1 and x1.ndim == 3:      # [B, T, C] tokens: treat T as the pixel axis
+        a.B, a.H, a.W = x1.shape[0], x1.shape[1], 1
+    if workspace is None:
+        need = lib.afldm_conv2d_workspace(ctypes.byref(a))
+        if need:
+            workspace = torch.empty(need // 4, dtype=torch.float32, device=x1.device)
+            a.workspace, a.workspace_bytes = ptr(workspace), need
+    check(lib.afldm_conv2d(ctypes.byref(a), stream_ptr()), "conv2d")
+    return out
+
+
+def conv_workspace_bytes(a):
+    return lib.afldm_conv2d_workspace(ctypes.byref(a))
+
+
+def conv2d_launch(a):
+    check(lib.afldm_conv2d(ctypes.byref(a), stream_ptr()), "conv2d")
+
+
+# ----------------------------------------------------------------------------- attention
+def attention(q, k, vt, heads, scale=None, out=None):
+    """q [B,Tq,C], k [Bk,Tk,C] token-major; vt [Bk,C,Tk] channel-major; returns [B,Tq,C]."""
+    _dev(q, "q"); _dev(k, "k"); _dev(vt, "vt")
+    B, Tq, C = q.shape
+    Bk, Tk, _ = k.shape
+    d = C // heads
+    if scale is None:
+        scale = d ** -0.5
+    if out is None:
+        out = torch.empty_like(q)
+    check(lib.afldm_attention(ptr(q), C, ptr(k), C, ptr(vt), ptr(out), C, B, Bk, heads, Tq, Tk, d, float(scale),
+                              _code(q), stream_ptr()), "attention")
+    return out
+
+
+# ----------------------------------------------------------------------------- DDIM
+def ddim_step(x, eps_nhwc, coef, step_idx, advance=False, out=None):
+    """x NCHW fp32, eps NHWC dtype; coef float[4*nsteps] and step_idx int32[1] on device."""
+    _dev(x, "x"); _dev(eps_nhwc, "eps")
+    B, C, H, W = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.afldm_ddim_step(ptr(x), ptr(eps_nhwc), ptr(out), ptr(coef), ptr(step_idx), int(advance), B, C, H, W,
+                              _code(eps_nhwc), stream_ptr()), "ddim_step")
+    return out
+
+
+def select_timestep(tvals, step_idx, t_out):
+    check(lib.afldm_select_timestep(ptr(tvals), ptr(step_idx), ptr(t_out), stream_ptr()), "select_timestep")
+    return t_out

@@ -1,0 +1,172 @@
+/*
+ * afldm_hip.h — C ABI of libafldm_hip.so: the MI355X (gfx950) kernels behind the
+ * alias-free latent-diffusion denoising path of SingleZombie/AFLDM.
+ *
+ * The reference has NO native boundary on this path: its operator API is PyTorch
+ * nn.Module surgery (afldm/af_modules/af_api.py:70-83) over diffusers modules whose
+ * arithmetic is dispatched to cuDNN / cuBLAS / cuFFT / SDPA.  This header is the native
+ * layer a maintainer would bind underneath those modules; each entry point names the
+ * reference computation (file:line) it replaces.  See INTEGRATION.md for the ctypes
+ * binding that afldm_amd ships and the module-level hook a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer except `afldm_filter_matrix`'s output is a DEVICE pointer;
+ *   - activations are NHWC ("channels last"), contiguous, dtype AFLDM_F32 or AFLDM_BF16;
+ *     [B, H*W, C] token tensors for attention are the same memory;
+ *   - conv / linear weights are OHWI ([Cout][KH][KW][Cin]) in the activation dtype
+ *     (afldm_pack_weight converts from the reference's OIHW fp32 state-dict layout);
+ *     biases, GroupNorm affine parameters and statistics are fp32;
+ *   - all launches are stream-ordered on `stream` (a hipStream_t), never block, never
+ *     allocate; the caller owns every buffer (graph-capturable);
+ *   - return 0 on success, <0 = AFLDM_E*; afldm_last_error() gives the message of the last
+ *     failure on the calling thread.  No entry point aborts.
+ */
+#ifndef AFLDM_HIP_H
+#define AFLDM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* afldm_stream_t; /* hipStream_t */
+
+enum { AFLDM_F32 = 0, AFLDM_BF16 = 1 };
+enum {
+  AFLDM_OK = 0,
+  AFLDM_ESHAPE = -1,  /* unsupported / inconsistent shape */
+  AFLDM_EDTYPE = -2,  /* unknown dtype code */
+  AFLDM_EALIGN = -3,  /* pointer or leading dimension not 16-byte aligned */
+  AFLDM_ELAUNCH = -4, /* HIP launch error */
+  AFLDM_ENULL = -5    /* required pointer is NULL */
+};
+
+int afldm_version(void);
+const char* afldm_last_error(void);
+/* name[] receives gcnArchName; returns CU count (<0 on error). */
+int afldm_device_info(char* name, int name_len);
+
+/* ---- filter matrices (host) ------------------------------------------------------------
+ * Builds the dense separable form of the reference's FFT-domain ideal filters from the
+ * reference's mask rules (create_lpf_rect ideal_lpf.py:12-24, create_recon_rect :38-49):
+ *   kind 0: U  [up*N x N], UpsampleRFFT(up)(X) == U X U^T      (ideal_lpf.py:148-158)
+ *   kind 1: D  [N/2 x N],  LPF_RFFT(1/2)(Z)[::2,::2] == D Z D^T (ideal_lpf.py:69-93 + af_blocks.py:26)
+ * `out` is HOST memory, row-major fp32 (computed in fp64). */
+int afldm_filter_matrix(int kind, int N, int up, float* out);
+
+/* ---- layout / dtype plumbing ----------------------------------------------------------- */
+/* src NCHW fp32 -> dst NHWC dtype (latent entry, randn_tensor ldm_pipeline.py:82-88) */
+int afldm_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int dtype,
+                       afldm_stream_t stream);
+/* src NHWC dtype -> dst NCHW fp32 */
+int afldm_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int dtype,
+                       afldm_stream_t stream);
+/* OIHW fp32 (state-dict layout) -> OHWI dtype.  KH*KW == 1 covers nn.Linear [O][I]. */
+int afldm_pack_weight(const float* src, void* dst, int O, int I, int KH, int KW, int dtype,
+                      afldm_stream_t stream);
+/* dtype -> fp32 / fp32 -> dtype flat copies */
+int afldm_cast(const void* src, int src_dtype, void* dst, int dst_dtype, size_t n,
+               afldm_stream_t stream);
+
+/* ---- timestep embedding ----------------------------------------------------------------
+ * diffusers Timesteps / get_timestep_embedding as used by UNet2DModel.time_proj
+ * (config configs/ldm/model_unet.json:28-29): out[r, :] = [cos(t w_i) | sin(t w_i)] when
+ * flip_sin_to_cos, w_i = exp(-ln(10000) i / (dim/2 - freq_shift)).
+ * `t` points to `rows` device floats (the timestep values).  out: [rows, dim] dtype. */
+int afldm_timestep_embedding(const float* t, void* out, int rows, int dim, int flip_sin_to_cos,
+                             float freq_shift, int dtype, afldm_stream_t stream);
+
+/* y = silu(x), flat.  (TimestepEmbedding.act and ResnetBlock2D.nonlinearity on the 2-D temb:
+ * af_blocks.py:20-21 keeps plain SiLU for <4-D tensors.) */
+int afldm_silu(const void* x, void* y, size_t n, int dtype, afldm_stream_t stream);
+
+/* ---- GroupNorm ----------------------------------------------------------------------------
+ * torch.nn.GroupNorm(G, C, eps) over an NHWC tensor that is the virtual channel-concat of
+ * x1 [B,HW,C1] and x2 [B,HW,C2] (x2 may be NULL with C2 = 0): the up-block skip
+ * torch.cat([h, skip], 1) is never materialised.  stats: [B, G, 2] fp32 (mean, rstd). */
+int afldm_gn_stats(const void* x1, int C1, const void* x2, int C2, float* stats, int B, int HW,
+                   int G, float eps, int dtype, afldm_stream_t stream);
+/* y = act((x - mean) * rstd * gamma + beta); act: 0 none (Attention.group_norm),
+ * 1 SiLU (conv_norm_out + conv_act, which make_af_unet does NOT wrap: af_api.py:70-83). */
+int afldm_gn_apply(const void* x1, int C1, const void* x2, int C2, const float* stats,
+                   const float* gamma, const float* beta, void* y, int B, int HW, int G, int act,
+                   int dtype, afldm_stream_t stream);
+
+/* ---- alias-free operators -----------------------------------------------------------------
+ * afldm_af_act: [GroupNorm-apply ->] WarpedNonlinearity(SiLU) (af_blocks.py:19-28):
+ *   y = D silu(U xn U^T) D^T per (b, c) plane,  xn = GN-applied x when stats != NULL.
+ * x = virtual concat of x1/x2 as above, [B,N,N,C]; y [B,N,N,C].  N in {2,4,8,16,32}.
+ * U: [2N x N], D: [N x 2N] device fp32 matrices from afldm_filter_matrix(0,N,2) / (1,2N,.). */
+int afldm_af_act(const void* x1, int C1, const void* x2, int C2, const float* stats,
+                 const float* gamma, const float* beta, int G, const float* U, const float* D,
+                 void* y, int B, int N, int dtype, afldm_stream_t stream);
+/* UpsampleRFFT(2) of AliasFreeUpsample2D (af_blocks.py:92-93): [B,N,N,C] -> [B,2N,2N,C].
+ * workspace: device fp32 scratch of B*2N*N*C floats (row pass result). */
+int afldm_af_up2(const void* x, const float* U, void* y, float* workspace, int B, int N, int C,
+                 int dtype, afldm_stream_t stream);
+/* LPF_RFFT(1/2) + [::2,::2] of AliasFreeDownsample2D (af_blocks.py:149-150):
+ * [B,N,N,C] -> [B,N/2,N/2,C];  D: [N/2 x N];  workspace: B*(N/2)*N*C floats. */
+int afldm_af_lpf_down2(const void* x, const float* D, void* y, float* workspace, int B, int N, int C,
+                       int dtype, afldm_stream_t stream);
+
+/* ---- convolution / linear as implicit GEMM on MFMA --------------------------------------
+ * y[b,oh,ow,n] = bias[n] + temb[b*temb_stride + n] + residual[b,oh,ow,n]
+ *              + sum_{kh,kw,ci} x[b, oh+kh-KS/2, ow+kw-KS/2, ci] * w[n,kh,kw,ci]
+ * stride 1, zero padding KS/2, KS in {1,3}.  Replaces F.conv2d of ResnetBlock2D.conv1/conv2/
+ * conv_shortcut, Downsample2D.conv with stride forced to 1 (af_blocks.py:129), Upsample2D.conv,
+ * conv_in/conv_out, and nn.Linear (H = W = 1, B = rows) of Attention.to_q/k/v/to_out and the
+ * time MLP.  x is the virtual concat of x1/x2.  out_mode 0: y NHWC with leading dim y_ld
+ * (>= Cout, lets several GEMMs write column slices of one buffer); out_mode 1: channel-major
+ * y[(b*Cout + n)*H*W + pix] (V^T for afldm_attention). */
+typedef struct {
+  const void* x1;
+  const void* x2;
+  const void* w;
+  const float* bias;
+  const void* temb;     /* dtype T, may be NULL */
+  const void* residual; /* dtype T, [B*H*W][res_ld], may be NULL */
+  void* y;
+  void* workspace; /* fp32 split-K slabs, may be NULL (=> no split-K) */
+  size_t workspace_bytes;
+  int C1, C2;
+  int B, H, W, Cout, KS;
+  int temb_stride; /* elements between samples in temb (0 = broadcast one row) */
+  int res_ld, y_ld;
+  int out_mode;
+  int dtype;
+} afldm_conv_args;
+int afldm_conv2d(const afldm_conv_args* args, afldm_stream_t stream);
+/* bytes of split-K workspace afldm_conv2d may use for this problem (0 if none). */
+size_t afldm_conv2d_workspace(const afldm_conv_args* args);
+
+/* ---- attention ---------------------------------------------------------------------------
+ * F.scaled_dot_product_attention as called by AttnProcessor2_0 / CrossFrameAttnProcessor
+ * (cross_frame_attn.py:125,128): o = softmax(q k^T * scale) v per (batch, head).
+ * q [B,Tq,ldq] k [Bk,Tk,ldk] token-major with head h at columns [h*d, (h+1)*d);
+ * vt [Bk, heads*d, Tk] channel-major (written by afldm_conv2d out_mode 1); o [B,Tq,ldo].
+ * Bk divides B: sample b reads K/V of kv-sample b / (B/Bk)  (the batch repeat of
+ * cross_frame_attn.py:91-96). */
+int afldm_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, void* o, int ldo,
+                    int B, int Bk, int heads, int Tq, int Tk, int d, float scale, int dtype,
+                    afldm_stream_t stream);
+
+/* ---- DDIM update -------------------------------------------------------------------------
+ * DDIMScheduler.step, eta = 0, epsilon prediction, no clipping:
+ *   x0 = (x - sqrt(1-a_t) eps) / sqrt(a_t);  x_prev = sqrt(a_prev) x0 + sqrt(1-a_prev) eps
+ * coef: device float[4*nsteps] rows (sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev));
+ * step_idx: device int, row to use; if advance != 0 the kernel increments it afterwards (so
+ * a captured hipGraph of one step can be replayed 50x with no host involvement).
+ * x, x_prev: NCHW fp32 latents [B,C,H,W]; eps: NHWC dtype (the UNet output layout). */
+int afldm_ddim_step(const float* x, const void* eps, float* x_prev, const float* coef,
+                    int* step_idx, int advance, int B, int C, int H, int W, int dtype,
+                    afldm_stream_t stream);
+/* tvals[step] -> t_out[0] (device->device), so the timestep also follows step_idx. */
+int afldm_select_timestep(const float* tvals, const int* step_idx, float* t_out,
+                          afldm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFLDM_HIP_H */
