@@ -48,10 +48,12 @@ def _load():
         "afldm_af_act": ([vp, ip, vp, ip, vp, vp, vp, ip, vp, vp, vp, ip, ip, ip, vp], c_int),
         "afldm_af_up2": ([vp, vp, vp, vp, ip, ip, ip, ip, vp], c_int),
         "afldm_af_lpf_down2": ([vp, vp, vp, vp, ip, ip, ip, ip, vp], c_int),
+        "afldm_af_resample": ([vp, vp, vp, vp, ip, ip, ip, ip, ip, vp], c_int),
         "afldm_conv2d": ([POINTER(ConvArgs), vp], c_int),
         "afldm_conv2d_workspace": ([POINTER(ConvArgs)], c_size_t),
         "afldm_attention": ([vp, ip, vp, ip, vp, vp, ip, ip, ip, ip, ip, ip, ip, fp, ip, vp], c_int),
         "afldm_ddim_step": ([vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, vp], c_int),
+        "afldm_ddim_step_flat": ([vp, vp, vp, fp, fp, fp, fp, c_size_t, vp], c_int),
         "afldm_select_timestep": ([vp, vp, vp, vp], c_int),
     }
     for name, (argtypes, restype) in sigs.items():
@@ -75,8 +77,8 @@ def check(rc, what=""):
 
 
 def filter_matrix(kind: int, N: int, up: int = 2) -> torch.Tensor:
-    """Host fp32 matrix: kind 0 -> U [up*N, N]; kind 1 -> D [N/2, N]."""
-    rows, cols = (up * N, N) if kind == 0 else (N // 2, N)
+    """Host fp32 matrix: kind 0 -> U [up*N, N]; kind 1 -> D [N/2, N]; kind 2 -> L [N, N]."""
+    rows, cols = {0: (up * N, N), 1: (N // 2, N), 2: (N, N)}[kind]
     buf = (c_float * (rows * cols))()
     check(lib.afldm_filter_matrix(kind, N, up, buf), "afldm_filter_matrix")
     return torch.frombuffer(buf, dtype=torch.float32).clone().reshape(rows, cols)

@@ -1,0 +1,68 @@
+"""Alias-free blocks — module surface of reference afldm/af_modules/af_blocks.py
+(WarpedNonlinearity :12-28, AliasFreeUpsample2D :45-106, AliasFreeDownsample2D :109-152),
+executing on the HIP kernels of libafldm_hip.so.
+
+Inside a UNet forward these modules see NHWC tensors (see models/blocks.py).  Note that
+ResnetBlock2D fuses GroupNorm + WarpedNonlinearity into one kernel when its `nonlinearity` is a
+WarpedNonlinearity, so `WarpedNonlinearity.forward` itself only runs for stand-alone use.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..af_libs.ideal_lpf import LPF_RFFT, UpsampleRFFT  # noqa: F401  (re-exported like the reference)
+from ..models.blocks import Downsample2D, Upsample2D, conv_forward
+
+
+class WarpedNonlinearity(nn.Module):
+    def __init__(self, nonlinearity):
+        super().__init__()
+        if not isinstance(nonlinearity, nn.SiLU):
+            raise NotImplementedError("the fused alias-free activation kernel implements SiLU "
+                                      "(the only activation of the AF-LDM UNet / VAE configs)")
+        self.up_layer = UpsampleRFFT()
+        self.lpf = LPF_RFFT(1 / 2)
+        self.nonlinearity = nonlinearity
+
+    def forward(self, x):
+        """x: NHWC [B, N, N, C] (internal layout) or a <4-D tensor (plain SiLU, af_blocks.py:20-21)."""
+        if x.ndim < 4:
+            return ops.silu(x)
+        return ops.af_act(x)
+
+
+class AliasFreeUpsample2D(Upsample2D):
+    def __init__(self, channels, use_conv=False, use_conv_transpose=False, out_channels=None, name="conv",
+                 kernel_size=None, padding=1, norm_type=None, eps=None, elementwise_affine=None, bias=True,
+                 interpolate=True, ori_conv=None):
+        super().__init__(channels, use_conv, use_conv_transpose, out_channels, name, kernel_size, padding, norm_type,
+                         eps, elementwise_affine, bias, interpolate)
+        self.up_layer = UpsampleRFFT()
+        self.conv = ori_conv
+
+    def forward(self, hidden_states, output_size=None, *args, **kwargs):
+        assert hidden_states.shape[-1] == self.channels          # NHWC
+        if self.interpolate:
+            hidden_states = ops.af_up2(hidden_states)            # filters stay fp32-accumulated in any dtype
+        if self.use_conv:
+            hidden_states = conv_forward(self.conv if self.name == "conv" else self.Conv2d_0, hidden_states)
+        return hidden_states
+
+
+class AliasFreeDownsample2D(Downsample2D):
+    def __init__(self, channels, use_conv=False, out_channels=None, padding=1, name="conv", kernel_size=3,
+                 norm_type=None, eps=None, elementwise_affine=None, bias=True, ori_conv=None):
+        super().__init__(channels, use_conv, out_channels, padding, name, kernel_size, norm_type, eps,
+                         elementwise_affine, bias)
+        self.conv = ori_conv
+        self.conv.stride = 1           # reference af_blocks.py:129: the stride-2 conv runs at stride 1
+        self.lpf = LPF_RFFT()
+        if getattr(self, "Conv2d_0", None) is not None:
+            self.Conv2d_0 = None
+
+    def forward(self, hidden_states, *args, **kwargs):
+        assert hidden_states.shape[-1] == self.channels          # NHWC
+        if self.use_conv and self.padding == 0:
+            raise NotImplementedError("padding=0 (VAE encoder) downsampler: AF-VAE is a 'next' row (SURVEY 8f)")
+        hidden_states = conv_forward(self.conv, hidden_states)
+        return ops.af_lpf_down2(hidden_states)

@@ -452,3 +452,14 @@ extern "C" int afldm_af_lpf_down2(const void* x, const float* D, void* y, float*
   set_error("afldm_af_lpf_down2: unknown dtype %d", dtype);
   return AFLDM_EDTYPE;
 }
+
+extern "C" int afldm_af_resample(const void* x, const float* M, void* y, float* workspace, int B, int N, int C, int R,
+                                 int dtype, afldm_stream_t stream) {
+  AFLDM_REQUIRE(x && M && y && workspace, AFLDM_ENULL, "afldm_af_resample: NULL pointer");
+  AFLDM_REQUIRE(B > 0 && N > 0 && C > 0 && R > 0, AFLDM_ESHAPE, "afldm_af_resample: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == AFLDM_F32) return resample_dispatch<float>(x, M, y, workspace, B, N, C, R, st);
+  if (dtype == AFLDM_BF16) return resample_dispatch<bf16>(x, M, y, workspace, B, N, C, R, st);
+  set_error("afldm_af_resample: unknown dtype %d", dtype);
+  return AFLDM_EDTYPE;
+}

@@ -99,6 +99,16 @@ extern "C" int afldm_filter_matrix(int kind, int N, int up, float* out) {
       for (int j = 0; j < N; ++j) out[(size_t)i * N + j] = (float)h[((2 * i - j) % N + N) % N];
     return AFLDM_OK;
   }
+  if (kind == 2) {  // L [N x N] = C(lpf(N, 1/2))
+    AFLDM_REQUIRE(N >= 2, AFLDM_ESHAPE, "afldm_filter_matrix: LPF plane size %d too small", N);
+    const int lo = (int)floor((N * 0.5) / 2.0);
+    AFLDM_REQUIRE(!(N % 4 == 0 && lo == 0), AFLDM_ESHAPE, "afldm_filter_matrix: N=%d has no valid LPF mask", N);
+    mask_1d(N, 0.5, false, mask);
+    impulse_response(mask, h);
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < N; ++j) out[(size_t)i * N + j] = (float)h[((i - j) % N + N) % N];
+    return AFLDM_OK;
+  }
   set_error("afldm_filter_matrix: unknown kind %d", kind);
   return AFLDM_ESHAPE;
 }

@@ -206,3 +206,27 @@ extern "C" int afldm_select_timestep(const float* tvals, const int* step_idx, fl
   k_select_timestep<<<1, 1, 0, (hipStream_t)stream>>>(tvals, step_idx, t_out);
   return check_launch("afldm_select_timestep");
 }
+
+// Same update with the four coefficients passed by value and flat fp32 tensors (the
+// DDIMScheduler.step(model_output, t, sample) API path, where both tensors are NCHW fp32).
+__global__ void k_ddim_step_flat(const float* __restrict__ x, const float* __restrict__ eps,
+                                 float* __restrict__ xprev, float sa_t, float sb_t, float sa_p, float sb_p,
+                                 size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float e = eps[i];
+    float x0 = (x[i] - sb_t * e) / sa_t;
+    xprev[i] = sa_p * x0 + sb_p * e;
+  }
+}
+
+extern "C" int afldm_ddim_step_flat(const float* x, const float* eps, float* x_prev, float sqrt_a_t,
+                                    float sqrt_1m_a_t, float sqrt_a_prev, float sqrt_1m_a_prev, size_t n,
+                                    afldm_stream_t stream) {
+  AFLDM_REQUIRE(x && eps && x_prev, AFLDM_ENULL, "afldm_ddim_step_flat: NULL pointer");
+  if (n == 0) return AFLDM_OK;
+  size_t g = (n + 255) / 256;
+  if (g > 2048) g = 2048;
+  k_ddim_step_flat<<<(int)g, 256, 0, (hipStream_t)stream>>>(x, eps, x_prev, sqrt_a_t, sqrt_1m_a_t, sqrt_a_prev,
+                                                            sqrt_1m_a_prev, n);
+  return check_launch("afldm_ddim_step_flat");
+}

@@ -1,0 +1,389 @@
+"""diffusers-compatible building blocks of UNet2DModel, executing on libafldm_hip.so.
+
+Constructor arguments, attribute names and state-dict keys follow diffusers 0.32.1 (the
+package the reference builds on: reference afldm/af_modules/af_blocks.py:6-7,
+afldm/pipelines/cross_frame_attn.py:3), so unmodified diffusers checkpoints load and the
+reference's module surgery (af_api.py) applies as-is.
+
+INTERNAL TENSOR CONVENTION: inside a UNet forward every activation is an NHWC ("channels
+last") contiguous CUDA tensor [B, H, W, C] in the model dtype — the layout the MFMA implicit
+GEMM, the attention kernel ([B, HW, C] is the same memory) and the alias-free kernels want.
+`UNet2DModel.forward` converts from/to the public NCHW layout at its boundary.  A "virtual
+concat" (the up-block skip torch.cat) is passed around as a tuple (x1, x2) and resolved inside
+the kernels (two base pointers), never materialised.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+def _pair(x):
+    return x if isinstance(x, tuple) else (x, None)
+
+
+class PackedMixin:
+    """Caches kernel-ready copies of parameters (OHWI weights in the activation dtype, fp32
+    biases / affine params).  Invalidated by _apply (.to / .cuda / .half ...) and load_state_dict."""
+
+    def _packed(self, key, build):
+        cache = self.__dict__.setdefault("_afldm_cache", {})
+        if key not in cache:
+            cache[key] = build()
+        return cache[key]
+
+    def _invalidate(self):
+        self.__dict__.pop("_afldm_cache", None)
+
+
+def invalidate_packed(module: nn.Module):
+    for m in module.modules():
+        m.__dict__.pop("_afldm_cache", None)
+
+
+def packed_conv(mod, dtype):
+    """(OHWI weight in `dtype`, fp32 bias) for an nn.Conv2d / nn.Linear, cached on the module."""
+    cache = mod.__dict__.setdefault("_afldm_cache", {})
+    key = ("w", dtype)
+    if key not in cache:
+        w = ops.pack_weight(mod.weight, dtype)
+        b = None if mod.bias is None else mod.bias.detach().to(torch.float32).contiguous()
+        cache[key] = (w, b)
+    return cache[key]
+
+
+def packed_norm(mod):
+    cache = mod.__dict__.setdefault("_afldm_cache", {})
+    if "gn" not in cache:
+        cache["gn"] = (mod.weight.detach().to(torch.float32).contiguous(),
+                       mod.bias.detach().to(torch.float32).contiguous())
+    return cache["gn"]
+
+
+def conv_forward(conv: nn.Conv2d, x, **kw):
+    """F.conv2d(x, conv.weight, conv.bias, stride 1, 'same') on NHWC (or a virtual concat)."""
+    x1, x2 = _pair(x)
+    w, b = packed_conv(conv, x1.dtype)
+    return ops.conv2d(x1, w, b, x2=x2, **kw)
+
+
+def linear_forward(lin: nn.Linear, x, **kw):
+    w, b = packed_conv(lin, x.dtype)
+    return ops.conv2d(x, w, b, **kw)
+
+
+# ----------------------------------------------------------------------------- embeddings
+class Timesteps(nn.Module):
+    def __init__(self, num_channels, flip_sin_to_cos, downscale_freq_shift):
+        super().__init__()
+        self.num_channels = num_channels
+        self.flip_sin_to_cos = flip_sin_to_cos
+        self.downscale_freq_shift = downscale_freq_shift
+
+    def forward(self, timesteps, dtype=torch.float32):
+        """timesteps: device float32 [rows] -> [rows, num_channels] in `dtype`."""
+        return ops.timestep_embedding(timesteps, self.num_channels, self.flip_sin_to_cos,
+                                      float(self.downscale_freq_shift), dtype)
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_channels, time_embed_dim, act_fn="silu"):
+        super().__init__()
+        assert act_fn == "silu"
+        self.linear_1 = nn.Linear(in_channels, time_embed_dim)
+        self.act = nn.SiLU()
+        self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
+
+    def forward(self, sample):
+        h = linear_forward(self.linear_1, sample)
+        h = ops.silu(h)
+        return linear_forward(self.linear_2, h)
+
+
+# ----------------------------------------------------------------------------- resampling
+class Downsample2D(nn.Module):
+    """diffusers.models.downsampling.Downsample2D (conv variant, stride 2).  The vanilla
+    stride-2 path is not on the alias-free hot path: only AliasFreeDownsample2D executes."""
+
+    def __init__(self, channels, use_conv=False, out_channels=None, padding=1, name="conv", kernel_size=3,
+                 norm_type=None, eps=None, elementwise_affine=None, bias=True):
+        super().__init__()
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.use_conv = use_conv
+        self.padding = padding
+        self.name = name
+        self.norm = None
+        assert norm_type is None, "norm_type is not used by the FFHQ / AF-VAE configs"
+        if use_conv:
+            conv = nn.Conv2d(self.channels, self.out_channels, kernel_size=kernel_size, stride=2, padding=padding,
+                             bias=bias)
+        else:
+            assert self.channels == self.out_channels
+            conv = nn.AvgPool2d(kernel_size=2, stride=2)
+        if name == "conv":
+            self.Conv2d_0 = conv
+            self.conv = conv
+        elif name == "Conv2d_0":
+            self.conv = conv
+        else:
+            self.conv = conv
+
+    def forward(self, hidden_states, *args, **kwargs):
+        raise NotImplementedError(
+            "afldm_amd executes the alias-free model only: call make_af_unet(unet) "
+            "(afldm.af_modules.af_api) before running; the strided Downsample2D has no HIP path")
+
+
+class Upsample2D(nn.Module):
+    """diffusers.models.upsampling.Upsample2D (nearest x2 + conv).  See Downsample2D."""
+
+    def __init__(self, channels, use_conv=False, use_conv_transpose=False, out_channels=None, name="conv",
+                 kernel_size=None, padding=1, norm_type=None, eps=None, elementwise_affine=None, bias=True,
+                 interpolate=True):
+        super().__init__()
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.use_conv = use_conv
+        self.use_conv_transpose = use_conv_transpose
+        self.name = name
+        self.interpolate = interpolate
+        self.norm = None
+        assert norm_type is None and not use_conv_transpose
+        conv = None
+        if use_conv:
+            if kernel_size is None:
+                kernel_size = 3
+            conv = nn.Conv2d(self.channels, self.out_channels, kernel_size=kernel_size, padding=padding, bias=bias)
+        if name == "conv":
+            self.conv = conv
+        else:
+            self.Conv2d_0 = conv
+
+    def forward(self, hidden_states, output_size=None, *args, **kwargs):
+        raise NotImplementedError(
+            "afldm_amd executes the alias-free model only: call make_af_unet(unet) first; the "
+            "nearest-neighbour Upsample2D has no HIP path")
+
+
+# ----------------------------------------------------------------------------- resnet
+class ResnetBlock2D(nn.Module):
+    """diffusers ResnetBlock2D (time_embedding_norm='default', no up/down, output_scale 1).
+
+    forward(x, temb_proj): `temb_proj` is this block's slice [rows, out_channels] of the
+    batched time_emb_proj GEMM computed once per step by UNet2DModel (rows = 1 broadcast or B),
+    i.e. time_emb_proj(nonlinearity(emb)) of the reference forward."""
+
+    def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout=0.0, temb_channels=512,
+                 groups=32, groups_out=None, pre_norm=True, eps=1e-6, non_linearity="swish",
+                 time_embedding_norm="default", output_scale_factor=1.0, use_in_shortcut=None):
+        super().__init__()
+        assert time_embedding_norm == "default" and output_scale_factor == 1.0
+        self.in_channels = in_channels
+        out_channels = in_channels if out_channels is None else out_channels
+        self.out_channels = out_channels
+        self.output_scale_factor = output_scale_factor
+        self.time_embedding_norm = time_embedding_norm
+        groups_out = groups if groups_out is None else groups_out
+        self.norm1 = nn.GroupNorm(num_groups=groups, num_channels=in_channels, eps=eps, affine=True)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        self.time_emb_proj = nn.Linear(temb_channels, out_channels) if temb_channels is not None else None
+        self.norm2 = nn.GroupNorm(num_groups=groups_out, num_channels=out_channels, eps=eps, affine=True)
+        self.dropout = nn.Dropout(dropout)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        self.nonlinearity = nn.SiLU()
+        self.upsample = self.downsample = None
+        self.use_in_shortcut = self.in_channels != out_channels if use_in_shortcut is None else use_in_shortcut
+        self.conv_shortcut = None
+        if self.use_in_shortcut:
+            self.conv_shortcut = nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0, bias=True)
+
+    def _norm_act(self, norm, x):
+        """norm -> self.nonlinearity fused: GroupNorm statistics, then either the fused
+        GN + WarpedNonlinearity kernel (alias-free model) or GN + SiLU."""
+        from ..af_modules.af_blocks import WarpedNonlinearity
+        x1, x2 = _pair(x)
+        gamma, beta = packed_norm(norm)
+        stats = ops.gn_stats(x1, norm.num_groups, norm.eps, x2=x2)
+        if isinstance(self.nonlinearity, WarpedNonlinearity):
+            return ops.af_act(x1, x2, stats, gamma, beta, norm.num_groups)
+        return ops.gn_apply(x1, stats, gamma, beta, norm.num_groups, act=1, x2=x2)
+
+    def forward(self, input_tensor, temb_proj=None, temb_stride=0):
+        x1, x2 = _pair(input_tensor)
+        h = self._norm_act(self.norm1, input_tensor)
+        h = conv_forward(self.conv1, h, temb=temb_proj, temb_stride=temb_stride)
+        h = self._norm_act(self.norm2, h)
+        if self.conv_shortcut is not None:
+            res = conv_forward(self.conv_shortcut, input_tensor)
+        else:
+            assert x2 is None
+            res = x1
+        return conv_forward(self.conv2, h, residual=res)
+
+
+# ----------------------------------------------------------------------------- attention
+class AttnProcessor2_0:
+    """diffusers AttnProcessor2_0 for the self-attention 'attn block' configuration
+    (residual_connection=True, rescale_output_factor=1), on NHWC tensors.
+
+    encoder_hidden_states, when given, is the already group-normed K/V source [Bk, HW, C]
+    (the protocol CrossFrameAttnProcessor uses, reference cross_frame_attn.py:125)."""
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None):
+        assert attention_mask is None
+        B, H, W, C = hidden_states.shape
+        gamma, beta = packed_norm(attn.group_norm)
+        stats = ops.gn_stats(hidden_states, attn.group_norm.num_groups, attn.group_norm.eps)
+        hn = ops.gn_apply(hidden_states, stats, gamma, beta, attn.group_norm.num_groups, act=0)
+        tokens = hn.view(B, H * W, C)
+        src = tokens if encoder_hidden_states is None else encoder_hidden_states
+        q = linear_forward(attn.to_q, tokens)
+        k = linear_forward(attn.to_k, src)
+        vt = linear_forward(attn.to_v, src, out_mode=1)            # [Bk, C, T] channel-major
+        o = ops.attention(q, k, vt, attn.heads, scale=attn.scale)
+        out = linear_forward(attn.to_out[0], o, residual=hidden_states.view(B, H * W, C))
+        return out.view(B, H, W, C)
+
+
+class Attention(nn.Module):
+    """diffusers.models.attention_processor.Attention restricted to what UNet2DModel's attention
+    blocks use (self-attention, group_norm, bias, residual connection)."""
+
+    def __init__(self, query_dim, heads=8, dim_head=64, rescale_output_factor=1.0, eps=1e-5, norm_num_groups=None,
+                 residual_connection=False, bias=False, upcast_softmax=False, _from_deprecated_attn_block=False,
+                 processor=None, **unused):
+        super().__init__()
+        assert rescale_output_factor == 1.0
+        self.inner_dim = dim_head * heads
+        self.query_dim = query_dim
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+        self.rescale_output_factor = rescale_output_factor
+        self.residual_connection = residual_connection
+        self.norm_cross = None
+        self.spatial_norm = None
+        self.group_norm = (nn.GroupNorm(num_channels=query_dim, num_groups=norm_num_groups, eps=eps, affine=True)
+                           if norm_num_groups is not None else None)
+        self.to_q = nn.Linear(query_dim, self.inner_dim, bias=bias)
+        self.to_k = nn.Linear(query_dim, self.inner_dim, bias=bias)
+        self.to_v = nn.Linear(query_dim, self.inner_dim, bias=bias)
+        self.to_out = nn.ModuleList([nn.Linear(self.inner_dim, query_dim, bias=True), nn.Dropout(0.0)])
+        self.processor = processor if processor is not None else AttnProcessor2_0()
+
+    def set_processor(self, processor):
+        self.processor = processor
+
+    def get_processor(self, return_deprecated_lora=False):
+        return self.processor
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kwargs):
+        return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
+                              attention_mask=attention_mask, **kwargs)
+
+
+# ----------------------------------------------------------------------------- UNet blocks
+class _BlockBase(nn.Module):
+    def _resnets(self, in_cs, out_c, temb_channels, eps, groups, dropout):
+        return nn.ModuleList([
+            ResnetBlock2D(in_channels=c, out_channels=out_c, temb_channels=temb_channels, eps=eps, groups=groups,
+                          dropout=dropout) for c in in_cs])
+
+    def _attns(self, n, c, head_dim, eps, groups):
+        return nn.ModuleList([
+            Attention(c, heads=c // head_dim, dim_head=head_dim, eps=eps, norm_num_groups=groups,
+                      residual_connection=True, bias=True, upcast_softmax=True, _from_deprecated_attn_block=True)
+            for _ in range(n)])
+
+
+class DownBlock2D(_BlockBase):
+    has_attention = False
+
+    def __init__(self, in_channels, out_channels, temb_channels, num_layers=1, resnet_eps=1e-6, resnet_groups=32,
+                 dropout=0.0, add_downsample=True, downsample_padding=1, attention_head_dim=1):
+        super().__init__()
+        self.resnets = self._resnets([in_channels if i == 0 else out_channels for i in range(num_layers)],
+                                     out_channels, temb_channels, resnet_eps, resnet_groups, dropout)
+        if self.has_attention:
+            self.attentions = self._attns(num_layers, out_channels, attention_head_dim, resnet_eps, resnet_groups)
+        self.downsamplers = (nn.ModuleList([Downsample2D(out_channels, use_conv=True, out_channels=out_channels,
+                                                         padding=downsample_padding, name="op")])
+                             if add_downsample else None)
+
+    def forward(self, hidden_states, temb_slices):
+        outs = ()
+        for i, resnet in enumerate(self.resnets):
+            hidden_states = resnet(hidden_states, *temb_slices[i])
+            if self.has_attention:
+                hidden_states = self.attentions[i](hidden_states)
+            outs += (hidden_states,)
+        if self.downsamplers is not None:
+            for d in self.downsamplers:
+                hidden_states = d(hidden_states)
+            outs += (hidden_states,)
+        return hidden_states, outs
+
+
+class AttnDownBlock2D(DownBlock2D):
+    has_attention = True
+
+
+class UNetMidBlock2D(_BlockBase):
+    def __init__(self, in_channels, temb_channels, dropout=0.0, num_layers=1, resnet_eps=1e-6, resnet_groups=32,
+                 attn_groups=None, add_attention=True, attention_head_dim=1):
+        super().__init__()
+        self.add_attention = add_attention
+        if attn_groups is None:
+            attn_groups = resnet_groups
+        self.resnets = self._resnets([in_channels] * (num_layers + 1), in_channels, temb_channels, resnet_eps,
+                                     resnet_groups, dropout)
+        self.attentions = (self._attns(num_layers, in_channels, attention_head_dim, resnet_eps, attn_groups)
+                           if add_attention else nn.ModuleList([None] * num_layers))
+
+    def forward(self, hidden_states, temb_slices):
+        hidden_states = self.resnets[0](hidden_states, *temb_slices[0])
+        for i, (attn, resnet) in enumerate(zip(self.attentions, self.resnets[1:])):
+            if attn is not None:
+                hidden_states = attn(hidden_states)
+            hidden_states = resnet(hidden_states, *temb_slices[i + 1])
+        return hidden_states
+
+
+class UpBlock2D(_BlockBase):
+    has_attention = False
+
+    def __init__(self, in_channels, prev_output_channel, out_channels, temb_channels, num_layers=1, resnet_eps=1e-6,
+                 resnet_groups=32, dropout=0.0, add_upsample=True, attention_head_dim=1):
+        super().__init__()
+        in_cs = []
+        for i in range(num_layers):
+            res_skip = in_channels if (i == num_layers - 1) else out_channels
+            rin = prev_output_channel if i == 0 else out_channels
+            in_cs.append(rin + res_skip)
+        self.resnets = self._resnets(in_cs, out_channels, temb_channels, resnet_eps, resnet_groups, dropout)
+        if self.has_attention:
+            self.attentions = self._attns(num_layers, out_channels, attention_head_dim, resnet_eps, resnet_groups)
+        self.upsamplers = (nn.ModuleList([Upsample2D(out_channels, use_conv=True, out_channels=out_channels)])
+                           if add_upsample else None)
+
+    def forward(self, hidden_states, res_hidden_states_tuple, temb_slices):
+        for i, resnet in enumerate(self.resnets):
+            res = res_hidden_states_tuple[-1]
+            res_hidden_states_tuple = res_hidden_states_tuple[:-1]
+            hidden_states = resnet((hidden_states, res), *temb_slices[i])      # virtual torch.cat([h, res], 1)
+            if self.has_attention:
+                hidden_states = self.attentions[i](hidden_states)
+        if self.upsamplers is not None:
+            for u in self.upsamplers:
+                hidden_states = u(hidden_states)
+        return hidden_states
+
+
+class AttnUpBlock2D(UpBlock2D):
+    has_attention = True
+
+
+DOWN_BLOCKS = {"DownBlock2D": DownBlock2D, "AttnDownBlock2D": AttnDownBlock2D}
+UP_BLOCKS = {"UpBlock2D": UpBlock2D, "AttnUpBlock2D": AttnUpBlock2D}

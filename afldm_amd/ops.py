@@ -10,6 +10,51 @@ from . import _lib
 from ._lib import ConvArgs, DTYPE_CODE, check, lib, ptr, stream_ptr
 
 _FILTER_CACHE = {}
+_PROFILE = None
+
+
+class Profiler:
+    """Per-op HIP-event timing on the launch stream (bench.py's roofline leg).  Records, per
+    wrapper call, the kernel family, its ALGORITHMIC flops / bytes and two events around it."""
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        global _PROFILE
+        _PROFILE = self
+        return self
+
+    def __exit__(self, *a):
+        global _PROFILE
+        _PROFILE = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for kind, flops, nbytes, e0, e1 in self.records:
+            d = agg.setdefault(kind, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return agg
+
+
+def _begin():
+    if _PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _end(tok, kind, flops=0.0, nbytes=0.0):
+    if tok is None:
+        return
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    _PROFILE.records.append((kind, float(flops), float(nbytes), tok, e))
 
 
 def _dev(t, name="tensor"):
@@ -124,8 +169,10 @@ def gn_stats(x1, G, eps, x2=None, out=None):
     HW = x1.numel() // (B * C1)
     if out is None:
         out = torch.empty((B, G, 2), dtype=torch.float32, device=x1.device)
+    tok = _begin()
     check(lib.afldm_gn_stats(ptr(x1), C1, ptr(x2), C2, ptr(out), B, HW, G, float(eps), _code(x1), stream_ptr()),
           "gn_stats")
+    _end(tok, "gn_stats", 0, B * HW * (C1 + C2) * x1.element_size())
     return out
 
 
@@ -135,8 +182,10 @@ def gn_apply(x1, stats, gamma, beta, G, act=0, x2=None, out=None):
     HW = x1.numel() // (B * C1)
     if out is None:
         out = torch.empty(tuple(x1.shape[:-1]) + (C1 + C2,), dtype=x1.dtype, device=x1.device)
+    tok = _begin()
     check(lib.afldm_gn_apply(ptr(x1), C1, ptr(x2), C2, ptr(stats), ptr(gamma), ptr(beta), ptr(out), B, HW, G,
                              int(act), _code(x1), stream_ptr()), "gn_apply")
+    _end(tok, "gn_apply", 0, 2 * B * HW * (C1 + C2) * x1.element_size())
     return out
 
 
@@ -149,8 +198,11 @@ def af_act(x1, x2=None, stats=None, gamma=None, beta=None, G=0, out=None):
     U, D = filter_matrices(N, x1.device)
     if out is None:
         out = torch.empty((B, N, N, C1 + C2), dtype=x1.dtype, device=x1.device)
+    tok = _begin()
     check(lib.afldm_af_act(ptr(x1), C1, ptr(x2), C2, ptr(stats), ptr(gamma), ptr(beta), int(G), ptr(U), ptr(D),
                            ptr(out), B, N, _code(x1), stream_ptr()), "af_act")
+    # dense separable form: 24 N^3 flop per plane; one read + one write of the tensor
+    _end(tok, f"af_act_N{N}", 24.0 * N ** 3 * B * (C1 + C2), 2 * B * N * N * (C1 + C2) * x1.element_size())
     return out
 
 
@@ -164,7 +216,9 @@ def af_up2(x, out=None, workspace=None):
     if workspace is None:
         workspace = torch.empty(B * 2 * N * N * C, dtype=torch.float32, device=x.device)
     assert workspace.numel() >= B * 2 * N * N * C
+    tok = _begin()
     check(lib.afldm_af_up2(ptr(x), ptr(U), ptr(out), ptr(workspace), B, N, C, _code(x), stream_ptr()), "af_up2")
+    _end(tok, "af_up2", 12.0 * N ** 3 * B * C, 5 * B * N * N * C * x.element_size())
     return out
 
 
@@ -178,8 +232,32 @@ def af_lpf_down2(x, out=None, workspace=None):
     if workspace is None:
         workspace = torch.empty(B * (N // 2) * N * C, dtype=torch.float32, device=x.device)
     assert workspace.numel() >= B * (N // 2) * N * C
+    tok = _begin()
     check(lib.afldm_af_lpf_down2(ptr(x), ptr(D), ptr(out), ptr(workspace), B, N, C, _code(x), stream_ptr()),
           "af_lpf_down2")
+    _end(tok, "af_lpf_down2", 1.5 * N ** 3 * B * C, 1.25 * B * N * N * C * x.element_size())
+    return out
+
+
+def lpf_matrix(N, device):
+    key = ("lpf", N, str(device))
+    if key not in _FILTER_CACHE:
+        _FILTER_CACHE[key] = _lib.filter_matrix(2, N).to(device)
+    return _FILTER_CACHE[key]
+
+
+def af_resample(x, M, out=None, workspace=None):
+    """y = M x M^T per plane: [B,N,N,C] -> [B,R,R,C] with M [R,N] device fp32."""
+    _dev(x, "x")
+    B, N, N2, C = x.shape
+    assert N == N2 and M.shape[1] == N
+    R = M.shape[0]
+    if out is None:
+        out = torch.empty((B, R, R, C), dtype=x.dtype, device=x.device)
+    if workspace is None:
+        workspace = torch.empty(B * R * N * C, dtype=torch.float32, device=x.device)
+    check(lib.afldm_af_resample(ptr(x), ptr(M), ptr(out), ptr(workspace), B, N, C, R, _code(x), stream_ptr()),
+          "af_resample")
     return out
 
 
@@ -229,7 +307,14 @@ def conv2d(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, o
         if need:
             workspace = torch.empty(need // 4, dtype=torch.float32, device=x1.device)
             a.workspace, a.workspace_bytes = ptr(workspace), need
+    tok = _begin()
     check(lib.afldm_conv2d(ctypes.byref(a), stream_ptr()), "conv2d")
+    if tok is not None:
+        M, Ct = a.B * a.H * a.W, a.C1 + a.C2
+        es = x1.element_size()
+        kind = "conv3x3" if a.KS == 3 else ("conv1x1" if a.H * a.W > 1 and x1.ndim == 4 else "linear")
+        _end(tok, kind, 2.0 * M * a.Cout * a.KS * a.KS * Ct,
+             (M * Ct + a.Cout * a.KS * a.KS * Ct + M * a.Cout) * es)
     return out
 
 
@@ -252,8 +337,10 @@ def attention(q, k, vt, heads, scale=None, out=None):
         scale = d ** -0.5
     if out is None:
         out = torch.empty_like(q)
+    tok = _begin()
     check(lib.afldm_attention(ptr(q), C, ptr(k), C, ptr(vt), ptr(out), C, B, Bk, heads, Tq, Tk, d, float(scale),
                               _code(q), stream_ptr()), "attention")
+    _end(tok, "attention", 4.0 * B * heads * Tq * Tk * d, (2 * B * Tq * C + 2 * Bk * Tk * C) * q.element_size())
     return out
 
 
@@ -266,6 +353,17 @@ def ddim_step(x, eps_nhwc, coef, step_idx, advance=False, out=None):
         out = torch.empty_like(x)
     check(lib.afldm_ddim_step(ptr(x), ptr(eps_nhwc), ptr(out), ptr(coef), ptr(step_idx), int(advance), B, C, H, W,
                               _code(eps_nhwc), stream_ptr()), "ddim_step")
+    return out
+
+
+def ddim_step_flat(x, eps, coefs, out=None):
+    """x, eps: same-shape contiguous fp32 CUDA tensors; coefs = 4 python floats."""
+    _dev(x, "x"); _dev(eps, "eps")
+    assert x.dtype == eps.dtype == torch.float32 and x.shape == eps.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.afldm_ddim_step_flat(ptr(x), ptr(eps), ptr(out), *[float(c) for c in coefs], x.numel(), stream_ptr()),
+          "ddim_step_flat")
     return out
 
 

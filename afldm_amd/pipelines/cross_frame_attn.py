@@ -1,0 +1,128 @@
+"""Cross-frame ("equivariant") attention hook — surface of reference
+afldm/pipelines/cross_frame_attn.py (AttnState :6-51, CrossFrameAttnProcessor :54-130,
+get_/set_unet_attn_processor :133-190) over afldm_amd's Attention modules.
+
+STORE: remember the pre-norm input of every self-attention, keyed by timestep; LOAD: take K and
+V from the remembered (unshifted-pass) map, group-normed with the layer's own GroupNorm, while
+Q comes from the current hidden states.  Tensors are NHWC inside the UNet forward."""
+import torch
+
+from .. import ops
+from ..models.blocks import AttnProcessor2_0, packed_norm
+
+
+class AttnState:
+    STORE = 0
+    LOAD = 1
+    IDLE = 2
+
+    def __init__(self):
+        self.reset()
+
+    @property
+    def state(self):
+        return self.__state
+
+    @property
+    def alpha(self):
+        return self.__alpha
+
+    @property
+    def store_id(self):
+        return self.__store_id
+
+    @property
+    def timestep(self):
+        return self.__timestep
+
+    def set_timestep(self, t):
+        self.__timestep = t.item() if isinstance(t, torch.Tensor) else t
+
+    def set_alpha(self, alpha):
+        self.__alpha = alpha
+
+    def set_store_id(self, store_id):
+        self.__store_id = store_id
+
+    def reset(self):
+        self.__state = AttnState.STORE
+        self.__timestep = 0
+        self.__store_id = 0
+        self.__alpha = 0
+
+    def to_load(self):
+        self.__state = AttnState.LOAD
+
+    def to_idle(self):
+        self.__state = AttnState.IDLE
+
+
+class CrossFrameAttnProcessor(AttnProcessor2_0):
+    def __init__(self, attn_state: AttnState, enable_interp=False):
+        super().__init__()
+        self.attn_state = attn_state
+        self.maps = [dict(), dict()]
+        self.enable_interp = enable_interp
+
+    def _kv_source(self, attn, stored, batch):
+        """group-normed [Bk, HW, C] tokens of a stored NHWC map; Bk must divide the batch (the
+        kernel indexes kv-sample b // (B/Bk): the reference's batch repeat, cross_frame_attn.py:91-96)."""
+        Bk, H, W, C = stored.shape
+        if batch % Bk != 0:
+            raise ValueError(f"stored map batch {Bk} does not divide the current batch {batch}")
+        gn = attn.group_norm
+        if gn is None:
+            return stored.view(Bk, H * W, C)
+        gamma, beta = packed_norm(gn)
+        stats = ops.gn_stats(stored, gn.num_groups, gn.eps)
+        return ops.gn_apply(stored, stats, gamma, beta, gn.num_groups, act=0).view(Bk, H * W, C)
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None):
+        if encoder_hidden_states is not None:       # not self-attention: vanilla
+            return super().__call__(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
+        st, t = self.attn_state.state, self.attn_state.timestep
+        if st == AttnState.IDLE:
+            return super().__call__(attn, hidden_states, None, attention_mask, temb)
+        if st == AttnState.STORE:
+            self.maps[self.attn_state.store_id][t] = hidden_states.detach().clone()
+            return super().__call__(attn, hidden_states, None, attention_mask, temb)
+        map0 = self._kv_source(attn, self.maps[0][t], hidden_states.shape[0])
+        if not self.enable_interp:
+            return super().__call__(attn, hidden_states, map0, attention_mask, temb)
+        alpha = self.attn_state.alpha
+        map1 = self._kv_source(attn, self.maps[1][t], hidden_states.shape[0])
+        r1 = super().__call__(attn, hidden_states, map0, attention_mask, temb)
+        r2 = super().__call__(attn, hidden_states, map1, attention_mask, temb)
+        return (1 - alpha) * r1 + alpha * r2
+
+
+def get_unet_attn_processors(unet):
+    """{'<module path>.processor': processor} for every module exposing get_processor()."""
+    found = {}
+
+    def walk(name, module):
+        if hasattr(module, "get_processor"):
+            found[f"{name}.processor"] = module.get_processor()
+        for sub, child in module.named_children():
+            walk(f"{name}.{sub}", child)
+
+    for name, module in unet.named_children():
+        walk(name, module)
+    return found
+
+
+def set_unet_attn_processor(unet, processor):
+    count = len(get_unet_attn_processors(unet))
+    if isinstance(processor, dict) and len(processor) != count:
+        raise ValueError(
+            f"A dict of processors was passed, but the number of processors {len(processor)} does not match the"
+            f" number of attention layers: {count}. Please make sure to pass {count} processor classes.")
+
+    def walk(name, module):
+        if hasattr(module, "set_processor"):
+            module.set_processor(processor.pop(f"{name}.processor") if isinstance(processor, dict) else processor)
+        for sub, child in module.named_children():
+            walk(f"{name}.{sub}", child)
+
+    for name, module in unet.named_children():
+        walk(name, module)

@@ -1,0 +1,88 @@
+"""MyLDMPipeline — surface of reference afldm/pipelines/ldm_pipeline.py:17-160 on MI355X.
+
+`__call__(output_type='latent')` is the throughput entry point: the DDIM loop runs as a
+replayed HIP graph (afldm_amd.engine.DenoiseEngine).  Decoding needs the alias-free VAE, which
+is the next row of the scope table and raises until it lands."""
+import inspect
+import json
+import os
+
+import torch
+
+from ..engine import DenoiseEngine
+from ..models.unet_2d import UNet2DModel
+from ..schedulers.ddim import DDIMScheduler
+from ..utils import randn_tensor
+from .pipeline_utils import DiffusionPipeline, ImagePipelineOutput
+
+
+class MyLDMPipeline(DiffusionPipeline):
+    def __init__(self, vae, unet: UNet2DModel, scheduler: DDIMScheduler):
+        super().__init__()
+        self.register_modules(vae=vae, unet=unet, scheduler=scheduler)
+        self._engines = {}
+
+    @classmethod
+    def from_pretrained(cls, path, **kw):
+        """Local diffusers-format directory: unet/ (config.json + safetensors), scheduler/
+        (scheduler_config.json), optional vae/.  There is no network access on the target boxes."""
+        if not os.path.isdir(path):
+            raise OSError(f"{path} is not a local directory (afldm_amd cannot download checkpoints)")
+        unet = UNet2DModel.from_pretrained(path, subfolder="unet")
+        with open(os.path.join(path, "scheduler", "scheduler_config.json")) as f:
+            scheduler = DDIMScheduler.from_config(json.load(f))
+        vae = None
+        if os.path.isdir(os.path.join(path, "vae")):
+            raise NotImplementedError("the alias-free VAE is not implemented yet (SURVEY.md 8f rank 1)")
+        return cls(vae, unet, scheduler)
+
+    def _engine(self, batch, steps, use_graph):
+        key = (batch, steps, use_graph, self.unet.dtype, str(self.unet.device), id(self.scheduler))
+        if key not in self._engines:
+            self._engines = {key: DenoiseEngine(self.unet, self.scheduler, batch, steps, use_graph)}
+        return self._engines[key]
+
+    @torch.no_grad()
+    def __call__(self, batch_size=1, generator=None, eta=0.0, num_inference_steps=50, latents=None,
+                 output_type="pil", return_dict=True, use_graph=True, **kwargs):
+        self.scheduler = DDIMScheduler.from_config(self.scheduler.config)
+        if eta != 0.0:
+            raise NotImplementedError("eta != 0 is not used by the reference scripts")
+        if latents is None:
+            latents = randn_tensor((batch_size, self.unet.config.in_channels, self.unet.config.sample_size,
+                                    self.unet.config.sample_size), generator=generator)
+        eng = self._engine(latents.shape[0], num_inference_steps, use_graph)
+        eng.scheduler = self.scheduler
+        latents = eng.run(latents).to(self.unet.dtype)
+        if output_type == "latent":
+            return latents
+        if self.vae is None:
+            raise NotImplementedError("decoding needs the alias-free VAE (SURVEY.md 8f rank 1); "
+                                      "use output_type='latent'")
+        latents = latents.to(self.vae.dtype) / self.vae.config.scaling_factor
+        image = self.vae.decode(latents).sample
+        if output_type != "pt":
+            image = (image / 2 + 0.5).clamp(0, 1).cpu().permute(0, 2, 3, 1).numpy()
+            if output_type == "pil":
+                image = self.numpy_to_pil(image)
+            return ImagePipelineOutput(images=image) if return_dict else (image,)
+        return image
+
+    @torch.no_grad()
+    def ddim_inversion(self, latent, bar=True):
+        """Deterministic DDIM inversion over reversed timesteps (reference ldm_pipeline.py:133-160)."""
+        from .. import ops
+        ts = list(reversed(self.scheduler._timesteps_host))
+        it = self.progress_bar(ts) if bar else ts
+        ac = self.scheduler.alphas_cumprod
+        for i, t in enumerate(it):
+            a_t = ac[t]
+            a_prev = ac[ts[i - 1]] if i > 0 else self.scheduler.final_alpha_cumprod
+            mu, mu_prev = a_t ** 0.5, a_prev ** 0.5
+            sigma, sigma_prev = (1 - a_t) ** 0.5, (1 - a_prev) ** 0.5
+            eps = self.unet(latent, t).sample
+            # latent <- mu * (latent - sigma_prev eps) / mu_prev + sigma eps : the DDIM update kernel
+            # with (sqrt a_t, sqrt(1-a_t)) := (mu_prev, sigma_prev) and (sqrt a_prev, ..) := (mu, sigma)
+            latent = ops.ddim_step_flat(latent.float().contiguous(), eps.float().contiguous(),
+                                        (float(mu_prev), float(sigma_prev), float(mu), float(sigma))).to(latent.dtype)
+        return latent

@@ -53,6 +53,7 @@ int afldm_device_info(char* name, int name_len);
  * reference's mask rules (create_lpf_rect ideal_lpf.py:12-24, create_recon_rect :38-49):
  *   kind 0: U  [up*N x N], UpsampleRFFT(up)(X) == U X U^T      (ideal_lpf.py:148-158)
  *   kind 1: D  [N/2 x N],  LPF_RFFT(1/2)(Z)[::2,::2] == D Z D^T (ideal_lpf.py:69-93 + af_blocks.py:26)
+ *   kind 2: L  [N x N],    LPF_RFFT(1/2)(Z) == L Z L^T           (ideal_lpf.py:69-93)
  * `out` is HOST memory, row-major fp32 (computed in fp64). */
 int afldm_filter_matrix(int kind, int N, int up, float* out);
 
@@ -111,6 +112,12 @@ int afldm_af_up2(const void* x, const float* U, void* y, float* workspace, int B
 int afldm_af_lpf_down2(const void* x, const float* D, void* y, float* workspace, int B, int N, int C,
                        int dtype, afldm_stream_t stream);
 
+/* Generic separable product y = M x M^T per (b, c) plane: [B,N,N,C] -> [B,R,R,C], M: [R x N]
+ * device fp32.  Serves UpsampleRFFT(up) for any `up` (ImageShifter('ideal', 8):
+ * shifters.py:163-170) and the same-size LPF_RFFT (kind 2 matrix).  workspace: B*R*N*C floats. */
+int afldm_af_resample(const void* x, const float* M, void* y, float* workspace, int B, int N, int C,
+                      int R, int dtype, afldm_stream_t stream);
+
 /* ---- convolution / linear as implicit GEMM on MFMA --------------------------------------
  * y[b,oh,ow,n] = bias[n] + temb[b*temb_stride + n] + residual[b,oh,ow,n]
  *              + sum_{kh,kw,ci} x[b, oh+kh-KS/2, ow+kw-KS/2, ci] * w[n,kh,kw,ci]
@@ -162,6 +169,11 @@ int afldm_attention(const void* q, int ldq, const void* k, int ldk, const void* 
 int afldm_ddim_step(const float* x, const void* eps, float* x_prev, const float* coef,
                     int* step_idx, int advance, int B, int C, int H, int W, int dtype,
                     afldm_stream_t stream);
+/* Same update on flat fp32 tensors with the coefficients by value: the
+ * DDIMScheduler.step(model_output, timestep, sample) API (ldm_pipeline.py:108-109). */
+int afldm_ddim_step_flat(const float* x, const float* eps, float* x_prev, float sqrt_a_t,
+                         float sqrt_1m_a_t, float sqrt_a_prev, float sqrt_1m_a_prev, size_t n,
+                         afldm_stream_t stream);
 /* tvals[step] -> t_out[0] (device->device), so the timestep also follows step_idx. */
 int afldm_select_timestep(const float* tvals, const int* step_idx, float* t_out,
                           afldm_stream_t stream);

@@ -1,0 +1,172 @@
+"""CPU-only tests: C-ABI exports vs the header, host-side logic (scheduler, configs, surgery,
+shifter masks, sharding incl. a 2-process gloo run), and that the product refuses to compute
+without a GPU (no CPU fallback)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_symbol_the_header_declares():
+    from afldm_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "afldm_hip.h")).read()
+    declared = set(re.findall(r"\b(afldm_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"afldm_conv_args"}
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(_lib.lib, name), f"{name} declared in afldm_hip.h but not exported"
+    assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
+    assert _lib.lib.afldm_version() >= 100
+
+
+def test_filter_matrices_match_oracle_and_reject_bad_sizes():
+    from afldm_amd import _lib
+    from oracle import ideal_filters as idf
+    for N in (2, 4, 8, 16, 32):
+        assert np.abs(_lib.filter_matrix(0, N, 2).numpy() - idf.up_matrix(N, 2)).max() < 1e-7
+        assert np.abs(_lib.filter_matrix(1, 2 * N).numpy() - idf.down_matrix(2 * N)).max() < 1e-7
+    assert np.abs(_lib.filter_matrix(0, 32, 8).numpy() - idf.up_matrix(32, 8)).max() < 1e-7
+    L = _lib.filter_matrix(2, 16).numpy()
+    assert np.abs(L[::2] - idf.down_matrix(16)).max() < 1e-7
+    with pytest.raises(_lib.AfldmError):
+        _lib.filter_matrix(0, 1, 8)          # the reference raises IndexError on this size too
+    with pytest.raises(_lib.AfldmError):
+        _lib.filter_matrix(1, 7)
+
+
+def test_configs_agree_with_oracle_copies():
+    from afldm_amd import configs as pc
+    from oracle import configs as oc
+    for k, v in oc.FFHQ_UNET.items():
+        assert pc.FFHQ_UNET_CONFIG[k] == v, k
+    for k, v in oc.FFHQ_DDIM.items():
+        assert pc.FFHQ_DDIM_CONFIG[k] == v, k
+    assert pc.tiny_unet_config()["block_out_channels"] == oc.tiny_unet()["block_out_channels"]
+
+
+def test_unet_surface_state_dict_and_surgery():
+    from afldm_amd.af_modules.af_api import make_af_unet
+    from afldm_amd.af_modules.af_blocks import AliasFreeDownsample2D, AliasFreeUpsample2D, WarpedNonlinearity
+    from afldm_amd.configs import FFHQ_UNET_CONFIG
+    from afldm_amd.models.unet_2d import UNet2DModel
+    from afldm_amd.pipelines.cross_frame_attn import get_unet_attn_processors
+    from oracle import configs as oc, unet as ou
+    unet = UNet2DModel.from_config(FFHQ_UNET_CONFIG)
+    sd = ou.init_unet_params(oc.FFHQ_UNET)
+    assert list(sd.keys()) and set(sd) == set(unet.state_dict())
+    assert sum(p.numel() for p in unet.parameters()) == 256_401_796
+    keys_before = list(unet.state_dict().keys())
+    make_af_unet(unet)
+    assert list(unet.state_dict().keys()) == keys_before, "AF surgery must not add parameters or buffers"
+    n_warp = sum(isinstance(m, WarpedNonlinearity) for m in unet.modules())
+    assert n_warp == 27                                                      # one per ResnetBlock2D
+    assert sum(isinstance(m, AliasFreeDownsample2D) for m in unet.modules()) == 4
+    assert sum(isinstance(m, AliasFreeUpsample2D) for m in unet.modules()) == 4
+    assert all(d.conv.stride in (1, (1, 1)) for d in unet.modules() if isinstance(d, AliasFreeDownsample2D))
+    assert not isinstance(unet.conv_act, WarpedNonlinearity)
+    assert unet.config.sample_size == 32 and unet.config.in_channels == 4 and unet.dtype == torch.float32
+    sites = [k[:-len(".processor")] for k in get_unet_attn_processors(unet)]
+    assert sites == ou.attention_sites(oc.FFHQ_UNET) and len(sites) == 21
+
+
+def test_no_cpu_fallback():
+    from afldm_amd import ops
+    from afldm_amd.configs import tiny_unet_config
+    from afldm_amd.models.unet_2d import UNet2DModel
+    from afldm_amd.schedulers.ddim import ffhq_ddim_scheduler
+    unet = UNet2DModel.from_config(tiny_unet_config())
+    with pytest.raises(RuntimeError, match="MI355X"):
+        unet(torch.zeros(1, 4, 16, 16), 3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.silu(torch.zeros(4))
+    s = ffhq_ddim_scheduler()
+    s.set_timesteps(50)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        s.step(torch.zeros(1, 4, 8, 8), 981, torch.zeros(1, 4, 8, 8))
+    src = open(os.path.join(ROOT, "afldm_amd", "ops.py")).read() + open(os.path.join(ROOT, "afldm_amd", "engine.py")).read()
+    assert "oracle" not in src, "the product must never import the oracle"
+
+
+def test_scheduler_matches_oracle_tables():
+    from afldm_amd.schedulers.ddim import DDIMScheduler, ffhq_ddim_scheduler
+    from oracle.ddim import DDIM
+    s, o = ffhq_ddim_scheduler(), DDIM()
+    s.set_timesteps(50)
+    o.set_timesteps(50)
+    assert torch.equal(s.timesteps, o.timesteps) and torch.equal(s.alphas_cumprod, o.alphas_cumprod)
+    assert float(s.final_alpha_cumprod) == float(o.final_alpha_cumprod) and s.init_noise_sigma == 1.0
+    for t in (981, 501, 21, 1):
+        assert s.coefficients(t) == o.coefficients(t)
+    assert s.coefficient_table("cpu").shape == (50, 4)
+    s2 = DDIMScheduler.from_config(s.config)
+    assert dict(s2.config) == dict(s.config)
+    with pytest.raises(ValueError):
+        s.set_timesteps(2000)
+
+
+def test_valid_masks_match_reference_fixture(golden):
+    from afldm_amd.shift_utils.shifters import gen_valid_mask
+    g = golden("g5_shift_metrics.npz")
+    for k, (ti, tj) in enumerate(((1.5, -2.25), (-0.5, 0.0), (0.0, 3.0))):
+        assert torch.equal(gen_valid_mask((1, 1, 8, 8), ti, tj), torch.from_numpy(g[f"valid_mask_{k}"]))
+
+
+def test_metrics_match_reference_fixture(golden):
+    from afldm_amd.shift_utils import metrics
+    g = golden("g5_shift_metrics.npz")
+    a, b, m = (torch.from_numpy(g[k]) for k in ("ma", "mb", "mm"))
+    assert torch.equal(metrics.mask_mse(a, b, m), torch.from_numpy(g["mask_mse"]))
+    assert torch.equal(metrics.mask_psnr(a, b, m), torch.from_numpy(g["mask_psnr"]))
+    assert torch.equal(metrics.psnr(a, b), torch.from_numpy(g["psnr"]))
+
+
+def test_randn_tensor_is_device_independent():
+    from afldm_amd.utils import randn_tensor
+    a = randn_tensor((2, 4, 8, 8), generator=torch.Generator().manual_seed(5))
+    b = torch.randn((2, 4, 8, 8), generator=torch.Generator().manual_seed(5))
+    assert torch.equal(a, b)
+
+
+def test_shard_ranges_cover_and_balance():
+    from afldm_amd.parallel import shard_range
+    for total in (1, 7, 64, 512, 513):
+        for world in (1, 2, 3, 8):
+            rs = [shard_range(total, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == total
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+            sizes = [e - s for s, e in rs]
+            assert max(sizes) - min(sizes) <= 1
+
+
+_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from afldm_amd import parallel
+rank, world, _ = parallel.init_distributed("gloo")
+total = int(sys.argv[2])
+fn = lambda z: z * 2.0 + z.flatten(1).sum(1).view(-1, 1, 1, 1)      # per-sample, like the sampler
+out = parallel.sample_sharded(fn, total, (4, 8, 8), 1234, rank, world, "cpu")
+ref = fn(parallel.global_noise(total, (4, 8, 8), 1234))
+assert out.shape == ref.shape and torch.equal(out, ref), (rank, out.shape)
+parallel.barrier()
+print("OK", rank)
+"""
+
+
+@pytest.mark.parametrize("total", [8, 7])
+def test_two_process_gloo_sharded_sampling(tmp_path, total):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    port = 29600 + (os.getpid() % 300) + total
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(script), ROOT, str(total)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("OK") == 2
