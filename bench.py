@@ -80,11 +80,13 @@ def roofline_pass(unet, batch, dtype):
     return roof, fam
 
 
-def cpu_baseline(steps=6):
+def cpu_baseline(steps=4):
     """The oracle (CPU restatement, eager PyTorch fp32: torch.fft filters, F.conv2d, SDPA) on
     the host cores, B = 1.  A reported baseline, never the thing measured above."""
     from oracle import configs as oc, pipeline as op, unet as ou
-    cores = os.cpu_count() or 1
+    # B = 1 eager ops do not scale past a few tens of threads (256 threads measured 100x SLOWER
+    # than 8 on the MI355X host: oversubscribed OpenMP barriers), so the thread count is capped.
+    cores = min(os.cpu_count() or 1, 16)
     sd = ou.init_unet_params(oc.FFHQ_UNET, seed=0, conv_out_scale=0.1)
     sec = op.time_denoise_steps(sd, oc.FFHQ_UNET, batch=1, steps=steps, threads=cores)
     return dict(value=round(1.0 / sec, 4), unit="denoise-steps/s", cores=cores, kind="port",
