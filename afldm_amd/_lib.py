@@ -43,14 +43,18 @@ def _load():
         "afldm_cast": ([vp, ip, vp, ip, c_size_t, vp], c_int),
         "afldm_timestep_embedding": ([vp, vp, ip, ip, ip, fp, ip, vp], c_int),
         "afldm_silu": ([vp, vp, c_size_t, ip, vp], c_int),
-        "afldm_gn_stats": ([vp, ip, vp, ip, vp, ip, ip, ip, fp, ip, vp], c_int),
-        "afldm_gn_apply": ([vp, ip, vp, ip, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp], c_int),
-        "afldm_af_act": ([vp, ip, vp, ip, vp, vp, vp, ip, vp, vp, vp, ip, ip, ip, vp], c_int),
+        "afldm_gn_stats_splits": ([ip], c_int),
+        "afldm_gn_stats": ([vp, ip, vp, ip, vp, ip, ip, ip, ip, vp], c_int),
+        "afldm_gn_apply": ([vp, ip, vp, ip, vp, vp, vp, vp, ip, ip, ip, fp, ip, ip, vp], c_int),
+        "afldm_af_act": ([vp, ip, vp, ip, vp, vp, vp, ip, fp, vp, vp, vp, vp, ip, ip, ip, vp], c_int),
+        "afldm_af_pack_bytes": ([ip, ip], c_size_t),
+        "afldm_af_pack": ([vp, vp, ip, ip, vp, vp], c_int),
         "afldm_af_up2": ([vp, vp, vp, vp, ip, ip, ip, ip, vp], c_int),
         "afldm_af_lpf_down2": ([vp, vp, vp, vp, ip, ip, ip, ip, vp], c_int),
         "afldm_af_resample": ([vp, vp, vp, vp, ip, ip, ip, ip, ip, vp], c_int),
         "afldm_conv2d": ([POINTER(ConvArgs), vp], c_int),
         "afldm_conv2d_workspace": ([POINTER(ConvArgs)], c_size_t),
+        "afldm_conv2d_tune": ([ip, ip], c_int),
         "afldm_attention": ([vp, ip, vp, ip, vp, vp, ip, ip, ip, ip, ip, ip, ip, fp, ip, vp], c_int),
         "afldm_ddim_step": ([vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, vp], c_int),
         "afldm_ddim_step_flat": ([vp, vp, vp, fp, fp, fp, fp, c_size_t, vp], c_int),

@@ -30,10 +30,13 @@ struct AfP {
   const float* stats;
   const float* gamma;
   const float* beta;
-  const float* U;  // [2N][N]
+  const float* U;  // [2N][N]   (small-plane kernel)
   const float* D;  // [N][2N]
+  const void* packed;  // LDS image of the matrices for the MFMA kernel (afldm_af_pack)
   T* y;
   int C1, C2, G, B;
+  int S;      // GroupNorm partial-sum splits (gn_splits(N*N))
+  float eps;
 };
 
 template <typename T>
@@ -49,6 +52,8 @@ __device__ __forceinline__ bf16x8 pack_chain<bf16>(const f32x4& lo, const f32x4&
   return v;
 }
 
+constexpr int af_nw(int N) { return N == 32 ? 8 : 4; }
+
 template <typename T, int N>
 struct AfCfg {
   typedef Mma<T> MM;
@@ -57,34 +62,76 @@ struct AfCfg {
   static constexpr int KH = ((N + KPF - 1) / KPF) * KPF;  // K extent for contractions over an N-long axis
   static constexpr int SL = (sizeof(T) == 2) ? 32 : 16;   // h' rows per slab
   static constexpr int NSLAB = H2 / SL;
-  static constexpr int WPW = N / 4;                        // w columns per wave in P1 / P4
+  static constexpr int NW = af_nw(N);                      // waves per workgroup
+  static constexpr int WPW = N / NW;                       // w columns per wave in P1 / P4 (4)
+  static constexpr int RPW = SL / NW;                      // h' rows per wave in P2/P3
+  static constexpr int RG = RPW < 4 ? RPW : 4;             // rows processed together (packed V writes)
   static constexpr bool PERM = sizeof(T) == 2;             // P3's matrix needs chain-permuted columns
-  // LDS carve (elements of T)
-  static constexpr int XS = N * 16 * KH;
+  // packed constants (= LDS image, elements of T): Us [H2][KH] | Ds [N][H2] | Dp [N][H2] (bf16 only)
   static constexpr int US = H2 * KH;
   static constexpr int DS = N * H2;
   static constexpr int DPS = PERM ? N * H2 : 0;
+  static constexpr int CONST_ELEMS = US + DS + DPS;
+  // LDS carve (elements of T)
+  static constexpr int XS = N * 16 * KH;                   // also re-used as the output staging tile
   static constexpr int T1S = SL * 16 * KH;
   static constexpr int VS = N * 16 * SL;
-  static constexpr int LDS_BYTES = (XS + US + DS + DPS + T1S + VS) * (int)sizeof(T) + 2 * 16 * (int)sizeof(float);
+  static constexpr int LDS_BYTES = (CONST_ELEMS + XS + T1S + VS) * (int)sizeof(T) + 2 * 16 * (int)sizeof(float);
+  static_assert(WPW == 4, "P1 packs 4 consecutive w columns per store");
+  static_assert(N * N * 16 <= XS, "output staging tile must fit in the X region");
 };
 
+// Builds the LDS image of the filter matrices once (host calls it once per (N, dtype)).
 template <typename T, int N>
-__global__ void __launch_bounds__(256) k_af_act_mfma(AfP<T> p) {
+__global__ void k_af_pack(const float* __restrict__ U, const float* __restrict__ D, T* __restrict__ out) {
+  typedef AfCfg<T, N> CF;
+  constexpr int H2 = CF::H2, KH = CF::KH;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < CF::CONST_ELEMS; i += gridDim.x * blockDim.x) {
+    float v;
+    if (i < CF::US) {
+      const int r = i / KH, k = i - r * KH;
+      v = k < N ? U[r * N + k] : 0.f;
+    } else if (i < CF::US + CF::DS) {
+      v = D[i - CF::US];
+    } else {
+      // column 32f + 8g + e of Dp  <-  column 32f + (e < 4 ? 4g + e : 16 + 4g + e - 4) of D
+      const int j = i - CF::US - CF::DS;
+      const int r = j / H2, k = j - r * H2;
+      const int f = k >> 5, g = (k >> 3) & 3, e = k & 7;
+      v = D[r * H2 + 32 * f + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4))];
+    }
+    out[i] = from_f32<T>(v);
+  }
+}
+
+template <typename T, int RG>
+__device__ __forceinline__ void store_run(T* p, const float* v);
+template <>
+__device__ __forceinline__ void store_run<bf16, 4>(bf16* p, const float* v) { store4<bf16>(p, v[0], v[1], v[2], v[3]); }
+template <>
+__device__ __forceinline__ void store_run<float, 4>(float* p, const float* v) { store4<float>(p, v[0], v[1], v[2], v[3]); }
+template <>
+__device__ __forceinline__ void store_run<float, 2>(float* p, const float* v) {
+  *reinterpret_cast<f32x2*>(p) = f32x2{v[0], v[1]};
+}
+
+template <typename T, int N>
+__global__ void __launch_bounds__(af_nw(N) * 64) k_af_act_mfma(AfP<T> p) {
   typedef AfCfg<T, N> CF;
   typedef Mma<T> MM;
   typedef typename MM::Chunk Chunk;
   constexpr int EPC = CF::EPC, KPF = CF::KPF, H2 = CF::H2, KH = CF::KH, SL = CF::SL, WPW = CF::WPW;
+  constexpr int NT = CF::NW * 64, RPW = CF::RPW, RG = CF::RG;
   constexpr int NKF1 = KH / KPF;   // chunk pairs when contracting an N-long axis
   constexpr int NKF3 = H2 / KPF;   // ... a 2N-long axis
   constexpr int NKF4 = SL / KPF;   // ... one slab of h'
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* Xs = reinterpret_cast<T*>(smem);
-  T* Us = Xs + CF::XS;
+  T* Us = reinterpret_cast<T*>(smem);
   T* Ds = Us + CF::US;
   T* Dp = CF::PERM ? Ds + CF::DS : Ds;
-  T* T1 = Ds + CF::DS + CF::DPS;
+  T* Xs = Us + CF::CONST_ELEMS;
+  T* T1 = Xs + CF::XS;
   T* Vs = T1 + CF::T1S;
   float* gsc = reinterpret_cast<float*>(Vs + CF::VS);
   float* gsh = gsc + 16;
@@ -93,77 +140,120 @@ __global__ void __launch_bounds__(256) k_af_act_mfma(AfP<T> p) {
   const int li = lane & 15, lg = lane >> 4;
   const int Ct = p.C1 + p.C2;
   const int ctiles = Ct / 16;
-  const int item = xcd_remap(blockIdx.x, gridDim.x);
-  const int b = item / ctiles;
-  const int c0 = (item % ctiles) * 16;
-  const bool second = c0 >= p.C1;
-  const T* xsrc = second ? p.x2 : p.x1;
-  const int Cs = second ? p.C2 : p.C1;
-  const int cs0 = second ? c0 - p.C1 : c0;
+  const int nitems = p.B * ctiles;
+  const int cpg = p.stats ? Ct / p.G : 1;
 
-  // ---- phase 0: constants into LDS
-  for (int i = tid; i < H2 * KH; i += 256) {
-    const int r = i / KH, k = i - r * KH;
-    Us[i] = from_f32<T>(k < N ? p.U[r * N + k] : 0.f);
+  // ---- once per (persistent) workgroup: packed constants (16-byte copies) + K padding of T1
+  {
+    const Chunk* src = reinterpret_cast<const Chunk*>(p.packed);
+    Chunk* dst = reinterpret_cast<Chunk*>(Us);
+    for (int i = tid; i < CF::CONST_ELEMS / EPC; i += NT) dst[i] = src[i];
   }
-  for (int i = tid; i < N * H2; i += 256) {
-    const int r = i / H2, k = i - r * H2;
-    Ds[i] = from_f32<T>(p.D[r * H2 + k]);
-    if (CF::PERM) {
-      // column 32f + 8g + e of Dp  <-  column 32f + (e < 4 ? 4g + e : 16 + 4g + e - 4) of D
-      const int f = k >> 5, g = (k >> 3) & 3, e = k & 7;
-      const int src = 32 * f + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4));
-      Dp[i] = from_f32<T>(p.D[r * H2 + src]);
-    }
-  }
-  if (tid < 16) {
-    float sc = 1.f, sh = 0.f;
-    if (p.stats) {
-      const int c = c0 + tid, g = c / (Ct / p.G);
-      const float mean = p.stats[2 * (b * p.G + g)], rstd = p.stats[2 * (b * p.G + g) + 1];
-      sc = rstd * p.gamma[c];
-      sh = p.beta[c] - mean * sc;
-    }
-    gsc[tid] = sc;
-    gsh[tid] = sh;
-  }
-  if (KH > N) {  // zero the K padding of the two B-operand arrays that contract an N-long axis
-    for (int i = tid; i < N * 16 * (KH - N); i += 256) {
-      const int row = i / (KH - N), k = N + (i - row * (KH - N));
-      Xs[row * KH + k] = from_f32<T>(0.f);
-    }
-    for (int i = tid; i < SL * 16 * (KH - N); i += 256) {
+  if constexpr (KH > N) {
+    for (int i = tid; i < SL * 16 * (KH - N); i += NT) {
       const int row = i / (KH - N), k = N + (i - row * (KH - N));
       T1[row * KH + k] = from_f32<T>(0.f);
     }
   }
-  __syncthreads();
 
-  // ---- phase 1: x tile -> Xs[w][c][h] (transposed so h is K-contiguous), GroupNorm applied
-  {
-    constexpr int CQ = 16 / EPC, HQ = N / EPC;
-    for (int u = tid; u < N * CQ * HQ; u += 256) {
-      const int cq = u % CQ;
-      const int w = (u / CQ) % N;
-      const int hq = u / (CQ * N);
-      float v[EPC][EPC];  // [h offset][channel offset]
+  // X tile staging units: unit u = (cq, w, hq) reads EPC pixels (h = hq*EPC + e) x EPC channels and
+  // writes them transposed (h contiguous).  UPT units per thread live in registers so that the NEXT
+  // item's tile is fetched from HBM while the current one is being computed.
+  constexpr int CQ = 16 / EPC, HQ = N / EPC, UNITS = N * CQ * HQ, UPT = (UNITS + NT - 1) / NT;
+  Chunk pre[UPT][EPC];
+  auto fetch = [&](int item) {
+    const int b = item / ctiles, c0 = (item - b * ctiles) * 16;
+    const bool second = c0 >= p.C1;
+    const T* xsrc = second ? p.x2 : p.x1;
+    const int Cs = second ? p.C2 : p.C1, cs0 = second ? c0 - p.C1 : c0;
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) {
-        const int h = hq * EPC + e;
-        Chunk ch = ld16<Chunk>(xsrc + ((size_t)(b * N + h) * N + w) * Cs + cs0 + cq * EPC);
+    for (int k = 0; k < UPT; ++k) {
+      const int u = tid + k * NT;
+      if (u < UNITS) {
+        const int cq = u % CQ, w = (u / CQ) % N, hq = u / (CQ * N);
 #pragma unroll
-        for (int cc = 0; cc < EPC; ++cc) v[e][cc] = to_f32(ch[cc]) * gsc[cq * EPC + cc] + gsh[cq * EPC + cc];
-      }
-#pragma unroll
-      for (int cc = 0; cc < EPC; ++cc) {
-        Chunk o;
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) o[e] = from_f32<T>(v[e][cc]);
-        st16<Chunk>(Xs + ((size_t)(w * 16 + cq * EPC + cc)) * KH + hq * EPC, o);
+        for (int e = 0; e < EPC; ++e)
+          pre[k][e] = ld16<Chunk>(xsrc + ((size_t)(b * N + hq * EPC + e) * N + w) * Cs + cs0 + cq * EPC);
       }
     }
-  }
-  __syncthreads();
+  };
+
+  // contiguous item range per workgroup: the 4 channel tiles that share a 128-byte line of a pixel
+  // are processed back-to-back by one workgroup (and neighbouring workgroups sit on one XCD)
+  const int wl = xcd_remap(blockIdx.x, gridDim.x);
+  const int ipw = (nitems + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int item_end = (wl + 1) * ipw < nitems ? (wl + 1) * ipw : nitems;
+  int item = wl * ipw;
+  if (item < item_end) fetch(item);
+  for (; item < item_end; ++item) {
+    const int b = item / ctiles;
+    const int c0 = (item - b * ctiles) * 16;
+
+    // ---- GroupNorm scale / shift of the 16 channels: the S partial sums are added by 16 x S lanes
+    if (tid < 16) {
+      gsc[tid] = 1.f;
+      gsh[tid] = 0.f;
+    }
+    if (p.stats) {
+      // thread (c = tid & 15, s = tid >> 4), s < S (S <= 32 <= NT / 16)
+      const int c = tid & 15, sidx = tid >> 4;
+      double s1 = 0.0, s2 = 0.0;
+      if (sidx < p.S) {
+        const f32x2 v = *reinterpret_cast<const f32x2*>(p.stats + (((size_t)b * p.S + sidx) * p.G + (c0 + c) / cpg) * 2);
+        s1 = (double)v[0];
+        s2 = (double)v[1];
+      }
+      s1 += __shfl_xor(s1, 16, 64);
+      s2 += __shfl_xor(s2, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      double* red = reinterpret_cast<double*>(Vs);  // Vs is free here (next written in P3, after 2 barriers)
+      if (lane < 16) {
+        red[(wave * 16 + lane) * 2 + 0] = s1;
+        red[(wave * 16 + lane) * 2 + 1] = s2;
+      }
+      __syncthreads();
+      if (tid < 16) {
+        double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < CF::NW; ++wv) {
+          a1 += red[(wv * 16 + tid) * 2 + 0];
+          a2 += red[(wv * 16 + tid) * 2 + 1];
+        }
+        const double inv_n = 1.0 / ((double)N * N * cpg);
+        const double m = a1 * inv_n;
+        const float var = fmaxf((float)(a2 * inv_n - m * m), 0.f);
+        const float rstd = rsqrtf(var + p.eps);
+        const float sc = rstd * p.gamma[c0 + tid];
+        gsc[tid] = sc;
+        gsh[tid] = p.beta[c0 + tid] - (float)m * sc;
+      }
+    }
+    __syncthreads();  // gsc/gsh ready; also: the previous item's output copy out of the X region is done
+    if constexpr (KH > N) {  // the output staging of the previous item overwrote the X region: re-zero its K padding
+      for (int i = tid; i < N * 16 * (KH - N); i += NT) {
+        const int row = i / (KH - N), k = N + (i - row * (KH - N));
+        Xs[row * KH + k] = from_f32<T>(0.f);
+      }
+    }
+    // ---- prefetched tile -> Xs[w][c][h] (h K-contiguous), GroupNorm applied
+#pragma unroll
+    for (int k = 0; k < UPT; ++k) {
+      const int u = tid + k * NT;
+      if (u < UNITS) {
+        const int cq = u % CQ, w = (u / CQ) % N, hq = u / (CQ * N);
+#pragma unroll
+        for (int cc = 0; cc < EPC; ++cc) {
+          const float sc = gsc[cq * EPC + cc], sh = gsh[cq * EPC + cc];
+          Chunk o;
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) o[e] = from_f32<T>(to_f32(pre[k][e][cc]) * sc + sh);
+          st16<Chunk>(Xs + ((size_t)(w * 16 + cq * EPC + cc)) * KH + hq * EPC, o);
+        }
+      }
+    }
+    __syncthreads();
+    if (item + 1 < item_end) fetch(item + 1);  // in flight during the MFMA passes
 
   f32x4 yacc[WPW][N / 16];
 #pragma unroll
@@ -172,7 +262,7 @@ __global__ void __launch_bounds__(256) k_af_act_mfma(AfP<T> p) {
     for (int t = 0; t < N / 16; ++t) yacc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int s = 0; s < CF::NSLAB; ++s) {
-    // ---- P1: T1[h'][c][w] = sum_h U[h'][h] X[h][w][c]   (this wave: its WPW columns w)
+    // ---- P1: T1[h'][c][w] = sum_h U[h'][h] X[h][w][c]   (this wave: its 4 columns w)
 #pragma unroll
     for (int ti = 0; ti < SL / 16; ++ti) {
       Chunk uf[NKF1];
@@ -188,45 +278,58 @@ __global__ void __launch_bounds__(256) k_af_act_mfma(AfP<T> p) {
           MM::mma(acc[wi], uf[kf], ld16<Chunk>(Xs + (w * 16 + li) * KH + kf * KPF + lg * EPC));
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        T* dst = T1 + ((16 * ti + 4 * lg + r) * 16 + li) * KH + wave * WPW;
-#pragma unroll
-        for (int w4 = 0; w4 < WPW; w4 += 4) store4<T>(dst + w4, acc[w4][r], acc[w4 + 1][r], acc[w4 + 2][r], acc[w4 + 3][r]);
-      }
+      for (int r = 0; r < 4; ++r)
+        store4<T>(T1 + ((16 * ti + 4 * lg + r) * 16 + li) * KH + wave * WPW, acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
     }
     __syncthreads();
 
-    // ---- P2 -> SiLU -> P3 for this wave's SL/4 rows h' of the slab, chained in registers
-    for (int hl = wave * (SL / 4); hl < (wave + 1) * (SL / 4); ++hl) {
-      Chunk tf[NKF1];
+    // ---- P2 -> SiLU -> P3 for this wave's rows h' of the slab, RG rows at a time, chained in registers
 #pragma unroll
-      for (int kf = 0; kf < NKF1; ++kf) tf[kf] = ld16<Chunk>(T1 + (hl * 16 + li) * KH + kf * KPF + lg * EPC);
-      f32x4 z[H2 / 16];
+    for (int rg = 0; rg < RPW / RG; ++rg) {
+      const int hl0 = wave * RPW + rg * RG;
+      f32x4 v[RG][N / 16];
 #pragma unroll
-      for (int t2 = 0; t2 < H2 / 16; ++t2) {
-        z[t2] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < RG; ++q) {
+        const int hl = hl0 + q;
+        Chunk tf[NKF1];
 #pragma unroll
-        for (int kf = 0; kf < NKF1; ++kf)
-          MM::mma(z[t2], ld16<Chunk>(Us + (16 * t2 + li) * KH + kf * KPF + lg * EPC), tf[kf]);
+        for (int kf = 0; kf < NKF1; ++kf) tf[kf] = ld16<Chunk>(T1 + (hl * 16 + li) * KH + kf * KPF + lg * EPC);
+        f32x4 z[H2 / 16];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) z[t2][r] = silu_f(z[t2][r]);
+        for (int t2 = 0; t2 < H2 / 16; ++t2) {
+          z[t2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kf = 0; kf < NKF1; ++kf)
+            MM::mma(z[t2], ld16<Chunk>(Us + (16 * t2 + li) * KH + kf * KPF + lg * EPC), tf[kf]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) z[t2][r] = silu_f(z[t2][r]);
+        }
+        Chunk pb[NKF3];
+        if constexpr (CF::PERM) {
+#pragma unroll
+          for (int f = 0; f < NKF3; ++f) pb[f] = pack_chain<T>(z[2 * f], z[2 * f + 1]);
+        } else {
+#pragma unroll
+          for (int f = 0; f < NKF3; ++f) pb[f] = z[f];
+        }
+#pragma unroll
+        for (int t3 = 0; t3 < N / 16; ++t3) {
+          v[q][t3] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int f = 0; f < NKF3; ++f)
+            MM::mma(v[q][t3], ld16<Chunk>(Dp + (16 * t3 + li) * H2 + f * KPF + lg * EPC), pb[f]);
+        }
       }
-      Chunk pb[NKF3];
-      if constexpr (CF::PERM) {
+      // V[w][c][h'] with the RG rows of this group contiguous -> one 8/16-byte LDS store each
 #pragma unroll
-        for (int f = 0; f < NKF3; ++f) pb[f] = pack_chain<T>(z[2 * f], z[2 * f + 1]);
-      } else {
+      for (int t3 = 0; t3 < N / 16; ++t3)
 #pragma unroll
-        for (int f = 0; f < NKF3; ++f) pb[f] = z[f];
-      }
+        for (int r = 0; r < 4; ++r) {
+          float run[RG];
 #pragma unroll
-      for (int t3 = 0; t3 < N / 16; ++t3) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int f = 0; f < NKF3; ++f) MM::mma(v, ld16<Chunk>(Dp + (16 * t3 + li) * H2 + f * KPF + lg * EPC), pb[f]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Vs[((16 * t3 + 4 * lg + r) * 16 + li) * SL + hl] = from_f32<T>(v[r]);
-      }
+          for (int q = 0; q < RG; ++q) run[q] = v[q][t3][r];
+          store_run<T, RG>(Vs + ((16 * t3 + 4 * lg + r) * 16 + li) * SL + hl0, run);
+        }
     }
     __syncthreads();
 
@@ -242,22 +345,29 @@ __global__ void __launch_bounds__(256) k_af_act_mfma(AfP<T> p) {
           MM::mma(yacc[wi][t4], ld16<Chunk>(Ds + (16 * t4 + li) * H2 + s * SL + kf * KPF + lg * EPC), vf);
       }
     }
-    // no barrier needed here: the next slab's P1 only writes T1 (all waves passed the barrier
-    // after P2/P3), and its P3 writes to Vs happen after the next barrier.
+    // no barrier needed here (see the slab protocol in the header comment): the next slab's P1
+    // writes T1 only, and its P3 writes Vs after the next barrier.
   }
 
-  // ---- store: lane (c = li, g) holds rows h = 16 t4 + 4 g + r of column w
+  // ---- output: stage the [N][N][16] tile through LDS (the X region is dead) -> 16-byte stores
+  T* Ys = Xs;
 #pragma unroll
   for (int wi = 0; wi < WPW; ++wi) {
     const int w = wave * WPW + wi;
 #pragma unroll
     for (int t4 = 0; t4 < N / 16; ++t4)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int h = 16 * t4 + 4 * lg + r;
-        p.y[((size_t)(b * N + h) * N + w) * Ct + c0 + li] = from_f32<T>(yacc[wi][t4][r]);
-      }
+      for (int r = 0; r < 4; ++r) Ys[((16 * t4 + 4 * lg + r) * N + w) * 16 + li] = from_f32<T>(yacc[wi][t4][r]);
   }
+  __syncthreads();
+  {
+    constexpr int CPP = 16 / EPC;  // 16-byte chunks per pixel
+    for (int i = tid; i < N * N * CPP; i += NT) {
+      const int pix = i / CPP, q = i - pix * CPP;
+      st16<Chunk>(p.y + ((size_t)b * N * N + pix) * Ct + c0 + q * EPC, ld16<Chunk>(Ys + pix * 16 + q * EPC));
+    }
+  }
+  }  // persistent item loop
 }
 
 // ----------------------------------------------------------------------------- small planes
@@ -276,8 +386,9 @@ __global__ void __launch_bounds__(256) k_af_act_small(AfP<T> p) {
     const int cc = second ? c - p.C1 : c;
     float sc = 1.f, sh = 0.f;
     if (p.stats) {
-      const int g = c / (Ct / p.G);
-      const float mean = p.stats[2 * (b * p.G + g)], rstd = p.stats[2 * (b * p.G + g) + 1];
+      const int cpg = Ct / p.G;
+      float mean, rstd;
+      gn_finalize(p.stats, p.S, p.G, b, c / cpg, (double)N * N * cpg, p.eps, mean, rstd);
       sc = rstd * p.gamma[c];
       sh = p.beta[c] - mean * sc;
     }
@@ -355,6 +466,53 @@ __global__ void __launch_bounds__(256) k_axis_contract(const TI* __restrict__ in
   }
 }
 
+// Register-blocked form of the same product for the plane sizes of the UNet: one thread owns the
+// whole contracted line (A inputs) of 4 adjacent channels, so inputs are read ONCE with 8/16-byte
+// coalesced loads and the matrix coefficients are wave-uniform scalar operands.
+//   in element (line, k, c) at  in  + base_in(line)  + k * stride_k + c
+//   out element (line, r, c) at out + base_out(line) + r * stride_k + c       (same stride)
+// axis 0: line = (b, w): base_in = (b*A*Wd + w)*C, base_out = (b*ROUT*Wd + w)*C, stride = Wd*C
+// axis 1: line = (b, i): base_in = (b*Ad + i)*A*C, base_out = (b*Ad + i)*ROUT*C, stride = C
+template <typename TI, typename TO, int A, int ROUT>
+__global__ void __launch_bounds__(256) k_axis_contract_reg(const TI* __restrict__ in, TO* __restrict__ out,
+                                                           const float* __restrict__ M, int B, int Jd, int C,
+                                                           int axis) {
+  const int nq = C / 4;
+  const size_t total = (size_t)B * Jd * nq;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = 4 * (int)(i % nq);
+    const size_t line = i / nq;           // b * Jd + j
+    const int j = (int)(line % Jd);
+    const int b = (int)(line / Jd);
+    size_t bin, bout, stride;
+    if (axis == 0) {
+      bin = ((size_t)b * A * Jd + j) * C;
+      bout = ((size_t)b * ROUT * Jd + j) * C;
+      stride = (size_t)Jd * C;
+    } else {
+      bin = line * A * C;
+      bout = line * ROUT * C;
+      stride = C;
+    }
+    float v[A][4];
+#pragma unroll
+    for (int k = 0; k < A; ++k) load4<TI>(in + bin + k * stride + c, v[k][0], v[k][1], v[k][2], v[k][3]);
+#pragma unroll 4
+    for (int r = 0; r < ROUT; ++r) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+      for (int k = 0; k < A; ++k) {
+        const float m = M[r * A + k];
+        a0 = fmaf(m, v[k][0], a0);
+        a1 = fmaf(m, v[k][1], a1);
+        a2 = fmaf(m, v[k][2], a2);
+        a3 = fmaf(m, v[k][3], a3);
+      }
+      store4<TO>(out + bout + r * stride + c, a0, a1, a2, a3);
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------- launchers
 template <typename T, int N>
 static int launch_af_mfma(const AfP<T>& p, hipStream_t st) {
@@ -365,8 +523,18 @@ static int launch_af_mfma(const AfP<T>& p, hipStream_t st) {
                               CF::LDS_BYTES);
     attr_set = true;
   }
-  const int grid = p.B * ((p.C1 + p.C2) / 16);
-  k_af_act_mfma<T, N><<<grid, 256, CF::LDS_BYTES, st>>>(p);
+  const int nitems = p.B * ((p.C1 + p.C2) / 16);
+  static int cus = 0;
+  if (!cus) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  const int per_cu = (160 * 1024) / CF::LDS_BYTES > 0 ? (160 * 1024) / CF::LDS_BYTES : 1;   // persistent workgroups per CU
+  int grid = cus * (per_cu > 2 ? 2 : per_cu);
+  if (grid > nitems) grid = nitems;
+  k_af_act_mfma<T, N><<<grid, CF::NW * 64, CF::LDS_BYTES, st>>>(p);
   return check_launch("afldm_af_act(mfma)");
 }
 template <typename T, int N>
@@ -379,9 +547,12 @@ static int launch_af_small(const AfP<T>& p, hipStream_t st) {
 
 template <typename T>
 static int af_act_dispatch(const void* x1, int C1, const void* x2, int C2, const float* stats, const float* gamma,
-                           const float* beta, int G, const float* U, const float* D, void* y, int B, int N,
-                           hipStream_t st) {
+                           const float* beta, int G, float eps, const float* U, const float* D, const void* packed,
+                           void* y, int B, int N, hipStream_t st) {
   AfP<T> p;
+  p.packed = packed;
+  p.S = gn_splits(N * N);
+  p.eps = eps;
   p.x1 = (const T*)x1; p.x2 = (const T*)x2; p.stats = stats; p.gamma = gamma; p.beta = beta;
   p.U = U; p.D = D; p.y = (T*)y; p.C1 = C1; p.C2 = C2; p.G = G; p.B = B;
   switch (N) {
@@ -399,6 +570,20 @@ template <typename T>
 static int resample_dispatch(const void* x, const float* M, void* y, float* ws, int B, int N, int C, int Rout,
                              hipStream_t st) {
   // pass 1 contracts H into the fp32 workspace [B][Rout][N][C]; pass 2 contracts W
+  if (C % 4 == 0 && (Rout == 2 * N || 2 * Rout == N) && N >= 2 && N <= 32 && (N & (N - 1)) == 0) {
+    const size_t t1 = (size_t)B * N * (C / 4), t2 = (size_t)B * Rout * (C / 4);
+    const int g1 = (int)((t1 + 255) / 256 < 8192 ? (t1 + 255) / 256 : 8192);
+    const int g2 = (int)((t2 + 255) / 256 < 8192 ? (t2 + 255) / 256 : 8192);
+#define AFLDM_RS(A_, R_)                                                                                      \
+  if (N == A_ && Rout == R_) {                                                                                \
+    k_axis_contract_reg<T, float, A_, R_><<<g1, 256, 0, st>>>((const T*)x, ws, M, B, N, C, 0);                \
+    k_axis_contract_reg<float, T, A_, R_><<<g2, 256, 0, st>>>(ws, (T*)y, M, B, Rout, C, 1);                   \
+    return check_launch("afldm_af_resample(reg)");                                                            \
+  }
+    AFLDM_RS(2, 4) AFLDM_RS(4, 8) AFLDM_RS(8, 16) AFLDM_RS(16, 32)
+    AFLDM_RS(4, 2) AFLDM_RS(8, 4) AFLDM_RS(16, 8) AFLDM_RS(32, 16)
+#undef AFLDM_RS
+  }
   size_t n1 = (size_t)B * Rout * N * C, n2 = (size_t)B * Rout * Rout * C;
   int g1 = (int)((n1 + 255) / 256 < 8192 ? (n1 + 255) / 256 : 8192);
   int g2 = (int)((n2 + 255) / 256 < 8192 ? (n2 + 255) / 256 : 8192);
@@ -412,9 +597,10 @@ static int resample_dispatch(const void* x, const float* M, void* y, float* ws, 
 using namespace afldm;
 
 extern "C" int afldm_af_act(const void* x1, int C1, const void* x2, int C2, const float* stats, const float* gamma,
-                            const float* beta, int G, const float* U, const float* D, void* y, int B, int N, int dtype,
-                            afldm_stream_t stream) {
+                            const float* beta, int G, float eps, const float* U, const float* D, const void* packed,
+                            void* y, int B, int N, int dtype, afldm_stream_t stream) {
   AFLDM_REQUIRE(x1 && U && D && y, AFLDM_ENULL, "afldm_af_act: NULL pointer");
+  AFLDM_REQUIRE(N < 16 || packed, AFLDM_ENULL, "afldm_af_act: N=%d needs the packed filter image (afldm_af_pack)", N);
   AFLDM_REQUIRE(C1 > 0 && C2 >= 0 && (C2 == 0 || x2), AFLDM_ESHAPE, "afldm_af_act: bad C1=%d C2=%d", C1, C2);
   AFLDM_REQUIRE(B > 0, AFLDM_ESHAPE, "afldm_af_act: B=%d", B);
   AFLDM_REQUIRE(!stats || (gamma && beta && G > 0 && (C1 + C2) % G == 0), AFLDM_ESHAPE,
@@ -425,10 +611,28 @@ extern "C" int afldm_af_act(const void* x1, int C1, const void* x2, int C2, cons
     AFLDM_REQUIRE(aligned16(x1) && aligned16(x2) && aligned16(y), AFLDM_EALIGN, "afldm_af_act: pointers must be 16-byte aligned");
   }
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == AFLDM_F32) return af_act_dispatch<float>(x1, C1, x2, C2, stats, gamma, beta, G, U, D, y, B, N, st);
-  if (dtype == AFLDM_BF16) return af_act_dispatch<bf16>(x1, C1, x2, C2, stats, gamma, beta, G, U, D, y, B, N, st);
+  if (dtype == AFLDM_F32) return af_act_dispatch<float>(x1, C1, x2, C2, stats, gamma, beta, G, eps, U, D, packed, y, B, N, st);
+  if (dtype == AFLDM_BF16) return af_act_dispatch<bf16>(x1, C1, x2, C2, stats, gamma, beta, G, eps, U, D, packed, y, B, N, st);
   set_error("afldm_af_act: unknown dtype %d", dtype);
   return AFLDM_EDTYPE;
+}
+
+extern "C" size_t afldm_af_pack_bytes(int N, int dtype) {
+  if (N == 16) return dtype == AFLDM_F32 ? AfCfg<float, 16>::CONST_ELEMS * 4 : AfCfg<bf16, 16>::CONST_ELEMS * 2;
+  if (N == 32) return dtype == AFLDM_F32 ? AfCfg<float, 32>::CONST_ELEMS * 4 : AfCfg<bf16, 32>::CONST_ELEMS * 2;
+  return 0;
+}
+
+extern "C" int afldm_af_pack(const float* U, const float* D, int N, int dtype, void* packed, afldm_stream_t stream) {
+  AFLDM_REQUIRE(U && D && packed, AFLDM_ENULL, "afldm_af_pack: NULL pointer");
+  AFLDM_REQUIRE(N == 16 || N == 32, AFLDM_ESHAPE, "afldm_af_pack: N=%d (only the MFMA plane sizes 16 / 32 are packed)", N);
+  AFLDM_REQUIRE(dtype == AFLDM_F32 || dtype == AFLDM_BF16, AFLDM_EDTYPE, "afldm_af_pack: unknown dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  if (N == 16 && dtype == AFLDM_F32) k_af_pack<float, 16><<<16, 256, 0, st>>>(U, D, (float*)packed);
+  if (N == 32 && dtype == AFLDM_F32) k_af_pack<float, 32><<<16, 256, 0, st>>>(U, D, (float*)packed);
+  if (N == 16 && dtype == AFLDM_BF16) k_af_pack<bf16, 16><<<16, 256, 0, st>>>(U, D, (bf16*)packed);
+  if (N == 32 && dtype == AFLDM_BF16) k_af_pack<bf16, 32><<<16, 256, 0, st>>>(U, D, (bf16*)packed);
+  return check_launch("afldm_af_pack");
 }
 
 extern "C" int afldm_af_up2(const void* x, const float* U, void* y, float* workspace, int B, int N, int C, int dtype,

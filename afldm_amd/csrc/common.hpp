@@ -55,7 +55,12 @@ __device__ __forceinline__ bf16 from_f32<bf16>(float v) {
   return (bf16)v;  // round-to-nearest-even (v_cvt_pk_bf16_f32 on gfx950)
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with the hardware exp2 / reciprocal (1 ulp class): an IEEE divide costs ~10
+// instructions and SiLU is evaluated 4x per element inside the alias-free activation.
+__device__ __forceinline__ float silu_f(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
 
 // ----------------------------------------------------------------------------- 16-byte fragments
 // A "chunk" is 16 bytes of a K-contiguous row: 4 fp32 or 8 bf16.  Both MFMA flavours below take
@@ -142,6 +147,30 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   int xcd = bid % NX, q = nwg / NX, r = nwg % NX;
   int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + bid / NX;
+}
+
+// GroupNorm partial-sum format shared by gn.hip (producer / apply) and af.hip (fused consumer):
+// part[b][s][g] = (sum, sum of squares) over split s of sample b; S = gn_splits(HW).
+__host__ __device__ inline int gn_splits(int HW) {
+  return HW >= 1024 ? 32 : HW >= 256 ? 16 : HW >= 64 ? 4 : 1;
+}
+
+// (mean, rstd) of group g of sample b from the S partial sums.  The sums are added in fp64 (the
+// E[x^2] - mean^2 cancellation is harmless there); everything else is fp32.
+__device__ __forceinline__ void gn_finalize(const float* __restrict__ part, int S, int G, int b, int g, double n,
+                                            float eps, float& mean, float& rstd) {
+  double s1 = 0.0, s2 = 0.0;
+  const float* q = part + ((size_t)b * S * G + g) * 2;
+  for (int s = 0; s < S; ++s) {
+    const f32x2 v = *reinterpret_cast<const f32x2*>(q + (size_t)s * G * 2);
+    s1 += (double)v[0];
+    s2 += (double)v[1];
+  }
+  const double inv_n = 1.0 / n;
+  const double m = s1 * inv_n;
+  const float var = fmaxf((float)(s2 * inv_n - m * m), 0.f);
+  mean = (float)m;
+  rstd = rsqrtf(var + eps);
 }
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -16,6 +16,8 @@
 // fragment read (16 rows x 4 chunks per ds_read_b128 wave access) is bank-conflict free.
 // Optional split-K (grid.z) writes fp32 slabs that k_splitk_reduce folds together with the
 // epilogue terms — used for the 2x2 / 4x4 levels where M = B*HW is too small to fill 256 CUs.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace afldm {
@@ -35,6 +37,7 @@ struct ConvP {
   int ksteps;   // total K steps = KS*KS * (C1+C2)/(KCH*EPR)
   int splitk;   // grid.z
   int tiles_n;
+  int vec_ok;   // leading dims allow 4-element vector epilogue accesses
 };
 
 __device__ __forceinline__ int swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
@@ -47,7 +50,7 @@ __device__ __forceinline__ void epilogue_store(const ConvP& p, int m, int n, f32
   T* y = (T*)p.y;
   const int HW = p.H * p.W;
   const int b = m / HW;
-  if (n + 3 < p.Cout) {
+  if (n + 3 < p.Cout && p.vec_ok) {
     if (p.bias) {
       f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
       v += bv;
@@ -238,6 +241,204 @@ __global__ void __launch_bounds__(WGM* WGN * 64) k_igemm(ConvP p) {
   }
 }
 
+// ----------------------------------------------------------------------------- v2: LDS-DMA pipeline
+// Same tiling / LDS image / epilogue as k_igemm, but the operands go HBM -> LDS directly
+// (buffer_load_dwordx4 ... lds: no staging VGPRs, no ds_write pass) through a STAGES-deep ring
+// with counted vmcnt waits and raw s_barrier, so STAGES-1 K steps of loads stay in flight across
+// barriers (guide T3/T4).  The LDS destination of an LDS-DMA is lane-linear (base + lane*16), so
+// the bank-conflict swizzle is applied to the per-lane SOURCE chunk instead (guide rule 21): lane
+// l of a 16-row group writes physical chunk (l & 3) of row (l >> 2) and therefore fetches logical
+// chunk (l & 3) ^ swz(row).  Zero padding, M / Cout tails and the "past the end" ring slots use
+// the buffer descriptor's bounds check: an out-of-range voffset writes zeros to LDS.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, int KCH, int STAGES>
+__global__ void __launch_bounds__(WGM* WGN * 64) k_igemm2(ConvP p) {
+  typedef Mma<T> MM;
+  typedef typename MM::Chunk Chunk;
+  constexpr int NW = WGM * WGN;
+  constexpr int EPC = MM::EPC, EPR = 4 * EPC, KSTEP = KCH * EPR;
+  constexpr int ESZ = (int)sizeof(T);
+  constexpr int WMS = BM / WGM, WNS = BN / WGN, TM = WMS / 16, TN = WNS / 16;
+  constexpr int XG = BM / 16, WG_ = BN / 16;          // 16-row groups per plane
+  constexpr int XI = KCH * XG, WI = KCH * WG_;         // wave-instructions per stage (X, W)
+  static_assert(XI % NW == 0 && WI % NW == 0, "row groups must divide among the waves");
+  constexpr int XPW = XI / NW, WPW = WI / NW;          // per wave
+  constexpr int LPS = XPW + WPW;                        // LDS-DMA instructions per wave per stage
+  constexpr int X_STAGE = KCH * BM * 64, W_STAGE = KCH * BN * 64, STAGE = X_STAGE + W_STAGE;
+  constexpr unsigned OOB = 0x80000000u;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int li = lane & 15, lg = lane >> 4;
+
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int Ct = p.C1 + p.C2;
+  const int cblocks = Ct / KSTEP;
+  const int HW = p.H * p.W;
+  const int pad = p.KS >> 1;
+  const int ks = blockIdx.z;
+  const int kbeg = (int)(((long long)p.ksteps * ks) / p.splitk);
+  const int kend = (int)(((long long)p.ksteps * (ks + 1)) / p.splitk);
+
+  // buffer descriptors (wave-uniform by construction: kernel arguments only)
+  const long long x1_bytes = (long long)p.M * p.C1 * ESZ, x2_bytes = (long long)p.M * p.C2 * ESZ;
+  const long long w_bytes = (long long)p.Cout * p.KS * p.KS * Ct * ESZ;
+  __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, (int)x1_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x1), 0, (int)x2_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)w_bytes, 0x00020000);
+
+  // per-lane source coordinates.  Instruction j (0..XI-1) of a stage covers plane kc = j / XG, row
+  // group g = j % XG; this wave issues j = wave + NW * i.  Lane l: row 16 g + (l >> 2), source
+  // chunk (l & 3) ^ swz(row)  [swz(row) depends only on (l >> 4)].
+  const int lrow = lane >> 2;
+  const int lchunk = (lane & 3) ^ ((4 - (lane >> 4)) & 3);
+  int xoh[XPW], xow[XPW], xkc[XPW];
+  unsigned xbase[XPW];  // byte offset of pixel (b, oh, ow) channel 0 in a tensor with C channels = 1 (scaled later)
+  bool xok[XPW];
+#pragma unroll
+  for (int i = 0; i < XPW; ++i) {
+    const int j = wave + NW * i;
+    const int g = j % XG;
+    xkc[i] = j / XG;
+    const int m = m0 + 16 * g + lrow;
+    xok[i] = m < p.M;
+    const int mm = xok[i] ? m : 0;
+    const int b = mm / HW, pix = mm - b * HW;
+    xoh[i] = pix / p.W;
+    xow[i] = pix - xoh[i] * p.W;
+    xbase[i] = (unsigned)mm;  // pixel index; multiplied by the channel count of the source tensor at issue time
+  }
+  unsigned wrow[WPW];
+  int wkc[WPW];
+  bool wok[WPW];
+#pragma unroll
+  for (int i = 0; i < WPW; ++i) {
+    const int j = wave + NW * i;
+    const int g = j % WG_;
+    wkc[i] = j / WG_;
+    const int n = n0 + 16 * g + lrow;
+    wok[i] = n < p.Cout;
+    wrow[i] = (unsigned)(wok[i] ? n : 0) * (unsigned)(p.KS * p.KS);
+  }
+
+  // K cursor of the NEXT step to issue (wave-uniform scalars, advanced incrementally: no division
+  // in the loop)
+  int is_kt = kbeg, is_tap = kbeg / cblocks, is_ci0 = (kbeg - is_tap * cblocks) * KSTEP;
+  int is_kh = is_tap / p.KS, is_kw = is_tap - is_kh * p.KS;
+
+  auto issue = [&](int slot) {
+    char* sbase = smem + slot * STAGE;
+    const bool live = is_kt < kend;
+    const bool second = is_ci0 >= p.C1;
+    const int Cs = second ? p.C2 : p.C1;
+    const int cs0 = second ? is_ci0 - p.C1 : is_ci0;
+    const int dh = is_kh - pad, dw = is_kw - pad;
+    const int dpix = dh * p.W + dw;
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) {
+      const int j = wave + NW * i;
+      const int ih = xoh[i] + dh, iw = xow[i] + dw;
+      const bool ok = live && xok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      const unsigned off = ok ? ((unsigned)((int)xbase[i] + dpix) * (unsigned)Cs + (unsigned)(cs0 + xkc[i] * EPR + lchunk * EPC)) * ESZ : OOB;
+      lds_ptr_t dst = (lds_ptr_t)(sbase + j * 1024);
+      if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, dst, 16, off, 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx1, dst, 16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+      const int j = wave + NW * i;
+      const unsigned off = (live && wok[i])
+                               ? ((wrow[i] + (unsigned)is_tap) * (unsigned)Ct + (unsigned)(is_ci0 + wkc[i] * EPR + lchunk * EPC)) * ESZ
+                               : OOB;
+      lds_ptr_t dst = (lds_ptr_t)(sbase + X_STAGE + j * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, dst, 16, off, 0, 0, 0);
+    }
+    // advance the cursor
+    ++is_kt;
+    is_ci0 += KSTEP;
+    if (is_ci0 >= Ct) {
+      is_ci0 = 0;
+      ++is_tap;
+      if (++is_kw == p.KS) {
+        is_kw = 0;
+        ++is_kh;
+      }
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: STAGES-1 K steps in flight (slots past kend are filled with zeros: uniform counts)
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s) issue(s);
+
+  int slot = 0;
+  for (int kt = kbeg; kt < kend; ++kt) {
+    // the oldest group in flight is K step kt: wait for it, leave the younger STAGES-2 in flight
+    wait_vmcnt<(STAGES - 2) * LPS>();
+    __builtin_amdgcn_s_barrier();
+    // every wave has finished reading the slot of step kt-1 -> refill it with step kt+STAGES-1
+    int nslot = slot + STAGES - 1;
+    if (nslot >= STAGES) nslot -= STAGES;
+    issue(nslot);
+    const char* sX = smem + slot * STAGE;
+    const char* sW = sX + X_STAGE;
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc) {
+      Chunk a[TN], b[TM];
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        const int row = wn * WNS + t * 16 + li;
+        a[t] = ld16<Chunk>(sW + (kc * BN + row) * 64 + ((lg ^ swz(row)) << 4));
+      }
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        const int row = wm * WMS + t * 16 + li;
+        b[t] = ld16<Chunk>(sX + (kc * BM + row) * 64 + ((lg ^ swz(row)) << 4));
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) MM::mma(acc[tn][tm], a[tn], b[tm]);
+    }
+    slot = slot + 1 == STAGES ? 0 : slot + 1;
+  }
+  wait_vmcnt<0>();  // drain the zero-fill tail before the workgroup's LDS can be re-assigned
+
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int m = m0 + wm * WMS + tm * 16 + li;
+      const int n = n0 + wn * WNS + tn * 16 + 4 * lg;
+      if (m >= p.M || n >= p.Cout) continue;
+      if (p.splitk > 1) {
+        float* dst = p.ws + ((size_t)ks * p.M + m) * p.Cout + n;
+        if (n + 3 < p.Cout) *reinterpret_cast<f32x4*>(dst) = acc[tn][tm];
+        else
+          for (int r = 0; r < 4 && n + r < p.Cout; ++r) dst[r] = acc[tn][tm][r];
+      } else {
+        epilogue_store<T>(p, m, n, acc[tn][tm]);
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) k_splitk_reduce(ConvP p) {
   const int nq = (p.Cout + 3) / 4;
@@ -286,6 +487,52 @@ __global__ void __launch_bounds__(256) k_conv_small_cin(ConvP p) {
     if (p.residual) acc += to_f32(((const T*)p.residual)[(size_t)m * p.res_ld + n]);
     if (p.out_mode == 0) y[(size_t)m * p.y_ld + n] = from_f32<T>(acc);
     else y[((size_t)b * p.Cout + n) * HW + pix] = from_f32<T>(acc);
+  }
+}
+
+// conv_in fast path (Cin = 4, KS = 3): weights as fp32 in LDS, one thread = one pixel x a quarter of
+// the couts (interleaved in groups of 4 so a wave writes 32-byte runs), inputs in registers.
+template <typename T, int CIN, int KS>
+__global__ void __launch_bounds__(256) k_conv_cin4(ConvP p) {
+  constexpr int KK = KS * KS * CIN;
+  static_assert(KK % 4 == 0 && CIN == 4, "k_conv_cin4 assumes 4 input channels");
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [Cout][KK]
+  const T* w = (const T*)p.w;
+  for (int i = threadIdx.x; i < p.Cout * KK; i += 256) wl[i] = to_f32(w[i]);
+  __syncthreads();
+  const int HW = p.H * p.W, pad = KS >> 1;
+  const int m = blockIdx.x * 64 + (threadIdx.x >> 2), cg = threadIdx.x & 3;
+  if (m >= p.M) return;
+  const int b = m / HW, pix = m - b * HW, oh = pix / p.W, ow = pix - oh * p.W;
+  const T* x = (const T*)p.x1;
+  float xin[KK];
+#pragma unroll
+  for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < KS; ++kw) {
+      const int ih = oh + kh - pad, iw = ow + kw - pad, t = (kh * KS + kw) * CIN;
+      if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+        load4<T>(x + ((size_t)(b * p.H + ih) * p.W + iw) * CIN, xin[t], xin[t + 1], xin[t + 2], xin[t + 3]);
+      else
+        xin[t] = xin[t + 1] = xin[t + 2] = xin[t + 3] = 0.f;
+    }
+  T* y = (T*)p.y + (size_t)m * p.y_ld;
+  for (int n0 = 4 * cg; n0 < p.Cout; n0 += 16) {
+    float acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[e] = p.bias ? p.bias[n0 + e] : 0.f;
+      const f32x4* wr = reinterpret_cast<const f32x4*>(wl + (n0 + e) * KK);
+#pragma unroll
+      for (int k4 = 0; k4 < KK / 4; ++k4) {
+        const f32x4 wv = wr[k4];
+        acc[e] = fmaf(xin[4 * k4 + 0], wv[0], acc[e]);
+        acc[e] = fmaf(xin[4 * k4 + 1], wv[1], acc[e]);
+        acc[e] = fmaf(xin[4 * k4 + 2], wv[2], acc[e]);
+        acc[e] = fmaf(xin[4 * k4 + 3], wv[3], acc[e]);
+      }
+    }
+    store4<T>(y + n0, acc[0], acc[1], acc[2], acc[3]);
   }
 }
 
@@ -338,6 +585,9 @@ __global__ void __launch_bounds__(256) k_conv_small_cout(ConvP p) {
 }
 
 // ----------------------------------------------------------------------------- host dispatch
+// tuning overrides (afldm_conv2d_tune): -1 = automatic
+static int g_force_variant = -1, g_force_splitk = -1;
+
 struct Plan {
   int kind;  // 0 igemm, 1 small_cin, 2 small_cout
   int cfg;   // igemm tile config
@@ -353,30 +603,42 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
   Plan pl{0, 0, 1};
   const int Ct = a->C1 + a->C2;
   const int kstep = KCH_DEFAULT * elems_per_row;
-  const bool gemm_ok = (Ct % kstep == 0) && (a->C2 == 0 || a->C1 % kstep == 0) && a->Cout >= 16;
+  const bool gemm_ok = (Ct % kstep == 0) && (a->C2 == 0 || a->C1 % kstep == 0);
   if (!gemm_ok) {
     pl.kind = (a->Cout <= 8) ? 2 : 1;
     return pl;
   }
   const long long M = (long long)a->B * a->H * a->W;
-  // tile choice: 128x128 when Cout is a multiple of 128 (or large), 128x64 otherwise; 64-pixel
-  // tiles when M is small
-  int bm = (M >= 128 * 96) ? 128 : 64;
-  int bn = (a->Cout % 128 == 0) ? 128 : 64;
-  pl.cfg = (bm == 128 ? 0 : 2) + (bn == 128 ? 0 : 1);
-  // split-K when the grid cannot fill the chip
+  // Variant choice from the MI355X sweep (tools/bench_kernels.py conv, profiles/r01/conv_sweep*.log):
+  //   M >= 32768 and Cout % 192 == 0 : 128x192 LDS-DMA tile (840-1050 TF on the 32x32 level)
+  //   M >= 4096                      : 128x128 (Cout % 128 == 0) else 128x64, LDS-DMA, 2 stages
+  //   1024 <= M < 4096               : 128x64 LDS-DMA
+  //   M < 1024                       : 64x64 LDS-DMA, 4 stages (short K loops are latency bound)
+  // and split-K so that tiles * splitk ~ 2-3 workgroups per CU.
+  int vid, bm, bn;
+  if (M >= 32768 && a->Cout % 192 == 0) { vid = 12; bm = 128; bn = 192; }
+  else if (M >= 4096 && a->Cout % 128 == 0) { vid = 4; bm = 128; bn = 128; }
+  else if (M >= 1024) { vid = 6; bm = 128; bn = 64; }
+  else { vid = 11; bm = 64; bn = 64; }
+  if (g_force_variant >= 0 && g_force_variant < 16) {
+    static const int fbm[16] = {128, 128, 64, 64, 128, 128, 128, 128, 128, 64, 64, 64, 128, 256, 256, 64};
+    static const int fbn[16] = {128, 64, 128, 64, 128, 128, 64, 64, 64, 128, 128, 64, 192, 64, 64, 64};
+    vid = g_force_variant; bm = fbm[vid]; bn = fbn[vid];
+  }
+  pl.cfg = vid;
   const long long tiles = ((M + bm - 1) / bm) * ((a->Cout + bn - 1) / bn);
   const int ksteps = a->KS * a->KS * (Ct / kstep);
   int sk = 1;
-  if (tiles < 256) {
-    sk = (int)((512 + tiles - 1) / tiles);
+  if (tiles < 384) {
+    sk = (int)((640 + tiles - 1) / tiles);
     int maxsk = ksteps / 4;
     if (maxsk < 1) maxsk = 1;
     if (sk > maxsk) sk = maxsk;
-    if (sk > 32) sk = 32;
+    if (sk > 16) sk = 16;
     if (sk < 1) sk = 1;
   }
   pl.splitk = sk;
+  if (g_force_splitk >= 1) pl.splitk = g_force_splitk;
   return pl;
 }
 
@@ -397,6 +659,70 @@ static void launch_igemm(const ConvP& p0, hipStream_t st) {
   k_igemm<T, BM, BN, WGM, WGN, KCH><<<grid, WGM * WGN * 64, lds, st>>>(p);
 }
 
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES>
+static void launch_igemm2(const ConvP& p0, hipStream_t st) {
+  ConvP p = p0;
+  constexpr int KCH = KCH_DEFAULT;
+  p.tiles_n = (p.Cout + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  dim3 grid(tiles_m * p.tiles_n, 1, p.splitk);
+  constexpr int lds = STAGES * KCH * (BM + BN) * 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_igemm2<T, BM, BN, WGM, WGN, KCH, STAGES>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  k_igemm2<T, BM, BN, WGM, WGN, KCH, STAGES><<<grid, WGM * WGN * 64, lds, st>>>(p);
+}
+
+struct Variant {
+  int bm, bn, ver, stages;
+};
+// index = variant id used by afldm_conv2d_tune / the automatic chooser
+static const Variant kVariants[] = {
+    {128, 128, 1, 2},  // 0
+    {128, 64, 1, 2},   // 1
+    {64, 128, 1, 2},   // 2
+    {64, 64, 1, 2},    // 3
+    {128, 128, 2, 2},  // 4
+    {128, 128, 2, 3},  // 5
+    {128, 64, 2, 2},   // 6
+    {128, 64, 2, 3},   // 7
+    {128, 64, 2, 4},   // 8
+    {64, 128, 2, 3},   // 9
+    {64, 128, 2, 4},   // 10
+    {64, 64, 2, 4},    // 11
+    {128, 192, 2, 2},  // 12
+    {256, 64, 2, 2},   // 13
+    {256, 64, 2, 3},   // 14
+    {64, 64, 2, 6},    // 15
+};
+constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
+
+template <typename T>
+static bool launch_variant(int id, const ConvP& p, hipStream_t st) {
+  switch (id) {
+    case 0: launch_igemm<T, 128, 128, 2, 2>(p, st); return true;
+    case 1: launch_igemm<T, 128, 64, 2, 2>(p, st); return true;
+    case 2: launch_igemm<T, 64, 128, 2, 2>(p, st); return true;
+    case 3: launch_igemm<T, 64, 64, 2, 2>(p, st); return true;
+    case 4: launch_igemm2<T, 128, 128, 2, 2, 2>(p, st); return true;
+    case 5: launch_igemm2<T, 128, 128, 2, 2, 3>(p, st); return true;
+    case 6: launch_igemm2<T, 128, 64, 2, 2, 2>(p, st); return true;
+    case 7: launch_igemm2<T, 128, 64, 2, 2, 3>(p, st); return true;
+    case 8: launch_igemm2<T, 128, 64, 2, 2, 4>(p, st); return true;
+    case 9: launch_igemm2<T, 64, 128, 2, 2, 3>(p, st); return true;
+    case 10: launch_igemm2<T, 64, 128, 2, 2, 4>(p, st); return true;
+    case 11: launch_igemm2<T, 64, 64, 2, 2, 4>(p, st); return true;
+    case 12: launch_igemm2<T, 128, 192, 2, 2, 2>(p, st); return true;
+    case 13: launch_igemm2<T, 256, 64, 4, 1, 2>(p, st); return true;
+    case 14: launch_igemm2<T, 256, 64, 4, 1, 3>(p, st); return true;
+    case 15: launch_igemm2<T, 64, 64, 2, 2, 6>(p, st); return true;
+  }
+  return false;
+}
+
 template <typename T>
 static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
   ConvP p;
@@ -406,7 +732,15 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
   p.temb_stride = a->temb_stride; p.res_ld = a->res_ld; p.y_ld = a->y_ld; p.out_mode = a->out_mode;
   p.M = a->B * a->H * a->W;
   p.splitk = 1; p.tiles_n = 1; p.ksteps = 0;
+  p.vec_ok = ((a->out_mode == 1 || a->y_ld % 4 == 0) && (!a->residual || a->res_ld % 4 == 0) &&
+              (!a->temb || a->temb_stride % 4 == 0)) ? 1 : 0;
   Plan pl = make_plan(a, epr<T>());
+  if (pl.kind == 1 && a->C1 == 4 && a->C2 == 0 && a->KS == 3 && a->Cout % 16 == 0 && a->Cout * 36 * 4 <= 64 * 1024 &&
+      !a->temb && !a->residual && a->out_mode == 0 && a->y_ld % 4 == 0) {
+    const int lds = a->Cout * 36 * (int)sizeof(float);
+    k_conv_cin4<T, 4, 3><<<(p.M + 63) / 64, 256, lds, st>>>(p);
+    return check_launch("afldm_conv2d(cin4)");
+  }
   if (pl.kind == 1) {
     AFLDM_REQUIRE(a->C2 == 0 && a->C1 <= 64, AFLDM_ESHAPE,
                   "afldm_conv2d: Cin=%d+%d is not a multiple of %d and too large for the direct kernel", a->C1,
@@ -430,12 +764,11 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
     size_t need = (size_t)p.splitk * p.M * p.Cout * sizeof(float);
     if (!a->workspace || a->workspace_bytes < need) p.splitk = 1;  // no workspace -> no split
   }
-  switch (pl.cfg) {
-    case 0: launch_igemm<T, 128, 128, 2, 2>(p, st); break;
-    case 1: launch_igemm<T, 128, 64, 2, 2>(p, st); break;
-    case 2: launch_igemm<T, 64, 128, 2, 2>(p, st); break;
-    default: launch_igemm<T, 64, 64, 2, 2>(p, st); break;
-  }
+  const bool v2_ok = (long long)p.M * (a->C1 > a->C2 ? a->C1 : a->C2) * (long long)sizeof(T) < (1ll << 31) &&
+                     (long long)a->Cout * a->KS * a->KS * Ct * (long long)sizeof(T) < (1ll << 31);
+  int vid = pl.cfg;
+  if (kVariants[vid].ver == 2 && !v2_ok) vid = kVariants[vid].bm == 128 ? (kVariants[vid].bn >= 128 ? 0 : 1) : 3;
+  launch_variant<T>(vid, p, st);
   int rc = check_launch("afldm_conv2d(igemm)");
   if (rc) return rc;
   if (p.splitk > 1) {
@@ -461,15 +794,19 @@ static int conv_validate(const afldm_conv_args* a) {
   AFLDM_REQUIRE(aligned16(a->x1) && aligned16(a->w) && aligned16(a->y) && aligned16(a->x2) && aligned16(a->residual) &&
                     aligned16(a->temb) && aligned16(a->bias),
                 AFLDM_EALIGN, "afldm_conv2d: all pointers must be 16-byte aligned");
-  AFLDM_REQUIRE(a->Cout < 16 || ((a->out_mode == 1 || a->y_ld % 4 == 0) && (!a->residual || a->res_ld % 4 == 0) &&
-                                 (!a->temb || a->temb_stride % 4 == 0)),
-                AFLDM_EALIGN, "afldm_conv2d: y_ld/res_ld/temb_stride must be multiples of 4 elements");
   return AFLDM_OK;
 }
 
 }  // namespace afldm
 
 using namespace afldm;
+
+extern "C" int afldm_conv2d_tune(int variant, int splitk) {
+  AFLDM_REQUIRE(variant < kNumVariants, AFLDM_ESHAPE, "afldm_conv2d_tune: variant %d out of range (%d)", variant, kNumVariants);
+  g_force_variant = variant;
+  g_force_splitk = splitk;
+  return AFLDM_OK;
+}
 
 extern "C" size_t afldm_conv2d_workspace(const afldm_conv_args* a) {
   if (!a || (a->dtype != AFLDM_F32 && a->dtype != AFLDM_BF16)) return 0;

@@ -206,10 +206,10 @@ class ResnetBlock2D(nn.Module):
         from ..af_modules.af_blocks import WarpedNonlinearity
         x1, x2 = _pair(x)
         gamma, beta = packed_norm(norm)
-        stats = ops.gn_stats(x1, norm.num_groups, norm.eps, x2=x2)
+        stats = ops.gn_stats(x1, norm.num_groups, x2=x2)
         if isinstance(self.nonlinearity, WarpedNonlinearity):
-            return ops.af_act(x1, x2, stats, gamma, beta, norm.num_groups)
-        return ops.gn_apply(x1, stats, gamma, beta, norm.num_groups, act=1, x2=x2)
+            return ops.af_act(x1, x2, stats, gamma, beta, norm.num_groups, norm.eps)
+        return ops.gn_apply(x1, stats, gamma, beta, norm.num_groups, norm.eps, act=1, x2=x2)
 
     def forward(self, input_tensor, temb_proj=None, temb_stride=0):
         x1, x2 = _pair(input_tensor)
@@ -236,8 +236,9 @@ class AttnProcessor2_0:
         assert attention_mask is None
         B, H, W, C = hidden_states.shape
         gamma, beta = packed_norm(attn.group_norm)
-        stats = ops.gn_stats(hidden_states, attn.group_norm.num_groups, attn.group_norm.eps)
-        hn = ops.gn_apply(hidden_states, stats, gamma, beta, attn.group_norm.num_groups, act=0)
+        gn = attn.group_norm
+        stats = ops.gn_stats(hidden_states, gn.num_groups)
+        hn = ops.gn_apply(hidden_states, stats, gamma, beta, gn.num_groups, gn.eps, act=0)
         tokens = hn.view(B, H * W, C)
         src = tokens if encoder_hidden_states is None else encoder_hidden_states
         q = linear_forward(attn.to_q, tokens)

@@ -199,8 +199,9 @@ class UNet2DModel(nn.Module):
             res, skips = skips[-n:], skips[:-n]
             h = blk(h, res, take(n))
         gamma, beta = B.packed_norm(self.conv_norm_out)
-        stats = ops.gn_stats(h, self.conv_norm_out.num_groups, self.conv_norm_out.eps)
-        h = ops.gn_apply(h, stats, gamma, beta, self.conv_norm_out.num_groups, act=1)   # conv_act is plain SiLU
+        gno = self.conv_norm_out
+        stats = ops.gn_stats(h, gno.num_groups)
+        h = ops.gn_apply(h, stats, gamma, beta, gno.num_groups, gno.eps, act=1)          # conv_act is plain SiLU
         return B.conv_forward(self.conv_out, h)
 
     @torch.no_grad()

@@ -82,6 +82,20 @@ def filter_matrices(N, device):
     return _FILTER_CACHE[key]
 
 
+def packed_filters(N, dtype, device):
+    """Device LDS image of (U, D) for the MFMA alias-free activation (N = 16, 32), cached."""
+    if N < 16:
+        return None
+    key = ("packed", N, dtype, str(device))
+    if key not in _FILTER_CACHE:
+        U, D = filter_matrices(N, device)
+        nbytes = lib.afldm_af_pack_bytes(N, DTYPE_CODE[dtype])
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        check(lib.afldm_af_pack(ptr(U), ptr(D), N, DTYPE_CODE[dtype], ptr(buf), stream_ptr()), "af_pack")
+        _FILTER_CACHE[key] = buf
+    return _FILTER_CACHE[key]
+
+
 def down_matrix(N, device):
     """D [N/2, N] for AliasFreeDownsample2D on an N x N plane."""
     key = ("down", N, str(device))
@@ -163,20 +177,30 @@ def _cat_args(x1, x2):
     return C1, x2, x2.shape[-1]
 
 
-def gn_stats(x1, G, eps, x2=None, out=None):
+def gn_stats(x1, G, x2=None, out=None):
+    """GroupNorm partial sums [B, S, G, 2] (sum, sum of squares per pixel split) of the virtual
+    concat x1|x2; consumed by gn_apply / af_act, which finish mean / rstd themselves."""
     C1, x2, C2 = _cat_args(x1, x2)
     B = x1.shape[0]
     HW = x1.numel() // (B * C1)
+    S = lib.afldm_gn_stats_splits(HW)
     if out is None:
-        out = torch.empty((B, G, 2), dtype=torch.float32, device=x1.device)
+        out = torch.empty((B, S, G, 2), dtype=torch.float32, device=x1.device)
     tok = _begin()
-    check(lib.afldm_gn_stats(ptr(x1), C1, ptr(x2), C2, ptr(out), B, HW, G, float(eps), _code(x1), stream_ptr()),
-          "gn_stats")
+    check(lib.afldm_gn_stats(ptr(x1), C1, ptr(x2), C2, ptr(out), B, HW, G, _code(x1), stream_ptr()), "gn_stats")
     _end(tok, "gn_stats", 0, B * HW * (C1 + C2) * x1.element_size())
     return out
 
 
-def gn_apply(x1, stats, gamma, beta, G, act=0, x2=None, out=None):
+def gn_mean_rstd(part, n, eps):
+    """(mean, rstd) [B, G] from partial sums — host-side helper for tests / debugging only."""
+    s = part.double().sum(1)
+    mean = s[..., 0] / n
+    var = (s[..., 1] / n - mean * mean).clamp_min(0)
+    return mean.float(), (1.0 / torch.sqrt(var + eps)).float()
+
+
+def gn_apply(x1, stats, gamma, beta, G, eps, act=0, x2=None, out=None):
     C1, x2, C2 = _cat_args(x1, x2)
     B = x1.shape[0]
     HW = x1.numel() // (B * C1)
@@ -184,23 +208,24 @@ def gn_apply(x1, stats, gamma, beta, G, act=0, x2=None, out=None):
         out = torch.empty(tuple(x1.shape[:-1]) + (C1 + C2,), dtype=x1.dtype, device=x1.device)
     tok = _begin()
     check(lib.afldm_gn_apply(ptr(x1), C1, ptr(x2), C2, ptr(stats), ptr(gamma), ptr(beta), ptr(out), B, HW, G,
-                             int(act), _code(x1), stream_ptr()), "gn_apply")
+                             float(eps), int(act), _code(x1), stream_ptr()), "gn_apply")
     _end(tok, "gn_apply", 0, 2 * B * HW * (C1 + C2) * x1.element_size())
     return out
 
 
 # ----------------------------------------------------------------------------- alias-free ops
-def af_act(x1, x2=None, stats=None, gamma=None, beta=None, G=0, out=None):
+def af_act(x1, x2=None, stats=None, gamma=None, beta=None, G=0, eps=0.0, out=None):
     """[GroupNorm-apply ->] WarpedNonlinearity(SiLU) on an NHWC tensor (virtual concat x1|x2)."""
     C1, x2, C2 = _cat_args(x1, x2)
     B, N, N2, _ = x1.shape
     assert N == N2, "the reference's ideal filters assume square planes (ideal_lpf.py:80)"
     U, D = filter_matrices(N, x1.device)
+    packed = packed_filters(N, x1.dtype, x1.device)
     if out is None:
         out = torch.empty((B, N, N, C1 + C2), dtype=x1.dtype, device=x1.device)
     tok = _begin()
-    check(lib.afldm_af_act(ptr(x1), C1, ptr(x2), C2, ptr(stats), ptr(gamma), ptr(beta), int(G), ptr(U), ptr(D),
-                           ptr(out), B, N, _code(x1), stream_ptr()), "af_act")
+    check(lib.afldm_af_act(ptr(x1), C1, ptr(x2), C2, ptr(stats), ptr(gamma), ptr(beta), int(G), float(eps), ptr(U),
+                           ptr(D), ptr(packed), ptr(out), B, N, _code(x1), stream_ptr()), "af_act")
     # dense separable form: 24 N^3 flop per plane; one read + one write of the tensor
     _end(tok, f"af_act_N{N}", 24.0 * N ** 3 * B * (C1 + C2), 2 * B * N * N * (C1 + C2) * x1.element_size())
     return out

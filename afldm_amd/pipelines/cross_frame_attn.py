@@ -74,8 +74,8 @@ class CrossFrameAttnProcessor(AttnProcessor2_0):
         if gn is None:
             return stored.view(Bk, H * W, C)
         gamma, beta = packed_norm(gn)
-        stats = ops.gn_stats(stored, gn.num_groups, gn.eps)
-        return ops.gn_apply(stored, stats, gamma, beta, gn.num_groups, act=0).view(Bk, H * W, C)
+        stats = ops.gn_stats(stored, gn.num_groups)
+        return ops.gn_apply(stored, stats, gamma, beta, gn.num_groups, gn.eps, act=0).view(Bk, H * W, C)
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None):
         if encoder_hidden_states is not None:       # not self-attention: vanilla

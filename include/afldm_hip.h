@@ -86,23 +86,35 @@ int afldm_silu(const void* x, void* y, size_t n, int dtype, afldm_stream_t strea
 /* ---- GroupNorm ----------------------------------------------------------------------------
  * torch.nn.GroupNorm(G, C, eps) over an NHWC tensor that is the virtual channel-concat of
  * x1 [B,HW,C1] and x2 [B,HW,C2] (x2 may be NULL with C2 = 0): the up-block skip
- * torch.cat([h, skip], 1) is never materialised.  stats: [B, G, 2] fp32 (mean, rstd). */
-int afldm_gn_stats(const void* x1, int C1, const void* x2, int C2, float* stats, int B, int HW,
-                   int G, float eps, int dtype, afldm_stream_t stream);
+ * torch.cat([h, skip], 1) is never materialised.
+ * Statistics are exchanged as PARTIAL SUMS: part[B][S][G][2] fp32 = (sum, sum of squares) of
+ * pixel-split s, S = afldm_gn_stats_splits(HW).  Consumers (afldm_gn_apply, afldm_af_act) add the
+ * S partials in a fixed order and finish mean / rstd in fp64: one launch per GroupNorm, no
+ * atomics, bit-reproducible. */
+int afldm_gn_stats_splits(int HW);
+int afldm_gn_stats(const void* x1, int C1, const void* x2, int C2, float* part, int B, int HW,
+                   int G, int dtype, afldm_stream_t stream);
 /* y = act((x - mean) * rstd * gamma + beta); act: 0 none (Attention.group_norm),
  * 1 SiLU (conv_norm_out + conv_act, which make_af_unet does NOT wrap: af_api.py:70-83). */
-int afldm_gn_apply(const void* x1, int C1, const void* x2, int C2, const float* stats,
-                   const float* gamma, const float* beta, void* y, int B, int HW, int G, int act,
-                   int dtype, afldm_stream_t stream);
+int afldm_gn_apply(const void* x1, int C1, const void* x2, int C2, const float* part,
+                   const float* gamma, const float* beta, void* y, int B, int HW, int G, float eps,
+                   int act, int dtype, afldm_stream_t stream);
 
 /* ---- alias-free operators -----------------------------------------------------------------
  * afldm_af_act: [GroupNorm-apply ->] WarpedNonlinearity(SiLU) (af_blocks.py:19-28):
- *   y = D silu(U xn U^T) D^T per (b, c) plane,  xn = GN-applied x when stats != NULL.
+ *   y = D silu(U xn U^T) D^T per (b, c) plane,  xn = GN-applied x when part != NULL
+ *   (part = the partial sums written by afldm_gn_stats for HW = N*N).
  * x = virtual concat of x1/x2 as above, [B,N,N,C]; y [B,N,N,C].  N in {2,4,8,16,32}.
  * U: [2N x N], D: [N x 2N] device fp32 matrices from afldm_filter_matrix(0,N,2) / (1,2N,.). */
-int afldm_af_act(const void* x1, int C1, const void* x2, int C2, const float* stats,
-                 const float* gamma, const float* beta, int G, const float* U, const float* D,
-                 void* y, int B, int N, int dtype, afldm_stream_t stream);
+int afldm_af_act(const void* x1, int C1, const void* x2, int C2, const float* part,
+                 const float* gamma, const float* beta, int G, float eps, const float* U,
+                 const float* D, const void* packed, void* y, int B, int N, int dtype,
+                 afldm_stream_t stream);
+/* One-time packing of U / D into the kernel's LDS image for the MFMA plane sizes (N = 16, 32):
+ * `packed` = device buffer of afldm_af_pack_bytes(N, dtype) bytes, passed to afldm_af_act. */
+size_t afldm_af_pack_bytes(int N, int dtype);
+int afldm_af_pack(const float* U, const float* D, int N, int dtype, void* packed,
+                  afldm_stream_t stream);
 /* UpsampleRFFT(2) of AliasFreeUpsample2D (af_blocks.py:92-93): [B,N,N,C] -> [B,2N,2N,C].
  * workspace: device fp32 scratch of B*2N*N*C floats (row pass result). */
 int afldm_af_up2(const void* x, const float* U, void* y, float* workspace, int B, int N, int C,
@@ -145,6 +157,9 @@ typedef struct {
   int dtype;
 } afldm_conv_args;
 int afldm_conv2d(const afldm_conv_args* args, afldm_stream_t stream);
+/* Tuning hook (benchmarks only): force tile/pipeline variant `variant` (>= 0) and/or a split-K
+ * factor (>= 1) for subsequent afldm_conv2d calls; -1 restores the automatic choice. */
+int afldm_conv2d_tune(int variant, int splitk);
 /* bytes of split-K workspace afldm_conv2d may use for this problem (0 if none). */
 size_t afldm_conv2d_workspace(const afldm_conv_args* args);
 

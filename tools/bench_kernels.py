@@ -1,0 +1,123 @@
+#!/usr/bin/env python
+"""Kernel micro-benchmarks on MI355X (HIP-event timing, interleaved rounds).
+
+  python tools/bench_kernels.py conv     # sweep igemm tile/pipeline variants per UNet layer shape
+  python tools/bench_kernels.py afact    # fused GN + alias-free activation
+  python tools/bench_kernels.py attn
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from afldm_amd import _lib, ops  # noqa: E402
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3   # us
+
+
+# (name, B, H, W, C1, C2, Cout, KS)  at batch 64
+CONV_SHAPES = [
+    ("L32 192->192 3x3", 64, 32, 32, 192, 0, 192, 3),
+    ("L32 384+192->192 3x3", 64, 32, 32, 384, 192, 192, 3),
+    ("L32 384->384 3x3 (up conv)", 64, 32, 32, 384, 0, 384, 3),
+    ("L32 192->192 1x1 (q/k/v/o)", 64, 32, 32, 192, 0, 192, 1),
+    ("L16 384->384 3x3", 64, 16, 16, 384, 0, 384, 3),
+    ("L16 384+384->384 3x3", 64, 16, 16, 384, 384, 384, 3),
+    ("L16 384->384 1x1", 64, 16, 16, 384, 0, 384, 1),
+    ("L8 384->384 3x3", 64, 8, 8, 384, 0, 384, 3),
+    ("L8 768+384->384 3x3", 64, 8, 8, 768, 384, 384, 3),
+    ("L8 768->768 3x3 (up conv)", 64, 8, 8, 768, 0, 768, 3),
+    ("L4 768->768 3x3", 64, 4, 4, 768, 0, 768, 3),
+    ("L4 768+768->768 3x3", 64, 4, 4, 768, 768, 768, 3),
+    ("L2 768->768 3x3", 64, 2, 2, 768, 0, 768, 3),
+    ("L2 768+768->768 3x3", 64, 2, 2, 768, 768, 768, 3),
+    ("L4 768->768 1x1", 64, 4, 4, 768, 0, 768, 1),
+    ("conv_out 192->4", 64, 32, 32, 192, 0, 4, 3),
+]
+
+
+def bench_conv(dtype=torch.bfloat16):
+    nvar = 16
+    out = {}
+    for name, B, H, W, C1, C2, Cout, KS in CONV_SHAPES:
+        x1 = torch.randn(B, H, W, C1, device="cuda").to(dtype)
+        x2 = torch.randn(B, H, W, C2, device="cuda").to(dtype) if C2 else None
+        w = (torch.randn(Cout, KS, KS, C1 + C2, device="cuda") / (KS * (C1 + C2) ** 0.5)).to(dtype)
+        bias = torch.randn(Cout, device="cuda")
+        y = torch.empty(B, H, W, Cout, device="cuda", dtype=dtype)
+        ws = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+        flops = 2.0 * B * H * W * Cout * KS * KS * (C1 + C2)
+        M = B * H * W
+        res = {}
+        ref = None
+        for v in list(range(nvar)):
+            for sk in ((-1,) if M >= 16384 else (1, 2, 4, 8, 16)):
+                bm = [128, 128, 64, 64, 128, 128, 128, 128, 128, 64, 64, 64, 128, 256, 256, 64][v]
+                if M < 16384 and bm > 128:
+                    pass
+                _lib.check(_lib.lib.afldm_conv2d_tune(v, sk), "tune")
+                try:
+                    fn = lambda: ops.conv2d(x1, w, bias, x2=x2, out=y, workspace=ws)
+                    fn()
+                    torch.cuda.synchronize()
+                    if ref is None:
+                        ref = y.float().clone()
+                    err = float((y.float() - ref).abs().max() / ref.abs().max())
+                    t = timeit(fn)
+                    res[f"v{v}/sk{sk}"] = (round(t, 1), round(flops / t / 1e6, 0), round(err, 5))
+                except Exception as e:  # noqa
+                    res[f"v{v}/sk{sk}"] = ("ERR", str(e)[:60])
+        _lib.lib.afldm_conv2d_tune(-1, -1)
+        auto = timeit(lambda: ops.conv2d(x1, w, bias, x2=x2, out=y, workspace=ws))
+        best = sorted((v for v in res.items() if v[1][0] != "ERR"), key=lambda kv: kv[1][0])[:4]
+        print(f"{name:30s} auto {auto:8.1f}us {flops/auto/1e6:7.0f} TF | best: " +
+              "  ".join(f"{k}:{v[0]}us/{v[1]:.0f}TF" for k, v in best), flush=True)
+        bad = [k for k, v in res.items() if v[0] == "ERR" or v[2] > 2e-2]
+        if bad:
+            print("    BAD:", bad[:6], [res[k] for k in bad[:3]])
+        out[name] = res
+    return out
+
+
+def bench_afact(dtype=torch.bfloat16):
+    for N, C in ((32, 192), (32, 576), (16, 384), (16, 768), (8, 768), (4, 1536), (2, 1536)):
+        x = torch.randn(64, N, N, C, device="cuda").to(dtype)
+        gamma = torch.ones(C, device="cuda")
+        beta = torch.zeros(C, device="cuda")
+        st = ops.gn_stats(x, 32)
+        y = torch.empty_like(x)
+        t = timeit(lambda: ops.af_act(x, None, st, gamma, beta, 32, 1e-5, out=y))
+        t2 = timeit(lambda: ops.gn_stats(x, 32, out=st))
+        nbytes = 2 * x.numel() * x.element_size()
+        print(f"af_act N={N:2d} C={C:4d}: {t:8.1f} us  {24.0*N**3*64*C/t/1e6:7.1f} TF(dense-eq)  {nbytes/t/1e3:7.1f} GB/s | "
+              f"gn_stats {t2:6.1f} us {nbytes/2/t2/1e3:7.1f} GB/s", flush=True)
+
+
+def bench_attn(dtype=torch.bfloat16):
+    for T, heads in ((1024, 8), (256, 16), (64, 16), (16, 32), (4, 32)):
+        C = heads * 24
+        q = torch.randn(64, T, C, device="cuda").to(dtype)
+        k = torch.randn(64, T, C, device="cuda").to(dtype)
+        vt = torch.randn(64, C, T, device="cuda").to(dtype)
+        o = torch.empty_like(q)
+        t = timeit(lambda: ops.attention(q, k, vt, heads, out=o))
+        print(f"attn T={T:4d} heads={heads:2d}: {t:8.1f} us  {4.0*64*heads*T*T*24/t/1e6:7.1f} TF", flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "conv"
+    {"conv": bench_conv, "afact": bench_afact, "attn": bench_attn}[what]()
