@@ -370,6 +370,185 @@ __global__ void __launch_bounds__(af_nw(N) * 64) k_af_act_mfma(AfP<T> p) {
   }  // persistent item loop
 }
 
+// ----------------------------------------------------------------------------- Kronecker form (N = 4, 8)
+// For small planes the whole 2-D operator is ONE dense matrix per direction:
+//   Z[(h',w'), c] = sum_{(h,w)} KU[(h',w'),(h,w)] X[(h,w), c],   KU = U (x) U   [4N^2 x N^2]
+//   Y[(h,w),  c]  = sum_{(h',w')} KD[(h,w),(h',w')] silu(Z)[(h',w'), c],  KD = D (x) D
+// One wave = one (sample, 16 channels) item: GEMM1 (A = KU rows from LDS, B = the transposed X
+// tile) leaves Z in the MFMA accumulator layout, which IS a legal B operand for GEMM2 once KD's
+// columns are permuted to match (chain trick, see Mma<T>) — the upsampled plane never leaves
+// registers.  The dense form costs more flops than the separable one (x N/3) but these levels are
+// tiny and HBM-bound; what matters is that the item is 64 MFMAs instead of ~6000 VALU FMAs.
+template <typename T, int N>
+struct KronCfg {
+  typedef Mma<T> MM;
+  static constexpr int EPC = MM::EPC, KPF = MM::KPF;
+  static constexpr int P = N * N, Q = 4 * N * N;
+  static constexpr int PK = ((P + KPF - 1) / KPF) * KPF;   // K extent of GEMM1
+  static constexpr int PR = ((P + 15) / 16) * 16;          // output rows of GEMM2, padded to tiles
+  static constexpr bool PERM = sizeof(T) == 2;
+  static constexpr int KU_ELEMS = Q * PK, KD_ELEMS = PR * Q;
+  static constexpr int CONST_ELEMS = KU_ELEMS + KD_ELEMS;
+  static constexpr int XK = 16 * PK;                        // per-wave transposed X tile
+  static constexpr int LDS_BYTES = (CONST_ELEMS + 4 * XK) * (int)sizeof(T);
+};
+
+template <typename T, int N>
+__global__ void k_af_pack_kron(const float* __restrict__ U, const float* __restrict__ D, T* __restrict__ out) {
+  typedef KronCfg<T, N> CF;
+  constexpr int P = CF::P, Q = CF::Q, PK = CF::PK, H2 = 2 * N;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < CF::CONST_ELEMS; i += gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (i < CF::KU_ELEMS) {
+      const int q = i / PK, pp = i - q * PK;
+      if (pp < P) {
+        const int hp = q / H2, wp = q - hp * H2, h = pp / N, w = pp - h * N;
+        v = U[hp * N + h] * U[wp * N + w];
+      }
+    } else {
+      const int j = i - CF::KU_ELEMS;
+      const int pr = j / Q;
+      int k = j - pr * Q;
+      if (CF::PERM) {  // column 32f + 8g + e  <-  column 32f + (e < 4 ? 4g + e : 16 + 4g + e - 4)
+        const int f = k >> 5, g = (k >> 3) & 3, e = k & 7;
+        k = 32 * f + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4));
+      }
+      if (pr < P) {
+        const int h = pr / N, w = pr - h * N, hp = k / H2, wp = k - hp * H2;
+        v = D[h * H2 + hp] * D[w * H2 + wp];
+      }
+    }
+    out[i] = from_f32<T>(v);
+  }
+}
+
+template <typename T, int N>
+__global__ void __launch_bounds__(256) k_af_act_kron(AfP<T> p) {
+  typedef KronCfg<T, N> CF;
+  typedef Mma<T> MM;
+  typedef typename MM::Chunk Chunk;
+  constexpr int EPC = CF::EPC, KPF = CF::KPF, P = CF::P, Q = CF::Q, PK = CF::PK, PR = CF::PR;
+  constexpr int NKF1 = PK / KPF, NZ = Q / 16, NKF2 = Q / KPF, NY = PR / 16;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* KU = reinterpret_cast<T*>(smem);
+  T* KD = KU + CF::KU_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  T* Xk = KD + CF::KD_ELEMS + wave * CF::XK;   // this wave's [16 c][PK] tile
+  const int li = lane & 15, lg = lane >> 4;
+  const int Ct = p.C1 + p.C2, ctiles = Ct / 16, nitems = p.B * ctiles;
+  const int cpg = p.stats ? Ct / p.G : 1;
+
+  {
+    const Chunk* src = reinterpret_cast<const Chunk*>(p.packed);
+    Chunk* dst = reinterpret_cast<Chunk*>(KU);
+    for (int i = tid; i < CF::CONST_ELEMS / EPC; i += 256) dst[i] = src[i];
+  }
+  if constexpr (PK > P) {  // zero K padding of the X tile once (never overwritten)
+    for (int i = lane; i < 16 * (PK - P); i += 64) {
+      const int row = i / (PK - P), k = P + (i - row * (PK - P));
+      Xk[row * PK + k] = from_f32<T>(0.f);
+    }
+  }
+  __syncthreads();
+
+  const int ngroups = (nitems + 3) / 4;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int item = grp * 4 + wave;
+    const bool live = item < nitems;
+    const int b = live ? item / ctiles : 0;
+    const int c0 = live ? (item - b * ctiles) * 16 : 0;
+    const bool second = c0 >= p.C1;
+    const T* xsrc = second ? p.x2 : p.x1;
+    const int Cs = second ? p.C2 : p.C1, cs0 = second ? c0 - p.C1 : c0;
+
+    // ---- GroupNorm scale/shift of channel c0 + li: lane group lg adds split lg (S <= 4 here)
+    float sc = 1.f, sh = 0.f;
+    if (p.stats) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int sidx = lg; sidx < p.S; sidx += 4) {
+        const f32x2 v = *reinterpret_cast<const f32x2*>(p.stats + (((size_t)b * p.S + sidx) * p.G + (c0 + li) / cpg) * 2);
+        s1 += (double)v[0];
+        s2 += (double)v[1];
+      }
+      s1 += __shfl_xor(s1, 16, 64);
+      s2 += __shfl_xor(s2, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      const double inv_n = 1.0 / ((double)P * cpg);
+      const double m = s1 * inv_n;
+      const float var = fmaxf((float)(s2 * inv_n - m * m), 0.f);
+      sc = rsqrtf(var + p.eps) * p.gamma[c0 + li];
+      sh = p.beta[c0 + li] - (float)m * sc;
+    }
+
+    // ---- X tile: [P px][16 c] -> Xk[c][px] (pixels K-contiguous), GroupNorm applied.
+    // unit = EPC pixels x EPC channels; lanes stride the units (the channel octet/quad of a lane
+    // is fixed: 64 % CQ == 0), so its scale/shift are fetched with full-wave shuffles up front.
+    constexpr int CQ = 16 / EPC, PQ = P / EPC, UNITS = CQ * PQ;
+    float usc[EPC], ush[EPC];
+#pragma unroll
+    for (int cc = 0; cc < EPC; ++cc) {
+      usc[cc] = __shfl(sc, (lane % CQ) * EPC + cc, 64);
+      ush[cc] = __shfl(sh, (lane % CQ) * EPC + cc, 64);
+    }
+    __syncthreads();   // previous group's GEMM1 reads of Xk are complete
+    if (live) {
+      for (int u = lane; u < UNITS; u += 64) {
+        const int cq = u % CQ, pq = u / CQ;
+        Chunk ch[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+          ch[e] = ld16<Chunk>(xsrc + ((size_t)b * P + pq * EPC + e) * Cs + cs0 + cq * EPC);
+#pragma unroll
+        for (int cc = 0; cc < EPC; ++cc) {
+          Chunk o;
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) o[e] = from_f32<T>(to_f32(ch[e][cc]) * usc[cc] + ush[cc]);
+          st16<Chunk>(Xk + (cq * EPC + cc) * PK + pq * EPC, o);
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- GEMM1 + SiLU
+    Chunk xf[NKF1];
+#pragma unroll
+    for (int kf = 0; kf < NKF1; ++kf) xf[kf] = ld16<Chunk>(Xk + li * PK + kf * KPF + lg * EPC);
+    f32x4 z[NZ];
+#pragma unroll
+    for (int t = 0; t < NZ; ++t) {
+      z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kf = 0; kf < NKF1; ++kf) MM::mma(z[t], ld16<Chunk>(KU + (16 * t + li) * PK + kf * KPF + lg * EPC), xf[kf]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z[t][r] = silu_f(z[t][r]);
+    }
+    // ---- GEMM2 (chained) + store: lane (c = li, g) holds pixels 16 t + 4 g + r
+    Chunk pb[NKF2];
+    if constexpr (CF::PERM) {
+#pragma unroll
+      for (int f = 0; f < NKF2; ++f) pb[f] = pack_chain<T>(z[2 * f], z[2 * f + 1]);
+    } else {
+#pragma unroll
+      for (int f = 0; f < NKF2; ++f) pb[f] = z[f];
+    }
+#pragma unroll
+    for (int t = 0; t < NY; ++t) {
+      f32x4 y = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int f = 0; f < NKF2; ++f) MM::mma(y, ld16<Chunk>(KD + (16 * t + li) * Q + f * KPF + lg * EPC), pb[f]);
+      if (live) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int px = 16 * t + 4 * lg + r;
+          if (px < P) p.y[((size_t)b * P + px) * Ct + c0 + li] = from_f32<T>(y[r]);
+        }
+      }
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------- small planes
 template <typename T, int N>
 __global__ void __launch_bounds__(256) k_af_act_small(AfP<T> p) {
@@ -538,6 +717,23 @@ static int launch_af_mfma(const AfP<T>& p, hipStream_t st) {
   return check_launch("afldm_af_act(mfma)");
 }
 template <typename T, int N>
+static int launch_af_kron(const AfP<T>& p, hipStream_t st) {
+  typedef KronCfg<T, N> CF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_af_act_kron<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
+    attr_set = true;
+  }
+  const int nitems = p.B * ((p.C1 + p.C2) / 16);
+  const int ngroups = (nitems + 3) / 4;
+  const int per_cu = (160 * 1024) / CF::LDS_BYTES >= 2 ? 2 : 1;
+  int grid = 256 * per_cu;
+  if (grid > ngroups) grid = ngroups;
+  k_af_act_kron<T, N><<<grid, 256, CF::LDS_BYTES, st>>>(p);
+  return check_launch("afldm_af_act(kron)");
+}
+
+template <typename T, int N>
 static int launch_af_small(const AfP<T>& p, hipStream_t st) {
   const int total = p.B * (p.C1 + p.C2);
   const int grid = (total + 255) / 256;
@@ -557,8 +753,12 @@ static int af_act_dispatch(const void* x1, int C1, const void* x2, int C2, const
   p.U = U; p.D = D; p.y = (T*)y; p.C1 = C1; p.C2 = C2; p.G = G; p.B = B;
   switch (N) {
     case 2: return launch_af_small<T, 2>(p, st);
-    case 4: return launch_af_small<T, 4>(p, st);
-    case 8: return launch_af_small<T, 8>(p, st);
+    case 4:
+      if (packed && p.C1 % 16 == 0 && p.C2 % 16 == 0) return launch_af_kron<T, 4>(p, st);
+      return launch_af_small<T, 4>(p, st);
+    case 8:
+      if (packed && p.C1 % 16 == 0 && p.C2 % 16 == 0) return launch_af_kron<T, 8>(p, st);
+      return launch_af_small<T, 8>(p, st);
     case 16: return launch_af_mfma<T, 16>(p, st);
     case 32: return launch_af_mfma<T, 32>(p, st);
   }
@@ -601,6 +801,8 @@ extern "C" int afldm_af_act(const void* x1, int C1, const void* x2, int C2, cons
                             void* y, int B, int N, int dtype, afldm_stream_t stream) {
   AFLDM_REQUIRE(x1 && U && D && y, AFLDM_ENULL, "afldm_af_act: NULL pointer");
   AFLDM_REQUIRE(N < 16 || packed, AFLDM_ENULL, "afldm_af_act: N=%d needs the packed filter image (afldm_af_pack)", N);
+  if ((N == 4 || N == 8) && packed && C1 % 16 == 0 && C2 % 16 == 0)
+    AFLDM_REQUIRE(aligned16(x1) && aligned16(x2) && aligned16(y), AFLDM_EALIGN, "afldm_af_act: pointers must be 16-byte aligned");
   AFLDM_REQUIRE(C1 > 0 && C2 >= 0 && (C2 == 0 || x2), AFLDM_ESHAPE, "afldm_af_act: bad C1=%d C2=%d", C1, C2);
   AFLDM_REQUIRE(B > 0, AFLDM_ESHAPE, "afldm_af_act: B=%d", B);
   AFLDM_REQUIRE(!stats || (gamma && beta && G > 0 && (C1 + C2) % G == 0), AFLDM_ESHAPE,
@@ -618,6 +820,8 @@ extern "C" int afldm_af_act(const void* x1, int C1, const void* x2, int C2, cons
 }
 
 extern "C" size_t afldm_af_pack_bytes(int N, int dtype) {
+  if (N == 4) return dtype == AFLDM_F32 ? KronCfg<float, 4>::CONST_ELEMS * 4 : KronCfg<bf16, 4>::CONST_ELEMS * 2;
+  if (N == 8) return dtype == AFLDM_F32 ? KronCfg<float, 8>::CONST_ELEMS * 4 : KronCfg<bf16, 8>::CONST_ELEMS * 2;
   if (N == 16) return dtype == AFLDM_F32 ? AfCfg<float, 16>::CONST_ELEMS * 4 : AfCfg<bf16, 16>::CONST_ELEMS * 2;
   if (N == 32) return dtype == AFLDM_F32 ? AfCfg<float, 32>::CONST_ELEMS * 4 : AfCfg<bf16, 32>::CONST_ELEMS * 2;
   return 0;
@@ -625,9 +829,13 @@ extern "C" size_t afldm_af_pack_bytes(int N, int dtype) {
 
 extern "C" int afldm_af_pack(const float* U, const float* D, int N, int dtype, void* packed, afldm_stream_t stream) {
   AFLDM_REQUIRE(U && D && packed, AFLDM_ENULL, "afldm_af_pack: NULL pointer");
-  AFLDM_REQUIRE(N == 16 || N == 32, AFLDM_ESHAPE, "afldm_af_pack: N=%d (only the MFMA plane sizes 16 / 32 are packed)", N);
+  AFLDM_REQUIRE(N == 4 || N == 8 || N == 16 || N == 32, AFLDM_ESHAPE, "afldm_af_pack: N=%d (only the MFMA plane sizes 4..32 are packed)", N);
   AFLDM_REQUIRE(dtype == AFLDM_F32 || dtype == AFLDM_BF16, AFLDM_EDTYPE, "afldm_af_pack: unknown dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
+  if (N == 4 && dtype == AFLDM_F32) k_af_pack_kron<float, 4><<<16, 256, 0, st>>>(U, D, (float*)packed);
+  if (N == 8 && dtype == AFLDM_F32) k_af_pack_kron<float, 8><<<64, 256, 0, st>>>(U, D, (float*)packed);
+  if (N == 4 && dtype == AFLDM_BF16) k_af_pack_kron<bf16, 4><<<16, 256, 0, st>>>(U, D, (bf16*)packed);
+  if (N == 8 && dtype == AFLDM_BF16) k_af_pack_kron<bf16, 8><<<64, 256, 0, st>>>(U, D, (bf16*)packed);
   if (N == 16 && dtype == AFLDM_F32) k_af_pack<float, 16><<<16, 256, 0, st>>>(U, D, (float*)packed);
   if (N == 32 && dtype == AFLDM_F32) k_af_pack<float, 32><<<16, 256, 0, st>>>(U, D, (float*)packed);
   if (N == 16 && dtype == AFLDM_BF16) k_af_pack<bf16, 16><<<16, 256, 0, st>>>(U, D, (bf16*)packed);

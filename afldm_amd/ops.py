@@ -84,7 +84,7 @@ def filter_matrices(N, device):
 
 def packed_filters(N, dtype, device):
     """Device LDS image of (U, D) for the MFMA alias-free activation (N = 16, 32), cached."""
-    if N < 16:
+    if N < 4:
         return None
     key = ("packed", N, dtype, str(device))
     if key not in _FILTER_CACHE:

@@ -170,3 +170,29 @@ def test_two_process_gloo_sharded_sampling(tmp_path, total):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("OK") == 2
+
+
+def test_afldm_alias_and_diffusers_shim():
+    """`afldm.X` is the same module object as `afldm_amd.X`; the diffusers shim exposes the names
+    the reference's hot-path files import (af_blocks.py:6-7, cross_frame_attn.py:3, ldm_pipeline.py:1-4)."""
+    import importlib
+    import afldm_amd.compat as compat
+    shimmed = compat.install()
+    from afldm.af_modules.af_api import make_af_unet as a
+    from afldm_amd.af_modules.af_api import make_af_unet as b
+    assert a is b
+    from afldm.pipelines.cross_frame_attn import AttnState as s1
+    from afldm_amd.pipelines.cross_frame_attn import AttnState as s2
+    assert s1 is s2
+    import afldm.shift_utils.shifters, afldm.pipelines.ldm_pipeline, afldm.io_utils, afldm.af_libs.ideal_lpf  # noqa
+    with pytest.raises(ModuleNotFoundError):
+        importlib.import_module("afldm.trainers.ldm_trainer")        # out of scope: not provided
+    if shimmed:
+        from diffusers.models import UNet2DModel
+        from diffusers.models.attention_processor import AttnProcessor2_0  # noqa
+        from diffusers.models.downsampling import Downsample2D  # noqa
+        from diffusers.pipelines.pipeline_utils import DiffusionPipeline, ImagePipelineOutput  # noqa
+        from diffusers.schedulers import DDIMScheduler  # noqa
+        from diffusers.utils.torch_utils import randn_tensor  # noqa
+        from afldm_amd.models.unet_2d import UNet2DModel as U2
+        assert UNet2DModel is U2
