@@ -21,7 +21,7 @@ class ConvArgs(Structure):
         ("residual", c_void_p), ("y", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("C1", c_int), ("C2", c_int), ("B", c_int), ("H", c_int), ("W", c_int), ("Cout", c_int),
         ("KS", c_int), ("temb_stride", c_int), ("res_ld", c_int), ("y_ld", c_int),
-        ("out_mode", c_int), ("dtype", c_int),
+        ("out_mode", c_int), ("dtype", c_int), ("y2", c_void_p), ("split_n", c_int),
     ]
 
 

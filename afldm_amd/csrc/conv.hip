@@ -30,7 +30,9 @@ struct ConvP {
   const void* temb;
   const void* residual;
   void* y;
+  void* y2;      // optional second output (channel-major) for couts >= split_n
   float* ws;
+  int split_n;
   int C1, C2, B, H, W, Cout, KS;
   int temb_stride, res_ld, y_ld, out_mode;
   int M;        // B*H*W
@@ -50,6 +52,15 @@ __device__ __forceinline__ void epilogue_store(const ConvP& p, int m, int n, f32
   T* y = (T*)p.y;
   const int HW = p.H * p.W;
   const int b = m / HW;
+  if (p.y2 && n >= p.split_n) {   // second output: channel-major [B][Cout - split_n][HW] (V^T of a fused QKV GEMM)
+    T* y2 = (T*)p.y2;
+    const int pix = m - b * HW, c2 = p.Cout - p.split_n;
+    for (int r = 0; r < 4 && n + r < p.Cout; ++r) {
+      float sv = v[r] + (p.bias ? p.bias[n + r] : 0.f);
+      y2[((size_t)b * c2 + (n + r - p.split_n)) * HW + pix] = from_f32<T>(sv);
+    }
+    return;
+  }
   if (n + 3 < p.Cout && p.vec_ok) {
     if (p.bias) {
       f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
@@ -616,7 +627,10 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
   //   M < 1024                       : 64x64 LDS-DMA, 4 stages (short K loops are latency bound)
   // and split-K so that tiles * splitk ~ 2-3 workgroups per CU.
   int vid, bm, bn;
-  if (M >= 32768 && a->Cout % 192 == 0) { vid = 12; bm = 128; bn = 192; }
+  const int ksteps_all = a->KS * a->KS * (Ct / kstep);
+  const long long tiles64 = ((M + 63) / 64) * ((a->Cout + 63) / 64);
+  if (M < 32768 && ksteps_all <= 64 && tiles64 >= 256 && tiles64 <= 4096) { vid = 11; bm = 64; bn = 64; }  // short-K GEMMs: many small tiles, no split-K
+  else if (M >= 32768 && a->Cout % 192 == 0) { vid = 12; bm = 128; bn = 192; }
   else if (M >= 4096 && a->Cout % 128 == 0) { vid = 4; bm = 128; bn = 128; }
   else if (M >= 1024) { vid = 6; bm = 128; bn = 64; }
   else { vid = 11; bm = 64; bn = 64; }
@@ -728,6 +742,7 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
   ConvP p;
   p.x1 = a->x1; p.x2 = a->x2; p.w = a->w; p.bias = a->bias; p.temb = a->temb; p.residual = a->residual;
   p.y = a->y; p.ws = (float*)a->workspace;
+  p.y2 = a->y2; p.split_n = a->split_n;
   p.C1 = a->C1; p.C2 = a->C2; p.B = a->B; p.H = a->H; p.W = a->W; p.Cout = a->Cout; p.KS = a->KS;
   p.temb_stride = a->temb_stride; p.res_ld = a->res_ld; p.y_ld = a->y_ld; p.out_mode = a->out_mode;
   p.M = a->B * a->H * a->W;
@@ -788,7 +803,11 @@ static int conv_validate(const afldm_conv_args* a) {
                 "afldm_conv2d: bad shape B=%d H=%d W=%d Cout=%d C1=%d C2=%d", a->B, a->H, a->W, a->Cout, a->C1, a->C2);
   AFLDM_REQUIRE(a->C2 == 0 || a->x2 != nullptr, AFLDM_ENULL, "afldm_conv2d: C2>0 but x2 is NULL");
   AFLDM_REQUIRE(a->out_mode == 0 || a->out_mode == 1, AFLDM_ESHAPE, "afldm_conv2d: out_mode %d", a->out_mode);
-  AFLDM_REQUIRE(a->out_mode == 1 || a->y_ld >= a->Cout, AFLDM_ESHAPE, "afldm_conv2d: y_ld=%d < Cout=%d", a->y_ld, a->Cout);
+  AFLDM_REQUIRE(!a->y2 || (a->split_n > 0 && a->split_n % 4 == 0 && a->split_n < a->Cout && a->out_mode == 0 &&
+                           !a->temb && !a->residual),
+                AFLDM_ESHAPE, "afldm_conv2d: y2 needs 0 < split_n < Cout, split_n %% 4 == 0, out_mode 0, no temb/residual");
+  AFLDM_REQUIRE(a->out_mode == 1 || a->y_ld >= (a->y2 ? a->split_n : a->Cout), AFLDM_ESHAPE,
+                "afldm_conv2d: y_ld=%d too small for Cout=%d", a->y_ld, a->Cout);
   AFLDM_REQUIRE(!a->residual || a->res_ld >= a->Cout, AFLDM_ESHAPE, "afldm_conv2d: res_ld=%d < Cout=%d", a->res_ld, a->Cout);
   AFLDM_REQUIRE((long long)a->B * a->H * a->W < (1ll << 30), AFLDM_ESHAPE, "afldm_conv2d: M too large");
   AFLDM_REQUIRE(aligned16(a->x1) && aligned16(a->w) && aligned16(a->y) && aligned16(a->x2) && aligned16(a->residual) &&

@@ -54,6 +54,18 @@ def packed_conv(mod, dtype):
     return cache[key]
 
 
+def packed_qkv(attn, dtype, which):
+    """Row-concatenated (to_q | to_k | to_v subset) OHWI weight + fp32 bias, cached on the module."""
+    cache = attn.__dict__.setdefault("_afldm_cache", {})
+    key = ("qkv", dtype, which)
+    if key not in cache:
+        mods = [getattr(attn, "to_" + n) for n in which]
+        w = torch.cat([m.weight.detach().float() for m in mods], 0)
+        b = torch.cat([m.bias.detach().float() for m in mods], 0).contiguous()
+        cache[key] = (ops.pack_weight(w, dtype), b)
+    return cache[key]
+
+
 def packed_norm(mod):
     cache = mod.__dict__.setdefault("_afldm_cache", {})
     if "gn" not in cache:
@@ -240,10 +252,16 @@ class AttnProcessor2_0:
         stats = ops.gn_stats(hidden_states, gn.num_groups)
         hn = ops.gn_apply(hidden_states, stats, gamma, beta, gn.num_groups, gn.eps, act=0)
         tokens = hn.view(B, H * W, C)
-        src = tokens if encoder_hidden_states is None else encoder_hidden_states
-        q = linear_forward(attn.to_q, tokens)
-        k = linear_forward(attn.to_k, src)
-        vt = linear_forward(attn.to_v, src, out_mode=1)            # [Bk, C, T] channel-major
+        if encoder_hidden_states is None:
+            # fused Q|K|V projection: one GEMM reads the normed tokens once; Q and K land token-major
+            # side by side, V channel-major (the attention kernel's V^T operand)
+            w, b = packed_qkv(attn, tokens.dtype, ("q", "k", "v"))
+            qk, vt = ops.linear_split(tokens, w, b, 2 * C)
+            q, k = qk[:, :, :C], qk[:, :, C:]
+        else:
+            q = linear_forward(attn.to_q, tokens)
+            w, b = packed_qkv(attn, tokens.dtype, ("k", "v"))
+            k, vt = ops.linear_split(encoder_hidden_states, w, b, C)
         o = ops.attention(q, k, vt, attn.heads, scale=attn.scale)
         out = linear_forward(attn.to_out[0], o, residual=hidden_states.view(B, H * W, C))
         return out.view(B, H, W, C)

@@ -288,7 +288,7 @@ def af_resample(x, M, out=None, workspace=None):
 
 # ----------------------------------------------------------------------------- conv / linear
 def conv_args(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, out=None, out_mode=0,
-              workspace=None, y_ld=None):
+              workspace=None, y_ld=None, out2=None, split_n=0):
     """Build the afldm_conv_args struct (keeps references to the tensors alive in `.keep`)."""
     C1, x2, C2 = _cat_args(x1, x2)
     _dev(w, "w")
@@ -309,6 +309,9 @@ def conv_args(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None
     a.y_ld = Cout if y_ld is None else int(y_ld)
     a.out_mode = int(out_mode)
     a.dtype = _code(x1)
+    a.y2, a.split_n = ptr(out2), int(split_n)
+    if out2 is not None and y_ld is None:
+        a.y_ld = int(split_n)
     a.keep = (x1, x2, w, bias, temb, residual, out, workspace)
     return a
 
@@ -347,23 +350,49 @@ def conv_workspace_bytes(a):
     return lib.afldm_conv2d_workspace(ctypes.byref(a))
 
 
+def linear_split(x, w, bias, split_n, workspace=None):
+    """One GEMM over tokens x [B, T, C] with weight rows [0, split_n) -> token-major [B, T, split_n]
+    and rows [split_n, Cout) -> channel-major [B, Cout - split_n, T] (fused Q|K|V projection)."""
+    _dev(x, "x")
+    B, T, C = x.shape
+    Cout = w.shape[0]
+    y = torch.empty((B, T, split_n), dtype=x.dtype, device=x.device)
+    y2 = torch.empty((B, Cout - split_n, T), dtype=x.dtype, device=x.device)
+    a = conv_args(x, w, bias, out=y, out2=y2, split_n=split_n)
+    a.B, a.H, a.W = B, T, 1
+    if workspace is None:
+        need = lib.afldm_conv2d_workspace(ctypes.byref(a))
+        if need:
+            workspace = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+            a.workspace, a.workspace_bytes = ptr(workspace), need
+    tok = _begin()
+    check(lib.afldm_conv2d(ctypes.byref(a), stream_ptr()), "conv2d(split)")
+    _end(tok, "linear", 2.0 * B * T * Cout * C, (B * T * C + Cout * C + B * T * Cout) * x.element_size())
+    return y, y2
+
+
 def conv2d_launch(a):
     check(lib.afldm_conv2d(ctypes.byref(a), stream_ptr()), "conv2d")
 
 
 # ----------------------------------------------------------------------------- attention
 def attention(q, k, vt, heads, scale=None, out=None):
-    """q [B,Tq,C], k [Bk,Tk,C] token-major; vt [Bk,C,Tk] channel-major; returns [B,Tq,C]."""
-    _dev(q, "q"); _dev(k, "k"); _dev(vt, "vt")
+    """q [B,Tq,C], k [Bk,Tk,C] token-major (may be column slices of wider buffers: the leading
+    dimension is taken from stride(1)); vt [Bk,C,Tk] channel-major; returns [B,Tq,C]."""
+    _dev(vt, "vt")
+    if not (q.is_cuda and k.is_cuda):
+        raise RuntimeError("afldm_amd: attention inputs must live on an MI355X (cuda) device; there is no CPU path")
     B, Tq, C = q.shape
     Bk, Tk, _ = k.shape
+    ldq, ldk = q.stride(1), k.stride(1)
+    assert q.stride(2) == 1 and k.stride(2) == 1 and q.stride(0) == Tq * ldq and k.stride(0) == Tk * ldk
     d = C // heads
     if scale is None:
         scale = d ** -0.5
     if out is None:
-        out = torch.empty_like(q)
+        out = torch.empty((B, Tq, C), dtype=q.dtype, device=q.device)
     tok = _begin()
-    check(lib.afldm_attention(ptr(q), C, ptr(k), C, ptr(vt), ptr(out), C, B, Bk, heads, Tq, Tk, d, float(scale),
+    check(lib.afldm_attention(ptr(q), ldq, ptr(k), ldk, ptr(vt), ptr(out), C, B, Bk, heads, Tq, Tk, d, float(scale),
                               _code(q), stream_ptr()), "attention")
     _end(tok, "attention", 4.0 * B * heads * Tq * Tk * d, (2 * B * Tq * C + 2 * Bk * Tk * C) * q.element_size())
     return out

@@ -155,6 +155,10 @@ typedef struct {
   int res_ld, y_ld;
   int out_mode;
   int dtype;
+  /* optional column split (fused Q|K|V projection): couts >= split_n go, channel-major
+   * ([B][Cout - split_n][H*W]), to y2 instead of y; y then holds couts [0, split_n) with y_ld. */
+  void* y2;
+  int split_n;
 } afldm_conv_args;
 int afldm_conv2d(const afldm_conv_args* args, afldm_stream_t stream);
 /* Tuning hook (benchmarks only): force tile/pipeline variant `variant` (>= 0) and/or a split-K

@@ -268,3 +268,23 @@ def test_ddim_step(dtype):
         ref = s.step(eps, s.timesteps[i], x)
         assert (out.cpu() - ref).abs().max() <= 2e-5 * ref.abs().max()
         assert int(idx.item()) == i + 1
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fused_qkv_split_gemm_and_strided_attention(dtype):
+    """One GEMM -> Q|K token-major + V channel-major, consumed by attention through column slices."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    B, T, heads, d = 2, 64, 8, 24          # C = 192: a multiple of the bf16 K step (64)
+    C = heads * d
+    x = rnd(dtype, torch.randn(B, T, C, generator=g))
+    w = rnd(dtype, torch.randn(3 * C, C, generator=g) / C ** 0.5)
+    b = torch.randn(3 * C, generator=g)
+    qk, vt = ops.linear_split(x.to(device="cuda", dtype=dtype), ops.pack_weight(w.cuda(), dtype), b.cuda(), 2 * C)
+    ref = F.linear(x, w, b)
+    close(qk.float().cpu(), ref[..., :2 * C], dtype, "qk", bf16_rms=6e-3)
+    close(vt.float().cpu(), ref[..., 2 * C:].transpose(1, 2), dtype, "vt", bf16_rms=6e-3)
+    o = ops.attention(qk[:, :, :C], qk[:, :, C:], vt, heads)
+    q, k, v = (rnd(dtype, ref[..., i * C:(i + 1) * C]).view(B, T, heads, d).transpose(1, 2) for i in range(3))
+    oref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, T, C)
+    close(o.float().cpu(), oref, dtype, "attention on fused qkv", f32_tol=5e-5, bf16_rms=1.5e-2)
