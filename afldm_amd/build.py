@@ -61,6 +61,13 @@ def build(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        # hipcc can silently drop a kernel template (seen with ROCm 7.2): refuse a library whose own
+        # kernels are unresolved instead of failing at dlopen time on the GPU box
+        nm = subprocess.run(["nm", "-D", "--undefined-only", LIB], capture_output=True, text=True)
+        missing = [l.split()[-1] for l in nm.stdout.splitlines() if "afldm" in l]
+        if missing:
+            os.remove(LIB)
+            raise RuntimeError("libafldm_hip.so has unresolved afldm symbols: " + ", ".join(missing[:4]))
         if verbose:
             print("[afldm_amd.build] linked", LIB, flush=True)
     return LIB

@@ -344,36 +344,51 @@ __global__ void __launch_bounds__(WGM* WGN * 64) k_igemm2(ConvP p) {
   }
 
   // K cursor of the NEXT step to issue (wave-uniform scalars, advanced incrementally: no division
-  // in the loop)
+  // in the loop).  Per-lane voffsets are recomputed only when the filter tap changes; inside a tap
+  // the channel block advances through the SGPR soffset of the buffer load, so a K step costs no
+  // VALU address arithmetic (weights: never; pixels: once per tap).
   int is_kt = kbeg, is_tap = kbeg / cblocks, is_ci0 = (kbeg - is_tap * cblocks) * KSTEP;
   int is_kh = is_tap / p.KS, is_kw = is_tap - is_kh * p.KS;
+  unsigned xoff1[XPW], xoff2[XPW];   // byte voffset of (pixel + tap shift, channel kc*EPR + chunk) in x1 / x2, or OOB
+  unsigned woff[WPW];                 // byte voffset of (cout row, tap 0, channel kc*EPR + chunk), or OOB
+#pragma unroll
+  for (int i = 0; i < WPW; ++i)
+    woff[i] = wok[i] ? (wrow[i] * (unsigned)Ct + (unsigned)(wkc[i] * EPR + lchunk * EPC)) * ESZ : OOB;
+  auto retap = [&]() {
+    const int dh = is_kh - pad, dw = is_kw - pad;
+    const int dpix = dh * p.W + dw;
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) {
+      const int ih = xoh[i] + dh, iw = xow[i] + dw;
+      const bool ok = xok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      const unsigned pixel = (unsigned)((int)xbase[i] + dpix);
+      const unsigned cin = (unsigned)(xkc[i] * EPR + lchunk * EPC);
+      xoff1[i] = ok ? (pixel * (unsigned)p.C1 + cin) * ESZ : OOB;
+      xoff2[i] = ok ? (pixel * (unsigned)p.C2 + cin) * ESZ : OOB;
+    }
+  };
+  retap();
 
   auto issue = [&](int slot) {
     char* sbase = smem + slot * STAGE;
     const bool live = is_kt < kend;
     const bool second = is_ci0 >= p.C1;
-    const int Cs = second ? p.C2 : p.C1;
-    const int cs0 = second ? is_ci0 - p.C1 : is_ci0;
-    const int dh = is_kh - pad, dw = is_kw - pad;
-    const int dpix = dh * p.W + dw;
+    const unsigned xs = live ? (unsigned)((second ? is_ci0 - p.C1 : is_ci0) * ESZ) : OOB;      // SGPR offsets
+    const unsigned wsoff = live ? (unsigned)((is_tap * Ct + is_ci0) * ESZ) : OOB;
 #pragma unroll
     for (int i = 0; i < XPW; ++i) {
       const int j = wave + NW * i;
-      const int ih = xoh[i] + dh, iw = xow[i] + dw;
-      const bool ok = live && xok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-      const unsigned off = ok ? ((unsigned)((int)xbase[i] + dpix) * (unsigned)Cs + (unsigned)(cs0 + xkc[i] * EPR + lchunk * EPC)) * ESZ : OOB;
       lds_ptr_t dst = (lds_ptr_t)(sbase + j * 1024);
-      if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, dst, 16, off, 0, 0, 0);
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx1, dst, 16, off, 0, 0, 0);
+      // (explicit int casts: hipcc 7.2 silently drops the whole kernel template when an element of a
+      //  captured unsigned array is passed straight to this builtin)
+      if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, dst, 16, (int)xoff2[i], (int)xs, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx1, dst, 16, (int)xoff1[i], (int)xs, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
       const int j = wave + NW * i;
-      const unsigned off = (live && wok[i])
-                               ? ((wrow[i] + (unsigned)is_tap) * (unsigned)Ct + (unsigned)(is_ci0 + wkc[i] * EPR + lchunk * EPC)) * ESZ
-                               : OOB;
       lds_ptr_t dst = (lds_ptr_t)(sbase + X_STAGE + j * 1024);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, dst, 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, dst, 16, (int)woff[i], (int)wsoff, 0, 0);
     }
     // advance the cursor
     ++is_kt;
@@ -385,6 +400,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) k_igemm2(ConvP p) {
         is_kw = 0;
         ++is_kh;
       }
+      if (is_kt < kend) retap();
     }
   };
 
@@ -629,7 +645,7 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
   int vid, bm, bn;
   const int ksteps_all = a->KS * a->KS * (Ct / kstep);
   const long long tiles64 = ((M + 63) / 64) * ((a->Cout + 63) / 64);
-  if (M < 32768 && ksteps_all <= 64 && tiles64 >= 256 && tiles64 <= 4096) { vid = 11; bm = 64; bn = 64; }  // short-K GEMMs: many small tiles, no split-K
+  if (M <= 4096 && ksteps_all <= 64 && tiles64 >= 256) { vid = 11; bm = 64; bn = 64; }  // short-K GEMMs: many small tiles, no split-K
   else if (M >= 32768 && a->Cout % 192 == 0) { vid = 12; bm = 128; bn = 192; }
   else if (M >= 4096 && a->Cout % 128 == 0) { vid = 4; bm = 128; bn = 128; }
   else if (M >= 1024) { vid = 6; bm = 128; bn = 64; }
@@ -643,12 +659,12 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
   const long long tiles = ((M + bm - 1) / bm) * ((a->Cout + bn - 1) / bn);
   const int ksteps = a->KS * a->KS * (Ct / kstep);
   int sk = 1;
-  if (tiles < 384) {
-    sk = (int)((640 + tiles - 1) / tiles);
+  if (tiles < 256) {   // measured: ~320 workgroups and at most 4 K slices is the sweet spot (conv_variant_sweep2.log)
+    sk = (int)((320 + tiles - 1) / tiles);
     int maxsk = ksteps / 4;
     if (maxsk < 1) maxsk = 1;
     if (sk > maxsk) sk = maxsk;
-    if (sk > 16) sk = 16;
+    if (sk > 4) sk = 4;
     if (sk < 1) sk = 1;
   }
   pl.splitk = sk;
