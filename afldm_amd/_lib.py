@@ -25,6 +25,17 @@ class ConvArgs(Structure):
     ]
 
 
+class SepArgs(Structure):
+    _fields_ = [
+        ("x", c_void_p), ("y", c_void_p), ("M", c_void_p), ("M2", c_void_p), ("gn_table", c_void_p),
+        ("outer_count", ctypes.c_longlong), ("inner_count", ctypes.c_longlong),
+        ("in_outer_stride", ctypes.c_longlong), ("in_k_stride", ctypes.c_longlong),
+        ("out_outer_stride", ctypes.c_longlong), ("out_k_stride", ctypes.c_longlong),
+        ("K", c_int), ("R", c_int), ("R2", c_int), ("C", c_int), ("outer_per_sample", c_int),
+        ("act", c_int), ("dtype", c_int),
+    ]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -52,6 +63,9 @@ def _load():
         "afldm_af_up2": ([vp, vp, vp, vp, ip, ip, ip, ip, vp], c_int),
         "afldm_af_lpf_down2": ([vp, vp, vp, vp, ip, ip, ip, ip, vp], c_int),
         "afldm_af_resample": ([vp, vp, vp, vp, ip, ip, ip, ip, ip, vp], c_int),
+        "afldm_sep_pass": ([POINTER(SepArgs), vp], c_int),
+        "afldm_gn_table": ([vp, vp, vp, vp, ip, ip, ip, ip, fp, vp], c_int),
+        "afldm_softmax_rows": ([vp, vp, ctypes.c_longlong, ip, fp, ip, vp], c_int),
         "afldm_conv2d": ([POINTER(ConvArgs), vp], c_int),
         "afldm_conv2d_workspace": ([POINTER(ConvArgs)], c_size_t),
         "afldm_conv2d_tune": ([ip, ip], c_int),

@@ -62,7 +62,9 @@ class AliasFreeDownsample2D(Downsample2D):
 
     def forward(self, hidden_states, *args, **kwargs):
         assert hidden_states.shape[-1] == self.channels          # NHWC
-        if self.use_conv and self.padding == 0:
-            raise NotImplementedError("padding=0 (VAE encoder) downsampler: AF-VAE is a 'next' row (SURVEY 8f)")
+        # padding == 0 (VAE encoder): the reference zero-pads (1,1,1,1) and runs the conv unpadded
+        # (af_blocks.py:142-144) == a 'same' 3x3 conv, which is what the implicit GEMM computes;
+        # padding == 1 (UNet): the conv's own padding.  Both are the stride-1 'same' convolution.
+        assert self.padding in (0, 1) and tuple(self.conv.kernel_size) == (3, 3)
         hidden_states = conv_forward(self.conv, hidden_states)
         return ops.af_lpf_down2(hidden_states)

@@ -23,9 +23,7 @@ def install_diffusers_shim(force=False):
         sys.modules[name] = m
         return m
 
-    class AutoencoderKL:  # placeholder: the alias-free VAE is the next scope row
-        def __init__(self, *a, **k):
-            raise NotImplementedError("afldm_amd: AutoencoderKL (AF-VAE) is not implemented yet (SURVEY.md 8f rank 1)")
+    from .models.vae import AutoencoderKL
 
     root = mod("diffusers", UNet2DModel=UNet2DModel, DDIMScheduler=DDIMScheduler, AutoencoderKL=AutoencoderKL,
                DiffusionPipeline=DiffusionPipeline, __version__="0.32.1+afldm_amd_shim", __path__=[])

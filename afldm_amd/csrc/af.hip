@@ -67,38 +67,51 @@ struct AfCfg {
   static constexpr int RPW = SL / NW;                      // h' rows per wave in P2/P3
   static constexpr int RG = RPW < 4 ? RPW : 4;             // rows processed together (packed V writes)
   static constexpr bool PERM = sizeof(T) == 2;             // P3's matrix needs chain-permuted columns
-  // packed constants (= LDS image, elements of T): Us [H2][KH] | Ds [N][H2] | Dp [N][H2] (bf16 only)
-  static constexpr int US = H2 * KH;
-  static constexpr int DS = N * H2;
-  static constexpr int DPS = PERM ? N * H2 : 0;
+  // Every LDS array is a set of K-contiguous rows read as 16-byte chunks by 16 lanes at a time.
+  // Power-of-two row strides (64 / 128 B) put those lanes on the same banks (up to 8-way on the
+  // packed writes), so rows are padded by one chunk (guide G4).  fp32 N = 32 has no LDS to spare.
+  static constexpr int PAD = (sizeof(T) == 2 && N == 32) ? EPC : 0;   // (N = 16 keeps 2 workgroups per CU unpadded)
+  static constexpr int KHP = KH + PAD;                     // row stride of Xs / T1 / Us
+  static constexpr int H2P = H2 + PAD;                     // row stride of Ds / Dp
+  static constexpr int SLP = SL + PAD;                     // row stride of Vs
+  // packed constants (= LDS image, elements of T): Us [H2][KHP] | Ds [N][H2P] | Dp [N][H2P] (bf16 only)
+  static constexpr int US = H2 * KHP;
+  static constexpr int DS = N * H2P;
+  static constexpr int DPS = PERM ? N * H2P : 0;
   static constexpr int CONST_ELEMS = US + DS + DPS;
   // LDS carve (elements of T)
-  static constexpr int XS = N * 16 * KH;                   // also re-used as the output staging tile
-  static constexpr int T1S = SL * 16 * KH;
-  static constexpr int VS = N * 16 * SL;
+  static constexpr int XS = N * 16 * KHP;                  // also re-used as the output staging tile
+  static constexpr int T1S = SL * 16 * KHP;
+  static constexpr int VS = N * 16 * SLP;
   static constexpr int LDS_BYTES = (CONST_ELEMS + XS + T1S + VS) * (int)sizeof(T) + 2 * 16 * (int)sizeof(float);
   static_assert(WPW == 4, "P1 packs 4 consecutive w columns per store");
   static_assert(N * N * 16 <= XS, "output staging tile must fit in the X region");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+  static_assert(CONST_ELEMS % EPC == 0, "constant image must be whole chunks");
 };
 
 // Builds the LDS image of the filter matrices once (host calls it once per (N, dtype)).
 template <typename T, int N>
 __global__ void k_af_pack(const float* __restrict__ U, const float* __restrict__ D, T* __restrict__ out) {
   typedef AfCfg<T, N> CF;
-  constexpr int H2 = CF::H2, KH = CF::KH;
+  constexpr int H2 = CF::H2, KHP = CF::KHP, H2P = CF::H2P;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < CF::CONST_ELEMS; i += gridDim.x * blockDim.x) {
-    float v;
+    float v = 0.f;
     if (i < CF::US) {
-      const int r = i / KH, k = i - r * KH;
-      v = k < N ? U[r * N + k] : 0.f;
+      const int r = i / KHP, k = i - r * KHP;
+      if (k < N) v = U[r * N + k];
     } else if (i < CF::US + CF::DS) {
-      v = D[i - CF::US];
+      const int j = i - CF::US;
+      const int r = j / H2P, k = j - r * H2P;
+      if (k < H2) v = D[r * H2 + k];
     } else {
       // column 32f + 8g + e of Dp  <-  column 32f + (e < 4 ? 4g + e : 16 + 4g + e - 4) of D
       const int j = i - CF::US - CF::DS;
-      const int r = j / H2, k = j - r * H2;
-      const int f = k >> 5, g = (k >> 3) & 3, e = k & 7;
-      v = D[r * H2 + 32 * f + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4))];
+      const int r = j / H2P, k = j - r * H2P;
+      if (k < H2) {
+        const int f = k >> 5, g = (k >> 3) & 3, e = k & 7;
+        v = D[r * H2 + 32 * f + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4))];
+      }
     }
     out[i] = from_f32<T>(v);
   }
@@ -121,6 +134,7 @@ __global__ void __launch_bounds__(af_nw(N) * 64) k_af_act_mfma(AfP<T> p) {
   typedef Mma<T> MM;
   typedef typename MM::Chunk Chunk;
   constexpr int EPC = CF::EPC, KPF = CF::KPF, H2 = CF::H2, KH = CF::KH, SL = CF::SL, WPW = CF::WPW;
+  constexpr int KHP = CF::KHP, H2P = CF::H2P, SLP = CF::SLP;
   constexpr int NT = CF::NW * 64, RPW = CF::RPW, RG = CF::RG;
   constexpr int NKF1 = KH / KPF;   // chunk pairs when contracting an N-long axis
   constexpr int NKF3 = H2 / KPF;   // ... a 2N-long axis
@@ -152,7 +166,7 @@ __global__ void __launch_bounds__(af_nw(N) * 64) k_af_act_mfma(AfP<T> p) {
   if constexpr (KH > N) {
     for (int i = tid; i < SL * 16 * (KH - N); i += NT) {
       const int row = i / (KH - N), k = N + (i - row * (KH - N));
-      T1[row * KH + k] = from_f32<T>(0.f);
+      T1[row * KHP + k] = from_f32<T>(0.f);
     }
   }
 
@@ -233,7 +247,7 @@ __global__ void __launch_bounds__(af_nw(N) * 64) k_af_act_mfma(AfP<T> p) {
     if constexpr (KH > N) {  // the output staging of the previous item overwrote the X region: re-zero its K padding
       for (int i = tid; i < N * 16 * (KH - N); i += NT) {
         const int row = i / (KH - N), k = N + (i - row * (KH - N));
-        Xs[row * KH + k] = from_f32<T>(0.f);
+        Xs[row * KHP + k] = from_f32<T>(0.f);
       }
     }
     // ---- prefetched tile -> Xs[w][c][h] (h K-contiguous), GroupNorm applied
@@ -248,7 +262,7 @@ __global__ void __launch_bounds__(af_nw(N) * 64) k_af_act_mfma(AfP<T> p) {
           Chunk o;
 #pragma unroll
           for (int e = 0; e < EPC; ++e) o[e] = from_f32<T>(to_f32(pre[k][e][cc]) * sc + sh);
-          st16<Chunk>(Xs + ((size_t)(w * 16 + cq * EPC + cc)) * KH + hq * EPC, o);
+          st16<Chunk>(Xs + ((size_t)(w * 16 + cq * EPC + cc)) * KHP + hq * EPC, o);
         }
       }
     }
@@ -267,7 +281,7 @@ __global__ void __launch_bounds__(af_nw(N) * 64) k_af_act_mfma(AfP<T> p) {
     for (int ti = 0; ti < SL / 16; ++ti) {
       Chunk uf[NKF1];
 #pragma unroll
-      for (int kf = 0; kf < NKF1; ++kf) uf[kf] = ld16<Chunk>(Us + (s * SL + 16 * ti + li) * KH + kf * KPF + lg * EPC);
+      for (int kf = 0; kf < NKF1; ++kf) uf[kf] = ld16<Chunk>(Us + (s * SL + 16 * ti + li) * KHP + kf * KPF + lg * EPC);
       f32x4 acc[WPW];
 #pragma unroll
       for (int wi = 0; wi < WPW; ++wi) {
@@ -275,11 +289,11 @@ __global__ void __launch_bounds__(af_nw(N) * 64) k_af_act_mfma(AfP<T> p) {
         const int w = wave * WPW + wi;
 #pragma unroll
         for (int kf = 0; kf < NKF1; ++kf)
-          MM::mma(acc[wi], uf[kf], ld16<Chunk>(Xs + (w * 16 + li) * KH + kf * KPF + lg * EPC));
+          MM::mma(acc[wi], uf[kf], ld16<Chunk>(Xs + (w * 16 + li) * KHP + kf * KPF + lg * EPC));
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        store4<T>(T1 + ((16 * ti + 4 * lg + r) * 16 + li) * KH + wave * WPW, acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+        store4<T>(T1 + ((16 * ti + 4 * lg + r) * 16 + li) * KHP + wave * WPW, acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
     }
     __syncthreads();
 
@@ -293,14 +307,14 @@ __global__ void __launch_bounds__(af_nw(N) * 64) k_af_act_mfma(AfP<T> p) {
         const int hl = hl0 + q;
         Chunk tf[NKF1];
 #pragma unroll
-        for (int kf = 0; kf < NKF1; ++kf) tf[kf] = ld16<Chunk>(T1 + (hl * 16 + li) * KH + kf * KPF + lg * EPC);
+        for (int kf = 0; kf < NKF1; ++kf) tf[kf] = ld16<Chunk>(T1 + (hl * 16 + li) * KHP + kf * KPF + lg * EPC);
         f32x4 z[H2 / 16];
 #pragma unroll
         for (int t2 = 0; t2 < H2 / 16; ++t2) {
           z[t2] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int kf = 0; kf < NKF1; ++kf)
-            MM::mma(z[t2], ld16<Chunk>(Us + (16 * t2 + li) * KH + kf * KPF + lg * EPC), tf[kf]);
+            MM::mma(z[t2], ld16<Chunk>(Us + (16 * t2 + li) * KHP + kf * KPF + lg * EPC), tf[kf]);
 #pragma unroll
           for (int r = 0; r < 4; ++r) z[t2][r] = silu_f(z[t2][r]);
         }
@@ -317,7 +331,7 @@ __global__ void __launch_bounds__(af_nw(N) * 64) k_af_act_mfma(AfP<T> p) {
           v[q][t3] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int f = 0; f < NKF3; ++f)
-            MM::mma(v[q][t3], ld16<Chunk>(Dp + (16 * t3 + li) * H2 + f * KPF + lg * EPC), pb[f]);
+            MM::mma(v[q][t3], ld16<Chunk>(Dp + (16 * t3 + li) * H2P + f * KPF + lg * EPC), pb[f]);
         }
       }
       // V[w][c][h'] with the RG rows of this group contiguous -> one 8/16-byte LDS store each
@@ -328,7 +342,7 @@ __global__ void __launch_bounds__(af_nw(N) * 64) k_af_act_mfma(AfP<T> p) {
           float run[RG];
 #pragma unroll
           for (int q = 0; q < RG; ++q) run[q] = v[q][t3][r];
-          store_run<T, RG>(Vs + ((16 * t3 + 4 * lg + r) * 16 + li) * SL + hl0, run);
+          store_run<T, RG>(Vs + ((16 * t3 + 4 * lg + r) * 16 + li) * SLP + hl0, run);
         }
     }
     __syncthreads();
@@ -339,10 +353,10 @@ __global__ void __launch_bounds__(af_nw(N) * 64) k_af_act_mfma(AfP<T> p) {
       const int w = wave * WPW + wi;
 #pragma unroll
       for (int kf = 0; kf < NKF4; ++kf) {
-        Chunk vf = ld16<Chunk>(Vs + (w * 16 + li) * SL + kf * KPF + lg * EPC);
+        Chunk vf = ld16<Chunk>(Vs + (w * 16 + li) * SLP + kf * KPF + lg * EPC);
 #pragma unroll
         for (int t4 = 0; t4 < N / 16; ++t4)
-          MM::mma(yacc[wi][t4], ld16<Chunk>(Ds + (16 * t4 + li) * H2 + s * SL + kf * KPF + lg * EPC), vf);
+          MM::mma(yacc[wi][t4], ld16<Chunk>(Ds + (16 * t4 + li) * H2P + s * SL + kf * KPF + lg * EPC), vf);
       }
     }
     // no barrier needed here (see the slab protocol in the header comment): the next slab's P1

@@ -650,9 +650,9 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
   else if (M >= 4096 && a->Cout % 128 == 0) { vid = 4; bm = 128; bn = 128; }
   else if (M >= 1024) { vid = 6; bm = 128; bn = 64; }
   else { vid = 11; bm = 64; bn = 64; }
-  if (g_force_variant >= 0 && g_force_variant < 16) {
-    static const int fbm[16] = {128, 128, 64, 64, 128, 128, 128, 128, 128, 64, 64, 64, 128, 256, 256, 64};
-    static const int fbn[16] = {128, 64, 128, 64, 128, 128, 64, 64, 64, 128, 128, 64, 192, 64, 64, 64};
+  if (g_force_variant >= 0 && g_force_variant < 21) {
+    static const int fbm[21] = {128, 128, 64, 64, 128, 128, 128, 128, 128, 64, 64, 64, 128, 256, 256, 64, 128, 128, 128, 128, 128};
+    static const int fbn[21] = {128, 64, 128, 64, 128, 128, 64, 64, 64, 128, 128, 64, 192, 64, 64, 64, 192, 128, 192, 192, 128};
     vid = g_force_variant; bm = fbm[vid]; bn = fbn[vid];
   }
   pl.cfg = vid;
@@ -689,10 +689,10 @@ static void launch_igemm(const ConvP& p0, hipStream_t st) {
   k_igemm<T, BM, BN, WGM, WGN, KCH><<<grid, WGM * WGN * 64, lds, st>>>(p);
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int STAGES>
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int KCH = KCH_DEFAULT>
 static void launch_igemm2(const ConvP& p0, hipStream_t st) {
   ConvP p = p0;
-  constexpr int KCH = KCH_DEFAULT;
+  p.ksteps = p0.ksteps * KCH_DEFAULT / KCH;     // p0.ksteps counts KCH_DEFAULT-wide steps
   p.tiles_n = (p.Cout + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   dim3 grid(tiles_m * p.tiles_n, 1, p.splitk);
@@ -727,6 +727,11 @@ static const Variant kVariants[] = {
     {256, 64, 2, 2},   // 13
     {256, 64, 2, 3},   // 14
     {64, 64, 2, 6},    // 15
+    {128, 192, 2, 4},  // 16  (K step = one 64-byte row piece: KCH = 1)
+    {128, 128, 2, 4},  // 17  (KCH = 1)
+    {128, 192, 2, 3},  // 18  (KCH = 1)
+    {128, 192, 2, 2},  // 19  (KCH = 1: 40 KB LDS -> 4 workgroups per CU)
+    {128, 128, 2, 2},  // 20  (KCH = 1: 32 KB LDS)
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -749,6 +754,11 @@ static bool launch_variant(int id, const ConvP& p, hipStream_t st) {
     case 13: launch_igemm2<T, 256, 64, 4, 1, 2>(p, st); return true;
     case 14: launch_igemm2<T, 256, 64, 4, 1, 3>(p, st); return true;
     case 15: launch_igemm2<T, 64, 64, 2, 2, 6>(p, st); return true;
+    case 16: launch_igemm2<T, 128, 192, 2, 2, 4, 1>(p, st); return true;
+    case 17: launch_igemm2<T, 128, 128, 2, 2, 4, 1>(p, st); return true;
+    case 18: launch_igemm2<T, 128, 192, 2, 2, 3, 1>(p, st); return true;
+    case 19: launch_igemm2<T, 128, 192, 2, 2, 2, 1>(p, st); return true;
+    case 20: launch_igemm2<T, 128, 128, 2, 2, 2, 1>(p, st); return true;
   }
   return false;
 }

@@ -1,0 +1,309 @@
+// sep.hip — one-axis constant-matrix products for LARGE planes (the alias-free VAE: 64^2..256^2,
+// reference afldm/models/af_vae.py + af_api.make_af_vae), where a whole 2N x 2N plane no longer
+// fits in LDS and the alias-free operators become separable passes through HBM:
+//
+//   y[line][r] = act( sum_k M[r][k] * xn[line][k] )                    (R x K matrix M)
+//   y[line][r2] = sum_r M2[r2][r] * silu( sum_k M[r][k] xn[line][k] )   (chained: up -> SiLU -> down
+//                                                                       along one axis, in registers)
+// A "line" is a strided vector of the tensor (stride = in_k_stride elements); 16 memory-adjacent
+// lines (channels, or (w, c) pairs) form the MFMA column index j, so the matrix is always the A
+// operand (rows from LDS) and the data the B operand after a 16 x K transposing stage through LDS.
+// GroupNorm-apply (per (sample, channel) scale/shift table) can be fused into the load.
+//
+// Composition (host side, afldm_amd/ops.py):
+//   AF activation N >= 64 : [GN +] up-H  ->  up-W/SiLU/down-W chained  ->  down-H      (3 launches)
+//   UpsampleRFFT(2) / LPF+decimate at N >= 32 : pass over H, pass over W                (2 launches)
+#include "common.hpp"
+
+namespace afldm {
+
+struct SepP {
+  const void* x;
+  void* y;
+  const float* M;   // [R][K]
+  const float* M2;  // [R2][R] or NULL
+  const float* gn_table;  // [B][C][2] (scale, shift) or NULL
+  long long outer_count, inner_count;
+  long long in_outer_stride, in_k_stride, out_outer_stride, out_k_stride;
+  int C, outer_per_sample, act;
+};
+
+template <typename T, int K, int R, int R2>
+struct SepCfg {
+  typedef Mma<T> MM;
+  static constexpr int EPC = MM::EPC, KPF = MM::KPF;
+  static constexpr int KP = ((K + KPF - 1) / KPF) * KPF;   // K extent of the first product
+  static constexpr int KPS = KP + EPC;                     // padded LDS row strides (bank conflicts)
+  static constexpr int RP = ((R + KPF - 1) / KPF) * KPF;   // K extent of the chained product
+  static constexpr int RPS = RP + EPC;
+  static constexpr int RT = (R + 15) / 16, R2T = (R2 + 15) / 16;
+  static constexpr int M_ELEMS = RT * 16 * KPS;
+  static constexpr int M2_ELEMS = R2 > 0 ? R2T * 16 * RPS : 0;
+  static constexpr int TILE = 16 * KPS;
+  static constexpr int LDS_BYTES = (M_ELEMS + M2_ELEMS + 4 * TILE) * (int)sizeof(T);
+  static constexpr bool PERM = sizeof(T) == 2;
+};
+
+template <typename T, int K, int R, int R2>
+__global__ void __launch_bounds__(256) k_sep(SepP p) {
+  typedef SepCfg<T, K, R, R2> CF;
+  typedef Mma<T> MM;
+  typedef typename MM::Chunk Chunk;
+  constexpr int EPC = CF::EPC, KPF = CF::KPF, KP = CF::KP, KPS = CF::KPS, RP = CF::RP, RPS = CF::RPS;
+  constexpr int RT = CF::RT, R2T = CF::R2T, NKF1 = KP / KPF, NKF2 = R2 > 0 ? RP / KPF : 1;
+  static_assert(R2 == 0 || (RT % 2 == 0 || !CF::PERM), "chained bf16 product packs row tiles in pairs");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* Ms = reinterpret_cast<T*>(smem);
+  T* M2s = Ms + CF::M_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  T* tile = M2s + CF::M2_ELEMS + wave * CF::TILE;
+  const int li = lane & 15, lg = lane >> 4;
+
+  // ---- matrices -> LDS (zero padded; M2 columns chain-permuted for bf16), once per workgroup
+  for (int i = tid; i < CF::M_ELEMS; i += 256) {
+    const int r = i / KPS, k = i - r * KPS;
+    Ms[i] = from_f32<T>((r < R && k < K) ? p.M[(size_t)r * K + k] : 0.f);
+  }
+  if constexpr (R2 > 0) {
+    for (int i = tid; i < CF::M2_ELEMS; i += 256) {
+      const int r = i / RPS;
+      int k = i - r * RPS;
+      float v = 0.f;
+      if (k < RP) {
+        if (CF::PERM) {  // column 32f + 8g + e  <-  column 32f + (e < 4 ? 4g + e : 16 + 4g + e - 4)
+          const int f = k >> 5, g = (k >> 3) & 3, e = k & 7;
+          k = 32 * f + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4));
+        }
+        if (r < R2 && k < R) v = p.M2[(size_t)r * R + k];
+      }
+      M2s[i] = from_f32<T>(v);
+    }
+  }
+  if constexpr (KP > K) {  // K padding of this wave's tile (never overwritten)
+    for (int i = lane; i < 16 * (KP - K); i += 64) {
+      const int row = i / (KP - K), k = K + (i - row * (KP - K));
+      tile[row * KPS + k] = from_f32<T>(0.f);
+    }
+  }
+  __syncthreads();
+
+  const long long groups_per_outer = p.inner_count / 16;
+  const long long ngroups = p.outer_count * groups_per_outer;
+  const T* x = (const T*)p.x;
+  T* y = (T*)p.y;
+  for (long long g0 = (long long)blockIdx.x * 4; g0 < ngroups; g0 += (long long)gridDim.x * 4) {
+    const long long grp = g0 + wave;
+    const bool live = grp < ngroups;
+    const long long outer = live ? grp / groups_per_outer : 0;
+    const long long inner0 = live ? (grp - outer * groups_per_outer) * 16 : 0;
+    const T* src = x + outer * p.in_outer_stride + inner0;
+    // per-line GroupNorm scale / shift (line = inner0 + li; channel = line % C)
+    float sc = 1.f, sh = 0.f;
+    if (p.gn_table) {
+      const int c = (int)((inner0 + li) % p.C);
+      const long long b = outer / p.outer_per_sample;
+      const f32x2 t = *reinterpret_cast<const f32x2*>(p.gn_table + ((size_t)b * p.C + c) * 2);
+      sc = t[0];
+      sh = t[1];
+    }
+    constexpr int CQ = 16 / EPC, KQ = K / EPC, UNITS = CQ * KQ;
+    static_assert(K % EPC == 0, "K must be a whole number of chunks");
+    float usc[EPC], ush[EPC];
+#pragma unroll
+    for (int cc = 0; cc < EPC; ++cc) {
+      usc[cc] = __shfl(sc, (lane % CQ) * EPC + cc, 64);
+      ush[cc] = __shfl(sh, (lane % CQ) * EPC + cc, 64);
+    }
+    __syncthreads();   // the previous group's fragment reads of `tile` are complete
+    if (live) {
+      for (int u = lane; u < UNITS; u += 64) {
+        const int cq = u % CQ, kq = u / CQ;
+        Chunk ch[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) ch[e] = ld16<Chunk>(src + (long long)(kq * EPC + e) * p.in_k_stride + cq * EPC);
+#pragma unroll
+        for (int cc = 0; cc < EPC; ++cc) {
+          Chunk o;
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) o[e] = from_f32<T>(to_f32(ch[e][cc]) * usc[cc] + ush[cc]);
+          st16<Chunk>(tile + (cq * EPC + cc) * KPS + kq * EPC, o);
+        }
+      }
+    }
+    __syncthreads();
+
+    Chunk xf[NKF1];
+#pragma unroll
+    for (int kf = 0; kf < NKF1; ++kf) xf[kf] = ld16<Chunk>(tile + li * KPS + kf * KPF + lg * EPC);
+    T* dst = y + outer * p.out_outer_stride + inner0 + li;
+    if constexpr (R2 == 0) {
+      for (int t = 0; t < RT; ++t) {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kf = 0; kf < NKF1; ++kf) MM::mma(z, ld16<Chunk>(Ms + (16 * t + li) * KPS + kf * KPF + lg * EPC), xf[kf]);
+        if (live) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * t + 4 * lg + r;
+            if (row < R) dst[(long long)row * p.out_k_stride] = from_f32<T>(p.act ? silu_f(z[r]) : z[r]);
+          }
+        }
+      }
+    } else {
+      f32x4 z[RT];
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kf = 0; kf < NKF1; ++kf) MM::mma(z[t], ld16<Chunk>(Ms + (16 * t + li) * KPS + kf * KPF + lg * EPC), xf[kf]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[t][r] = silu_f(z[t][r]);
+      }
+      Chunk pb[NKF2];
+      if constexpr (CF::PERM) {
+#pragma unroll
+        for (int f = 0; f < NKF2; ++f) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pb[f][r] = (bf16)z[2 * f][r];
+            pb[f][4 + r] = (bf16)z[2 * f + 1][r];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int f = 0; f < NKF2; ++f) pb[f] = z[f];
+      }
+      for (int t = 0; t < R2T; ++t) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < NKF2; ++f) MM::mma(v, ld16<Chunk>(M2s + (16 * t + li) * RPS + f * KPF + lg * EPC), pb[f]);
+        if (live) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * t + 4 * lg + r;
+            if (row < R2) dst[(long long)row * p.out_k_stride] = from_f32<T>(v[r]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// (scale, shift) per (sample, channel) from GroupNorm partial sums: table[b][c] = (rstd*gamma, beta - mean*rstd*gamma)
+__global__ void __launch_bounds__(256) k_gn_table(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, float* __restrict__ table, int B, int C,
+                                                  int G, int S, double n, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i - b * C, cpg = C / G;
+  float mean, rstd;
+  gn_finalize(part, S, G, b, c / cpg, n, eps, mean, rstd);
+  const float k = rstd * gamma[c];
+  table[2 * i + 0] = k;
+  table[2 * i + 1] = beta[c] - mean * k;
+}
+
+// row softmax: y[r][:] = softmax(x[r][:] * scale), one workgroup per row (cols <= 16384)
+template <typename T>
+__global__ void __launch_bounds__(256) k_softmax_rows(const T* __restrict__ x, T* __restrict__ y, int cols, float scale) {
+  __shared__ float red[8];
+  const T* xr = x + (size_t)blockIdx.x * cols;
+  T* yr = y + (size_t)blockIdx.x * cols;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float m = -1e30f;
+  for (int i = threadIdx.x; i < cols; i += 256) m = fmaxf(m, to_f32(xr[i]) * scale);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int i = threadIdx.x; i < cols; i += 256) s += __expf(to_f32(xr[i]) * scale - m);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+  for (int i = threadIdx.x; i < cols; i += 256) yr[i] = from_f32<T>(__expf(to_f32(xr[i]) * scale - m) * inv);
+}
+
+template <typename T, int K, int R, int R2>
+static int launch_sep(const SepP& p, hipStream_t st) {
+  typedef SepCfg<T, K, R, R2> CF;
+  static_assert(CF::LDS_BYTES <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_sep<T, K, R, R2>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
+    attr_set = true;
+  }
+  const long long ngroups = p.outer_count * (p.inner_count / 16);
+  const int per_cu = (160 * 1024) / CF::LDS_BYTES >= 2 ? 2 : 1;
+  long long grid = 256 * per_cu;
+  if (grid * 4 > ngroups) grid = (ngroups + 3) / 4;
+  k_sep<T, K, R, R2><<<(int)grid, 256, CF::LDS_BYTES, st>>>(p);
+  return check_launch("afldm_sep_pass");
+}
+
+template <typename T>
+static int sep_dispatch(const SepP& p, int K, int R, int R2, hipStream_t st) {
+#define AFLDM_SEP(K_, R_, R2_) \
+  if (K == K_ && R == R_ && R2 == R2_) return launch_sep<T, K_, R_, R2_>(p, st);
+  // x2 upsampling passes (K = N, R = 2N), decimating passes (K = N, R = N/2) and the 2N -> N
+  // passes of the large-plane activation, for the plane sizes of the AF-VAE (and small ones for tests)
+  AFLDM_SEP(16, 32, 0) AFLDM_SEP(32, 64, 0) AFLDM_SEP(64, 128, 0)
+  AFLDM_SEP(32, 16, 0) AFLDM_SEP(64, 32, 0) AFLDM_SEP(128, 64, 0)
+  AFLDM_SEP(16, 32, 16) AFLDM_SEP(32, 64, 32) AFLDM_SEP(64, 128, 64)
+  if constexpr (sizeof(T) == 2) {   // the 128^2 / 256^2 planes fit LDS in bf16 only
+    AFLDM_SEP(128, 256, 0) AFLDM_SEP(256, 128, 0) AFLDM_SEP(128, 256, 128)
+  }
+#undef AFLDM_SEP
+  set_error("afldm_sep_pass: no kernel for K=%d R=%d R2=%d in this dtype", K, R, R2);
+  return AFLDM_ESHAPE;
+}
+
+}  // namespace afldm
+
+using namespace afldm;
+
+extern "C" int afldm_sep_pass(const afldm_sep_args* a, afldm_stream_t stream) {
+  AFLDM_REQUIRE(a && a->x && a->y && a->M, AFLDM_ENULL, "afldm_sep_pass: NULL pointer");
+  AFLDM_REQUIRE(a->outer_count > 0 && a->inner_count > 0 && a->inner_count % 16 == 0, AFLDM_ESHAPE,
+                "afldm_sep_pass: inner_count=%lld must be a positive multiple of 16", (long long)a->inner_count);
+  AFLDM_REQUIRE(a->in_k_stride % 8 == 0 && a->in_outer_stride % 8 == 0 && aligned16(a->x), AFLDM_EALIGN,
+                "afldm_sep_pass: input strides must keep 16-byte chunks aligned");
+  AFLDM_REQUIRE(!a->gn_table || (a->C > 0 && a->outer_per_sample > 0), AFLDM_ESHAPE, "afldm_sep_pass: GN table needs C and outer_per_sample");
+  AFLDM_REQUIRE(a->R2 == 0 || a->M2, AFLDM_ENULL, "afldm_sep_pass: R2 > 0 needs M2");
+  SepP p;
+  p.x = a->x; p.y = a->y; p.M = a->M; p.M2 = a->R2 > 0 ? a->M2 : nullptr; p.gn_table = a->gn_table;
+  p.outer_count = a->outer_count; p.inner_count = a->inner_count;
+  p.in_outer_stride = a->in_outer_stride; p.in_k_stride = a->in_k_stride;
+  p.out_outer_stride = a->out_outer_stride; p.out_k_stride = a->out_k_stride;
+  p.C = a->C; p.outer_per_sample = a->outer_per_sample; p.act = a->act;
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == AFLDM_F32) return sep_dispatch<float>(p, a->K, a->R, a->R2, st);
+  if (a->dtype == AFLDM_BF16) return sep_dispatch<bf16>(p, a->K, a->R, a->R2, st);
+  set_error("afldm_sep_pass: unknown dtype %d", a->dtype);
+  return AFLDM_EDTYPE;
+}
+
+extern "C" int afldm_gn_table(const float* part, const float* gamma, const float* beta, float* table, int B, int C, int G,
+                              int HW, float eps, afldm_stream_t stream) {
+  AFLDM_REQUIRE(part && gamma && beta && table, AFLDM_ENULL, "afldm_gn_table: NULL pointer");
+  AFLDM_REQUIRE(B > 0 && C > 0 && G > 0 && C % G == 0 && HW > 0, AFLDM_ESHAPE, "afldm_gn_table: bad shape");
+  const int n = B * C;
+  k_gn_table<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(part, gamma, beta, table, B, C, G, gn_splits(HW),
+                                                                 (double)HW * (C / G), eps);
+  return check_launch("afldm_gn_table");
+}
+
+extern "C" int afldm_softmax_rows(const void* x, void* y, long long rows, int cols, float scale, int dtype,
+                                  afldm_stream_t stream) {
+  AFLDM_REQUIRE(x && y, AFLDM_ENULL, "afldm_softmax_rows: NULL pointer");
+  AFLDM_REQUIRE(rows > 0 && rows < (1ll << 31) && cols > 0, AFLDM_ESHAPE, "afldm_softmax_rows: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, (k_softmax_rows<float><<<(int)rows, 256, 0, st>>>((const float*)x, (float*)y, cols, scale)),
+             (k_softmax_rows<bf16><<<(int)rows, 256, 0, st>>>((const bf16*)x, (bf16*)y, cols, scale)), "afldm_softmax_rows");
+  return check_launch("afldm_softmax_rows");
+}

@@ -252,6 +252,15 @@ class AttnProcessor2_0:
         stats = ops.gn_stats(hidden_states, gn.num_groups)
         hn = ops.gn_apply(hidden_states, stats, gamma, beta, gn.num_groups, gn.eps, act=0)
         tokens = hn.view(B, H * W, C)
+        if C // attn.heads > 32:
+            # large head_dim (the VAE mid block: one head of 512): GEMM - row softmax - GEMM per sample
+            src = tokens if encoder_hidden_states is None else encoder_hidden_states
+            q = linear_forward(attn.to_q, tokens)
+            k = linear_forward(attn.to_k, src)
+            vt = linear_forward(attn.to_v, src, out_mode=1)
+            o = ops.attention_dense(q, k, vt, attn.scale)
+            out = linear_forward(attn.to_out[0], o, residual=hidden_states.view(B, H * W, C))
+            return out.view(B, H, W, C)
         if encoder_hidden_states is None:
             # fused Q|K|V projection: one GEMM reads the normed tokens once; Q and K land token-major
             # side by side, V channel-major (the attention kernel's V^T operand)
@@ -361,7 +370,9 @@ class UNetMidBlock2D(_BlockBase):
         self.attentions = (self._attns(num_layers, in_channels, attention_head_dim, resnet_eps, attn_groups)
                            if add_attention else nn.ModuleList([None] * num_layers))
 
-    def forward(self, hidden_states, temb_slices):
+    def forward(self, hidden_states, temb_slices=None):
+        if temb_slices is None:                       # VAE: no time embedding
+            temb_slices = [(None, 0)] * len(self.resnets)
         hidden_states = self.resnets[0](hidden_states, *temb_slices[0])
         for i, (attn, resnet) in enumerate(zip(self.attentions, self.resnets[1:])):
             if attn is not None:

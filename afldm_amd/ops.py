@@ -7,7 +7,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ConvArgs, DTYPE_CODE, check, lib, ptr, stream_ptr
+from ._lib import ConvArgs, DTYPE_CODE, SepArgs, check, lib, ptr, stream_ptr
 
 _FILTER_CACHE = {}
 _PROFILE = None
@@ -219,10 +219,14 @@ def af_act(x1, x2=None, stats=None, gamma=None, beta=None, G=0, eps=0.0, out=Non
     C1, x2, C2 = _cat_args(x1, x2)
     B, N, N2, _ = x1.shape
     assert N == N2, "the reference's ideal filters assume square planes (ideal_lpf.py:80)"
-    U, D = filter_matrices(N, x1.device)
-    packed = packed_filters(N, x1.dtype, x1.device)
     if out is None:
         out = torch.empty((B, N, N, C1 + C2), dtype=x1.dtype, device=x1.device)
+    if N > 32:
+        if x2 is not None:
+            raise RuntimeError("afldm_amd: the large-plane activation path (N > 32) does not take a virtual concat")
+        return _af_act_large(x1, stats, gamma, beta, G, eps, out)
+    U, D = filter_matrices(N, x1.device)
+    packed = packed_filters(N, x1.dtype, x1.device)
     tok = _begin()
     check(lib.afldm_af_act(ptr(x1), C1, ptr(x2), C2, ptr(stats), ptr(gamma), ptr(beta), int(G), float(eps), ptr(U),
                            ptr(D), ptr(packed), ptr(out), B, N, _code(x1), stream_ptr()), "af_act")
@@ -238,6 +242,8 @@ def af_up2(x, out=None, workspace=None):
     U = up_matrix(N, 2, x.device)
     if out is None:
         out = torch.empty((B, 2 * N, 2 * N, C), dtype=x.dtype, device=x.device)
+    if N >= 32 and C % 16 == 0:
+        return _resample_large(x, U, 2 * N, out)
     if workspace is None:
         workspace = torch.empty(B * 2 * N * N * C, dtype=torch.float32, device=x.device)
     assert workspace.numel() >= B * 2 * N * N * C
@@ -254,6 +260,8 @@ def af_lpf_down2(x, out=None, workspace=None):
     D = down_matrix(N, x.device)
     if out is None:
         out = torch.empty((B, N // 2, N // 2, C), dtype=x.dtype, device=x.device)
+    if N >= 64 and C % 16 == 0:
+        return _resample_large(x, D, N // 2, out)
     if workspace is None:
         workspace = torch.empty(B * (N // 2) * N * C, dtype=torch.float32, device=x.device)
     assert workspace.numel() >= B * (N // 2) * N * C
@@ -261,6 +269,80 @@ def af_lpf_down2(x, out=None, workspace=None):
     check(lib.afldm_af_lpf_down2(ptr(x), ptr(D), ptr(out), ptr(workspace), B, N, C, _code(x), stream_ptr()),
           "af_lpf_down2")
     _end(tok, "af_lpf_down2", 1.5 * N ** 3 * B * C, 1.25 * B * N * N * C * x.element_size())
+    return out
+
+
+# ----------------------------------------------------------------------------- large planes (AF-VAE)
+def sep_pass(x, y, M, K, R, outer_count, inner_count, in_outer_stride, in_k_stride, out_outer_stride, out_k_stride,
+             M2=None, R2=0, gn_table=None, C=0, outer_per_sample=1, act=0):
+    """One separable pass (afldm_sep_pass): y[line][r] = act(M xn[line]) or M2 silu(M xn[line])."""
+    a = SepArgs()
+    a.x, a.y, a.M, a.M2, a.gn_table = ptr(x), ptr(y), ptr(M), ptr(M2), ptr(gn_table)
+    a.outer_count, a.inner_count = int(outer_count), int(inner_count)
+    a.in_outer_stride, a.in_k_stride = int(in_outer_stride), int(in_k_stride)
+    a.out_outer_stride, a.out_k_stride = int(out_outer_stride), int(out_k_stride)
+    a.K, a.R, a.R2, a.C, a.outer_per_sample, a.act = int(K), int(R), int(R2), int(C), int(outer_per_sample), int(act)
+    a.dtype = _code(x)
+    tok = _begin()
+    check(lib.afldm_sep_pass(ctypes.byref(a), stream_ptr()), "sep_pass")
+    lines = outer_count * inner_count
+    _end(tok, "sep_pass", 2.0 * lines * K * R + (2.0 * lines * R * R2 if R2 else 0.0),
+         lines * (K + (R2 if R2 else R)) * x.element_size())
+    return y
+
+
+def gn_table(stats, gamma, beta, B, C, G, HW, eps):
+    """[B, C, 2] (scale, shift) table from GroupNorm partial sums (for the large-plane passes)."""
+    out = torch.empty((B, C, 2), dtype=torch.float32, device=stats.device)
+    check(lib.afldm_gn_table(ptr(stats), ptr(gamma), ptr(beta), ptr(out), B, C, G, HW, float(eps), stream_ptr()),
+          "gn_table")
+    return out
+
+
+def _af_act_large(x, stats, gamma, beta, G, eps, out):
+    """WarpedNonlinearity on planes too large for LDS (N >= 64): up-H, (up-W, SiLU, down-W) chained,
+    down-H — three MFMA passes through HBM with intermediates in the activation dtype."""
+    B, N, _, C = x.shape
+    U, D = filter_matrices(N, x.device)
+    table = gn_table(stats, gamma, beta, B, C, G, N * N, eps) if stats is not None else None
+    t1 = torch.empty((B, 2 * N, N, C), dtype=x.dtype, device=x.device)
+    sep_pass(x, t1, U, N, 2 * N, B, N * C, N * N * C, N * C, 2 * N * N * C, N * C,
+             gn_table=table, C=C, outer_per_sample=1)
+    v = torch.empty((B, 2 * N, N, C), dtype=x.dtype, device=x.device)
+    sep_pass(t1, v, U, N, 2 * N, B * 2 * N, C, N * C, C, N * C, C, M2=D, R2=N)
+    del t1
+    sep_pass(v, out, D, 2 * N, N, B, N * C, 2 * N * N * C, N * C, N * N * C, N * C)
+    return out
+
+
+def _resample_large(x, M, R, out):
+    """y = M x M^T per plane via two MFMA passes (planes N >= 32 of the AF-VAE)."""
+    B, N, _, C = x.shape
+    tmp = torch.empty((B, R, N, C), dtype=x.dtype, device=x.device)
+    sep_pass(x, tmp, M, N, R, B, N * C, N * N * C, N * C, R * N * C, N * C)
+    sep_pass(tmp, out, M, N, R, B * R, C, N * C, C, R * C, C)
+    return out
+
+
+def softmax_rows(x, scale=1.0, out=None):
+    _dev(x, "x")
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.afldm_softmax_rows(ptr(x), ptr(out), rows, cols, float(scale), _code(x), stream_ptr()), "softmax_rows")
+    return out
+
+
+def attention_dense(q, k, vt, scale):
+    """Single-head attention with a large head_dim (the VAE mid block: d = 512, T = 1024) as two
+    per-sample GEMMs around a row softmax.  q, k: [B, T, C] contiguous; vt: [B, C, T]."""
+    B, T, C = q.shape
+    out = torch.empty_like(q)
+    for b in range(B):
+        s = conv2d(q[b].view(1, T, 1, C), k[b].view(T, 1, 1, C))                # [1, T, 1, T] scores
+        p = softmax_rows(s.view(T, T), scale)
+        conv2d(p.view(1, T, 1, T), vt[b].view(C, 1, 1, T), out=out[b].view(1, T, 1, C))
     return out
 
 

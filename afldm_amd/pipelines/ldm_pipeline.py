@@ -1,8 +1,8 @@
 """MyLDMPipeline — surface of reference afldm/pipelines/ldm_pipeline.py:17-160 on MI355X.
 
 `__call__(output_type='latent')` is the throughput entry point: the DDIM loop runs as a
-replayed HIP graph (afldm_amd.engine.DenoiseEngine).  Decoding needs the alias-free VAE, which
-is the next row of the scope table and raises until it lands."""
+replayed HIP graph (afldm_amd.engine.DenoiseEngine); other output types decode through the
+(alias-free) AutoencoderKL of afldm_amd.models.vae."""
 import inspect
 import json
 import os
@@ -33,7 +33,8 @@ class MyLDMPipeline(DiffusionPipeline):
             scheduler = DDIMScheduler.from_config(json.load(f))
         vae = None
         if os.path.isdir(os.path.join(path, "vae")):
-            raise NotImplementedError("the alias-free VAE is not implemented yet (SURVEY.md 8f rank 1)")
+            from ..models.vae import AutoencoderKL
+            vae = AutoencoderKL.from_pretrained(path, subfolder="vae")
         return cls(vae, unet, scheduler)
 
     def _engine(self, batch, steps, use_graph):
@@ -57,8 +58,7 @@ class MyLDMPipeline(DiffusionPipeline):
         if output_type == "latent":
             return latents
         if self.vae is None:
-            raise NotImplementedError("decoding needs the alias-free VAE (SURVEY.md 8f rank 1); "
-                                      "use output_type='latent'")
+            raise NotImplementedError("this pipeline was built without a VAE: use output_type='latent'")
         latents = latents.to(self.vae.dtype) / self.vae.config.scaling_factor
         image = self.vae.decode(latents).sample
         if output_type != "pt":

@@ -130,6 +130,37 @@ int afldm_af_lpf_down2(const void* x, const float* D, void* y, float* workspace,
 int afldm_af_resample(const void* x, const float* M, void* y, float* workspace, int B, int N, int C,
                       int R, int dtype, afldm_stream_t stream);
 
+/* ---- large-plane separable passes (alias-free VAE, planes 64^2 .. 256^2) ----------------------
+ * y[line][r] = act(sum_k M[r][k] xn[line][k])            or, with M2 (chained in registers):
+ * y[line][r2] = sum_r M2[r2][r] silu(sum_k M[r][k] xn[line][k])
+ * A line is a strided vector: element k of line (outer, inner) sits at
+ *   x + outer * in_outer_stride + inner + k * in_k_stride      (inner_count lines are contiguous).
+ * xn = x * scale[b][c] + shift[b][c] when gn_table != NULL (b = outer / outer_per_sample,
+ * c = inner % C; table from afldm_gn_table).  Used for UpsampleRFFT / LPF_RFFT on big planes and,
+ * in three launches (up-H; up-W -> SiLU -> down-W chained; down-H), for WarpedNonlinearity when the
+ * 2N x 2N plane does not fit LDS (af_blocks.py:19-28 at N = 64, 128 in the AF-VAE). */
+typedef struct {
+  const void* x;
+  void* y;
+  const float* M;        /* [R][K] device fp32 */
+  const float* M2;       /* [R2][R] device fp32, or NULL */
+  const float* gn_table; /* [B][C][2] device fp32, or NULL */
+  long long outer_count, inner_count;
+  long long in_outer_stride, in_k_stride, out_outer_stride, out_k_stride; /* elements */
+  int K, R, R2;
+  int C, outer_per_sample;
+  int act;   /* 1: SiLU after M (only when R2 == 0) */
+  int dtype;
+} afldm_sep_args;
+int afldm_sep_pass(const afldm_sep_args* args, afldm_stream_t stream);
+/* table[b][c] = (rstd * gamma[c], beta[c] - mean * rstd * gamma[c]) from afldm_gn_stats partial sums */
+int afldm_gn_table(const float* part, const float* gamma, const float* beta, float* table, int B,
+                   int C, int G, int HW, float eps, afldm_stream_t stream);
+/* y[r][:] = softmax(x[r][:] * scale): the single-head d = 512 attention of the VAE mid block is
+ * two GEMMs (afldm_conv2d with per-sample "weights") around this kernel. */
+int afldm_softmax_rows(const void* x, void* y, long long rows, int cols, float scale, int dtype,
+                       afldm_stream_t stream);
+
 /* ---- convolution / linear as implicit GEMM on MFMA --------------------------------------
  * y[b,oh,ow,n] = bias[n] + temb[b*temb_stride + n] + residual[b,oh,ow,n]
  *              + sum_{kh,kw,ci} x[b, oh+kh-KS/2, ow+kw-KS/2, ci] * w[n,kh,kw,ci]

@@ -185,6 +185,32 @@ def part_b():
     np.savez_compressed(os.path.join(OUT, "g7_scheduler.npz"), **g)
 
 
+def part_c():
+    """Oracle-generated AF-VAE vectors (tiny same-topology config, 64x64 images -> 8x8 latents)."""
+    from . import vae as ov
+    from .shift import shift_ideal
+    torch.set_num_threads(8)
+    cfg = ov.tiny_vae()
+    sd = ov.init_vae_params(cfg, seed=3)
+    gen = torch.Generator().manual_seed(77)
+    x = torch.rand(2, 3, 64, 64, generator=gen) * 2 - 1
+    m = ov.encode_moments(sd, cfg, x)
+    z = torch.randn(2, 4, 8, 8, generator=gen)
+    img = ov.decode(sd, cfg, z)
+    g = {"x": x.numpy(), "moments": m.numpy(), "z": z.numpy(), "img": img.numpy()}
+    # large-plane activation vectors for the separable-pass kernels (N = 64 with GroupNorm)
+    xa = torch.randn(1, 32, 64, 64, generator=gen) * 1.5 + 0.2
+    gam, bet = 1 + 0.2 * torch.randn(32, generator=gen), 0.1 * torch.randn(32, generator=gen)
+    g["act64_x"], g["act64_gamma"], g["act64_beta"] = xa.numpy(), gam.numpy(), bet.numpy()
+    g["act64_y"] = idf_warp(F.group_norm(xa, 8, gam, bet, 1e-6)).numpy()
+    np.savez_compressed(os.path.join(OUT, "g8_tiny_vae.npz"), **g)
+
+
+def idf_warp(x):
+    from .ideal_filters import warped_nonlinearity
+    return warped_nonlinearity(x)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
@@ -192,5 +218,7 @@ if __name__ == "__main__":
         part_a()
     if which in ("b", "all"):
         part_b()
+    if which in ("c", "all"):
+        part_c()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,0 +1,139 @@
+"""AF-VAE on MI355X vs the oracle fixtures: large-plane separable passes,
+dense single-head attention, encode / decode of a same-topology tiny AutoencoderKL, and the
+fractional-shift equivariance of the decoder."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def rel_rms(got, ref):
+    got, ref = got.double().cpu(), torch.as_tensor(ref).double()
+    assert got.shape == ref.shape and torch.isfinite(got).all()
+    return float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+
+
+def nhwc(x, dtype):
+    return x.permute(0, 2, 3, 1).contiguous().to(device="cuda", dtype=dtype)
+
+
+def back(y):
+    return y.float().permute(0, 3, 1, 2).contiguous().cpu()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)])
+def test_large_plane_activation_vs_reference_filters(golden, dtype, tol):
+    """GN + WarpedNonlinearity at N = 64 (three separable MFMA passes) vs the oracle (whose filters
+    are pinned to the imported reference)."""
+    from afldm_amd import ops
+    g = golden("g8_tiny_vae.npz")
+    x = torch.from_numpy(g["act64_x"]).to(dtype).float()
+    ref = torch.from_numpy(g["act64_y"])
+    if dtype == torch.bfloat16:
+        from oracle import ideal_filters as idf
+        ref = idf.warped_nonlinearity(F.group_norm(x, 8, torch.from_numpy(g["act64_gamma"]),
+                                                   torch.from_numpy(g["act64_beta"]), 1e-6))
+    xh = nhwc(x, dtype)
+    st = ops.gn_stats(xh, 8)
+    y = ops.af_act(xh, None, st, torch.from_numpy(g["act64_gamma"]).cuda(), torch.from_numpy(g["act64_beta"]).cuda(),
+                   8, 1e-6)
+    assert rel_rms(back(y), ref) <= tol
+
+
+def test_large_plane_activation_n128_bf16():
+    from afldm_amd import ops
+    from oracle import ideal_filters as idf
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 16, 128, 128, generator=g).to(torch.bfloat16).float()
+    y = ops.af_act(nhwc(x, torch.bfloat16))
+    assert rel_rms(back(y), idf.warped_nonlinearity(x)) <= 1.5e-2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N", [32, 64, 128, 256])
+def test_large_plane_resample(dtype, N):
+    from afldm_amd import ops
+    from oracle import ideal_filters as idf
+    if dtype == torch.float32 and N >= 128:
+        pytest.skip("fp32 128^2 / 256^2 planes exceed LDS (bf16 only, DESIGN.md)")
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(1, 16, N, N, generator=g).to(dtype).float()
+    tol = 2e-5 if dtype == torch.float32 else 8e-3
+    if N <= 128:
+        assert rel_rms(back(ops.af_up2(nhwc(x, dtype))), idf.upsample_rfft(x, 2)) <= tol
+    if N >= 64:
+        assert rel_rms(back(ops.af_lpf_down2(nhwc(x, dtype))), idf.lpf_rfft(x)[:, :, ::2, ::2]) <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, 1.5e-2)])
+def test_dense_attention(dtype, tol):
+    from afldm_amd import ops
+    g = torch.Generator().manual_seed(13)
+    B, T, C = 2, 256, 128
+    q, k, v = (torch.randn(B, T, C, generator=g).to(dtype).float() for _ in range(3))
+    ref = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
+    o = ops.attention_dense(q.to(device="cuda", dtype=dtype), k.to(device="cuda", dtype=dtype),
+                            v.transpose(1, 2).contiguous().to(device="cuda", dtype=dtype), C ** -0.5)
+    assert rel_rms(o, ref) <= tol
+
+
+def build_vae(dtype):
+    from afldm_amd.af_modules.af_api import make_af_vae_from_config
+    from afldm_amd.models.vae import AutoencoderKL
+    from oracle import vae as ov
+    cfg = ov.tiny_vae()
+    sd = ov.init_vae_params(cfg, seed=3)
+    vae = AutoencoderKL(in_channels=3, out_channels=3, down_block_types=["DownEncoderBlock2D"] * 4,
+                        up_block_types=["UpDecoderBlock2D"] * 4, block_out_channels=cfg["block_out_channels"],
+                        layers_per_block=cfg["layers_per_block"], latent_channels=4, norm_num_groups=32,
+                        scaling_factor=cfg["scaling_factor"], mid_act=cfg["mid_act"],
+                        down_filtered_act=cfg["down_filtered_act"], up_filtered_act=cfg["up_filtered_act"],
+                        up_rescale=cfg["up_rescale"])
+    assert set(vae.state_dict()) == set(sd)
+    vae.load_state_dict(sd)
+    make_af_vae_from_config(vae)           # reads the non-constructor config keys (af_api.py:63-67)
+    return vae.to("cuda").to(dtype), cfg, sd
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
+def test_tiny_af_vae_encode_decode(golden, dtype, tol):
+    g = golden("g8_tiny_vae.npz")
+    vae, cfg, _ = build_vae(dtype)
+    post = vae.encode(torch.from_numpy(g["x"]).cuda()).latent_dist
+    assert rel_rms(post.parameters, g["moments"]) <= tol
+    assert torch.equal(post.mode(), post.mean) and post.sample(torch.Generator().manual_seed(0)).shape == (2, 4, 8, 8)
+    img = vae.decode(torch.from_numpy(g["z"]).cuda(), return_dict=False)[0]
+    assert rel_rms(img, g["img"]) <= tol
+    assert vae.config.scaling_factor == 0.6 and len(vae.up_block_types) == 4
+    with pytest.raises(RuntimeError, match="MI355X"):
+        vae.decode(torch.zeros(1, 4, 8, 8))
+
+
+def test_af_vae_class_and_decoder_shift_equivariance():
+    """AliasFreeAutoencoderKL surface + the property the whole design exists for: decoding an
+    ideally shifted latent == bilinear-free ideal shift of the decoded image (up to the boundary)."""
+    from afldm_amd.models.af_vae import AliasFreeAutoencoderKL
+    from afldm_amd.shift_utils.metrics import mask_psnr
+    from afldm_amd.shift_utils.shifters import ImageShifter
+    from oracle import vae as ov
+    cfg = ov.tiny_vae()
+    vae = AliasFreeAutoencoderKL(in_channels=3, out_channels=3, down_block_types=["DownEncoderBlock2D"] * 4,
+                                 up_block_types=["UpDecoderBlock2D"] * 4, block_out_channels=cfg["block_out_channels"],
+                                 layers_per_block=1, latent_channels=4, scaling_factor=0.6,
+                                 down_filtered_act=[False, True, True, True], up_filtered_act=[True, True, True, False])
+    vae.load_state_dict(ov.init_vae_params(cfg, seed=3))
+    vae = vae.cuda()
+    assert vae.downsample_ratio == 8
+    z = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(5)).cuda() * 0.6
+    img = vae.decode_scale(z)
+    assert img.shape == (1, 3, 64, 64)
+    zs, _ = ImageShifter("ideal", 8).shift(z, 0, 1.0)          # integer latent shift (circular)
+    img_s = vae.decode_scale(zs)
+    ref, _ = ImageShifter("ideal", 1).shift(img, 0, 8.0)
+    mask = torch.ones_like(img)
+    mask[..., :16] = 0
+    mask[..., -16:] = 0                                         # zero-padded convs break circularity near borders
+    assert float(mask_psnr(img_s, ref, mask)) > 20.0

@@ -51,7 +51,7 @@ CONV_SHAPES = [
 
 
 def bench_conv(dtype=torch.bfloat16):
-    nvar = 16
+    nvar = 21
     out = {}
     for name, B, H, W, C1, C2, Cout, KS in CONV_SHAPES:
         x1 = torch.randn(B, H, W, C1, device="cuda").to(dtype)
@@ -66,9 +66,6 @@ def bench_conv(dtype=torch.bfloat16):
         ref = None
         for v in list(range(nvar)):
             for sk in ((-1,) if M >= 16384 else (1, 2, 4, 8, 16)):
-                bm = [128, 128, 64, 64, 128, 128, 128, 128, 128, 64, 64, 64, 128, 256, 256, 64][v]
-                if M < 16384 and bm > 128:
-                    pass
                 _lib.check(_lib.lib.afldm_conv2d_tune(v, sk), "tune")
                 try:
                     fn = lambda: ops.conv2d(x1, w, bias, x2=x2, out=y, workspace=ws)
