@@ -137,3 +137,51 @@ def test_af_vae_class_and_decoder_shift_equivariance():
     mask[..., :16] = 0
     mask[..., -16:] = 0                                         # zero-padded convs break circularity near borders
     assert float(mask_psnr(img_s, ref, mask)) > 20.0
+
+
+def test_i2sb_scheduler_step_and_pipeline(golden):
+    """I2SB update kernel vs the oracle, and the SR pipeline end to end on tiny models
+    (VAE-encode -> num_steps-1 UNet evaluations -> decode), SURVEY.md 8 row a17."""
+    from afldm_amd.af_modules.af_api import make_af_unet
+    from afldm_amd.configs import FFHQ_DDIM_CONFIG
+    from afldm_amd.models.unet_2d import UNet2DModel
+    from afldm_amd.pipelines.i2sb_pipeline import I2SBLDMPipeline
+    from afldm_amd.schedulers.i2sb import I2SBScheduler
+    from oracle import configs as oc, i2sb as oi, unet as ou, vae as ov
+    cfg = {k: v for k, v in FFHQ_DDIM_CONFIG.items() if k != "set_alpha_to_one"}
+    s, o = I2SBScheduler.from_config(cfg), oi.I2SB()
+    s.set_timesteps(100)
+    o.set_timesteps(100)
+    g = torch.Generator().manual_seed(21)
+    x, e = torch.randn(2, 4, 8, 8, generator=g), torch.randn(2, 4, 8, 8, generator=g)
+    for t in (991, 501, 11):
+        got = s.step(e.cuda(), t, x.cuda(), is_ode=True).prev_sample.cpu()
+        ref = o.step(e, t, x)
+        assert (got - ref).abs().max() <= 2e-5 * ref.abs().max()
+    # pipeline: tiny AF-VAE (64x64 -> 8x8 latents) + tiny AF-UNet on 8x8... the tiny UNet needs
+    # sample_size 16 latents -> feed 128x128 images
+    vae, vcfg, vsd = build_vae(torch.float32)
+    ucfg = oc.tiny_unet()
+    usd = ou.randomize_norm_affine(ou.init_unet_params(ucfg, seed=0, conv_out_scale=0.1))
+    unet = UNet2DModel.from_config(ucfg)
+    unet.load_state_dict(usd)
+    make_af_unet(unet)
+    unet = unet.cuda()
+    pipe = I2SBLDMPipeline(vae, unet, s)
+    pipe.set_progress_bar_config(disable=True)
+    img = (torch.rand(1, 3, 128, 128, generator=g) * 2 - 1)
+    lat = pipe(img, is_ode=True, num_inference_steps=4, output_type="latent",
+               generator=torch.Generator().manual_seed(3))
+    # oracle: same chain on CPU
+    mom = ov.encode_moments(vsd, vcfg, img)
+    mean, logvar = mom.chunk(2, 1)
+    noise = torch.randn(mean.shape, generator=torch.Generator().manual_seed(3))
+    z = (mean + torch.exp(0.5 * logvar.clamp(-30, 20)) * noise) * vcfg["scaling_factor"]
+    o.set_timesteps(4)
+    for i, t in enumerate(o.timesteps):
+        if i == 3:
+            break
+        z = o.step(ou.unet_forward(usd, ucfg, z, int(t)), t, z)
+    assert rel_rms(lat, z) <= 1e-3
+    out = pipe(img, is_ode=True, num_inference_steps=2, output_type="pt")
+    assert out.shape == (1, 3, 128, 128) and torch.isfinite(out).all()

@@ -196,3 +196,25 @@ def test_afldm_alias_and_diffusers_shim():
         from diffusers.utils.torch_utils import randn_tensor  # noqa
         from afldm_amd.models.unet_2d import UNet2DModel as U2
         assert UNet2DModel is U2
+
+
+def test_i2sb_scheduler_tables_and_known_answers():
+    """sigma_fwd[0] = 0.0387298, sigma_fwd[999] = sigma_bwd[0] = 2.9672334."""
+    from afldm_amd.configs import FFHQ_DDIM_CONFIG
+    from afldm_amd.schedulers.i2sb import I2SBScheduler
+    from oracle.i2sb import I2SB
+    cfg = {k: v for k, v in FFHQ_DDIM_CONFIG.items() if k not in ("set_alpha_to_one",)}
+    s, o = I2SBScheduler.from_config(cfg), I2SB()
+    assert abs(float(s.std_fwd[0]) - 0.0387298) < 1e-6 and abs(float(s.std_fwd[999]) - 2.9672334) < 2e-6
+    assert abs(float(s.std_bwd[0]) - 2.9672334) < 2e-6
+    assert torch.equal(s.std_fwd, o.std_fwd) and torch.equal(s.mu_x0, o.mu_x0) and torch.equal(s.std_sb, o.std_sb)
+    s.set_timesteps(100)
+    o.set_timesteps(100)
+    assert torch.equal(s.timesteps, o.timesteps) and s.previous_timestep(991) == 981
+    x0, x1 = torch.randn(3, 4, 8, 8), torch.randn(3, 4, 8, 8)
+    ts = torch.tensor([5, 500, 999])
+    xt = s.add_noise(x0, x1, ts, is_ode=True)
+    assert torch.equal(xt, o.add_noise(x0, x1, ts, is_ode=True))
+    assert torch.allclose(s.compute_label(ts, x0, xt), o.compute_label(ts, x0, xt))
+    with pytest.raises(RuntimeError, match="MI355X"):
+        s.step(x0, 991, x1)
