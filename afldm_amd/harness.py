@@ -1,0 +1,97 @@
+"""Fractional-shift equivariance harness — the procedure of reference
+scripts/shift_ldm_ffhq.py::shift_ldm (:49-159) on the MI355X implementation:
+
+  1. install a CrossFrameAttnProcessor on every attention of the UNet;
+  2. STORE pass: denoise the initial latent, remembering every attention's input per timestep;
+  3. decode the result (the un-shifted image);
+  4. for each offset tj = 1/r .. n/r latent pixels: ideal-crop shift the INITIAL latent, denoise
+     it in LOAD mode (K/V from the stored maps), decode (masked), and stack
+     [shifted output | bilinear-shifted un-shifted image | abs difference] vertically;
+  5. restore the processors, write the frames as a GIF.
+
+Multi-GPU: the shift offsets are independent given the STORE pass, so ranks take interleaved
+offsets (each recomputes the cheap STORE pass locally) and the frames are gathered once.
+Returns the frames and, per offset, the masked latent-space equivariance MSE."""
+import torch
+
+from . import parallel
+from .io_utils import image_to_tensor, save_gif_from_tensors
+from .pipelines.cross_frame_attn import (AttnState, CrossFrameAttnProcessor, get_unet_attn_processors,
+                                         set_unet_attn_processor)
+from .shift_utils.metrics import mask_mse
+from .shift_utils.shifters import ImageShifter
+from .utils import randn_tensor
+
+
+def vae_encode(vae, x):
+    return vae.encode(x).latent_dist.sample() * vae.config.scaling_factor
+
+
+def vae_decode(vae, x):
+    return vae.decode(x / vae.config.scaling_factor, return_dict=False)[0]
+
+
+@torch.no_grad()
+def shift_ldm(pipeline, num_inference_steps=50, num_shift_steps=16, output_path="results/shift_ldm.gif",
+              input_path=None, generator=None, rank=0, world=1):
+    device = pipeline.device
+    vae, unet, scheduler = pipeline.vae, pipeline.unet, pipeline.scheduler
+    pipeline.set_progress_bar_config(disable=True)
+    ratio = 2 ** (len(vae.up_block_types) - 1) if vae is not None else 8
+    latent_shifter = ImageShifter("ideal_crop", ratio)
+    image_shifter = ImageShifter()
+
+    attn_state = AttnState()
+    previous = get_unet_attn_processors(unet)
+    set_unet_attn_processor(unet, {k: CrossFrameAttnProcessor(attn_state) for k in previous})
+
+    def denoise(latents):
+        latents = latents.to(device)
+        scheduler.set_timesteps(num_inference_steps, device=device)
+        for t in scheduler.timesteps:
+            attn_state.set_timestep(t)
+            eps = unet(scheduler.scale_model_input(latents, t), t, return_dict=False)[0]
+            latents = scheduler.step(eps, t, latents, eta=0, return_dict=False)[0]
+        return latents
+
+    try:
+        if input_path is not None:
+            size = unet.config.sample_size * ratio
+            tensor = vae_encode(vae, image_to_tensor(input_path, (size, size)).to(device))
+            scheduler.set_timesteps(num_inference_steps, device=device)
+            init_latent = pipeline.ddim_inversion(tensor, bar=False)
+        else:
+            # CPU-side draw (seedable, device independent) — the reference draws on the GPU
+            # (shift_ldm_ffhq.py:118-122), which is not reproducible across devices
+            init_latent = randn_tensor((1, unet.config.in_channels, unet.config.sample_size, unet.config.sample_size),
+                                       generator=generator).to(device)
+        attn_state.reset()
+        denoised = denoise(init_latent)
+        attn_state.to_load()
+        rec_img = vae_decode(vae, denoised) if vae is not None else None
+
+        offsets = torch.linspace(1 / ratio, num_shift_steps / ratio, num_shift_steps)
+        mine = list(range(rank, num_shift_steps, world))
+        frames, errors = {}, {}
+        for i in mine:
+            tj = float(offsets[i])
+            shifted, mask = latent_shifter.shift(init_latent, 0, tj)
+            den = denoise(shifted)
+            ref_lat, _ = latent_shifter.shift(denoised, 0, tj)
+            errors[i] = float(mask_mse(den, ref_lat, mask))
+            if vae is not None:
+                gt, _ = image_shifter.shift(rec_img, 0, tj * ratio)
+                img = vae_decode(vae, den * mask)
+                frames[i] = torch.cat((img, gt, torch.abs(img - gt)), -2).float().cpu()
+    finally:
+        set_unet_attn_processor(unet, dict(previous))
+
+    if world > 1:
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, (frames, errors))
+        frames = {k: v for f, _ in gathered for k, v in f.items()}
+        errors = {k: v for _, e in gathered for k, v in e.items()}
+    ordered = [frames[i] for i in sorted(frames)]
+    if ordered and rank == 0 and output_path:
+        save_gif_from_tensors(ordered, output_path, denorm=True)
+    return ordered, [errors[i] for i in sorted(errors)]

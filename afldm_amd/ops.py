@@ -224,6 +224,12 @@ def af_act(x1, x2=None, stats=None, gamma=None, beta=None, G=0, eps=0.0, out=Non
     if N > 32:
         if x2 is not None:
             raise RuntimeError("afldm_amd: the large-plane activation path (N > 32) does not take a virtual concat")
+        if x1.dtype == torch.float32 and N > 64:
+            # fp32 128^2 planes: the matrices do not fit LDS -> generic (VALU) separable products:
+            # GN-apply, U x U^T, SiLU, D z D^T as four elementary launches (exact-parity mode only)
+            xn = x1 if stats is None else gn_apply(x1, stats, gamma, beta, G, eps, act=0)
+            U, D = filter_matrices(N, x1.device)
+            return af_resample(silu(af_resample(xn, U)), D, out=out)
         return _af_act_large(x1, stats, gamma, beta, G, eps, out)
     U, D = filter_matrices(N, x1.device)
     packed = packed_filters(N, x1.dtype, x1.device)
@@ -242,7 +248,7 @@ def af_up2(x, out=None, workspace=None):
     U = up_matrix(N, 2, x.device)
     if out is None:
         out = torch.empty((B, 2 * N, 2 * N, C), dtype=x.dtype, device=x.device)
-    if N >= 32 and C % 16 == 0:
+    if N >= 32 and C % 16 == 0 and (x.dtype == torch.bfloat16 or N <= 64):
         return _resample_large(x, U, 2 * N, out)
     if workspace is None:
         workspace = torch.empty(B * 2 * N * N * C, dtype=torch.float32, device=x.device)
@@ -260,7 +266,7 @@ def af_lpf_down2(x, out=None, workspace=None):
     D = down_matrix(N, x.device)
     if out is None:
         out = torch.empty((B, N // 2, N // 2, C), dtype=x.dtype, device=x.device)
-    if N >= 64 and C % 16 == 0:
+    if N >= 64 and C % 16 == 0 and (x.dtype == torch.bfloat16 or N <= 128):
         return _resample_large(x, D, N // 2, out)
     if workspace is None:
         workspace = torch.empty(B * (N // 2) * N * C, dtype=torch.float32, device=x.device)

@@ -185,3 +185,28 @@ def test_i2sb_scheduler_step_and_pipeline(golden):
     assert rel_rms(lat, z) <= 1e-3
     out = pipe(img, is_ode=True, num_inference_steps=2, output_type="pt")
     assert out.shape == (1, 3, 128, 128) and torch.isfinite(out).all()
+
+
+def test_shift_harness_end_to_end(tmp_path):
+    """afldm_amd.harness.shift_ldm (the procedure of scripts/shift_ldm_ffhq.py) on tiny models:
+    processors installed + restored, frames stacked [out | gt | diff], GIF written."""
+    from afldm_amd.af_modules.af_api import make_af_unet
+    from afldm_amd.harness import shift_ldm
+    from afldm_amd.models.unet_2d import UNet2DModel
+    from afldm_amd.pipelines.cross_frame_attn import get_unet_attn_processors
+    from afldm_amd.pipelines.ldm_pipeline import MyLDMPipeline
+    from afldm_amd.schedulers.ddim import ffhq_ddim_scheduler
+    from oracle import configs as oc, unet as ou
+    vae, _, _ = build_vae(torch.float32)
+    ucfg = oc.tiny_unet()
+    unet = UNet2DModel.from_config(ucfg)
+    unet.load_state_dict(ou.randomize_norm_affine(ou.init_unet_params(ucfg, seed=0, conv_out_scale=0.1)))
+    make_af_unet(unet)
+    pipe = MyLDMPipeline(vae, unet.cuda(), ffhq_ddim_scheduler())
+    before = {k: type(v) for k, v in get_unet_attn_processors(pipe.unet).items()}
+    out = tmp_path / "shift.gif"
+    frames, errs = shift_ldm(pipe, num_inference_steps=3, num_shift_steps=2, output_path=str(out),
+                             generator=torch.Generator().manual_seed(1))
+    assert len(frames) == 2 and frames[0].shape == (1, 3, 3 * 128, 128) and out.exists() and out.stat().st_size > 0
+    assert all(np.isfinite(e) and e >= 0 for e in errs)
+    assert {k: type(v) for k, v in get_unet_attn_processors(pipe.unet).items()} == before
