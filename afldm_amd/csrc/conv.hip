@@ -40,6 +40,8 @@ struct ConvP {
   int splitk;   // grid.z
   int tiles_n;
   int vec_ok;   // leading dims allow 4-element vector epilogue accesses
+  int tap_inner;  // K order of the LDS-DMA kernel (see k_igemm2)
+  int dbg;      // AFLDM_CONV_DBG (timing decomposition only): bit 0 skip the LDS-DMA, bit 1 skip the MFMA phase
 };
 
 __device__ __forceinline__ int swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
@@ -268,11 +270,25 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int KCH, int STAGES>
-__global__ void __launch_bounds__(WGM* WGN * 64) k_igemm2(ConvP p) {
+// NPROD = 0: every wave both issues its share of the LDS-DMA and computes (v2).
+// NPROD > 0: wave specialisation (v3) — the first WGM*WGN waves are CONSUMERS (LDS fragment reads +
+// MFMA only), the last NPROD waves are PRODUCERS (LDS-DMA issue + counted vmcnt only).  An LDS-DMA
+// wave-instruction costs ~60-185 issue cycles (MI355X_MICROARCH.md); at 10 of them per wave per
+// K step that is as long as the 48 MFMAs, and an in-order wave cannot overlap the two.  Split
+// across waves that share a SIMD, the DMA issue runs under the other wave's MFMAs.
+// R128 (KCH = 2 only): an LDS row holds the whole 128-byte K step of one pixel / cout row, so every
+// LDS-DMA wave-instruction fetches 8 full 128-byte lines (8 lanes x 16 B per row) instead of 16
+// half lines.  Measured with AFLDM_CONV_DBG (profiles/r01/conv_dma_mfma_decomposition.log): with
+// 64-byte pieces the DMA stream ALONE took 93 % of the kernel time at ~13 TB/s of requested bytes
+// (each line requested twice, by the kc = 0 and kc = 1 instructions).  Row r keeps source chunk c
+// at position c ^ ((r >> 1) & 7): conflict-free for the 16-lane groups of ds_read_b128.
+template <typename T, int BM, int BN, int WGM, int WGN, int KCH, int STAGES, int NPROD = 0, bool R128 = false>
+__global__ void __launch_bounds__((WGM * WGN + NPROD) * 64) k_igemm2(ConvP p) {
   typedef Mma<T> MM;
   typedef typename MM::Chunk Chunk;
-  constexpr int NW = WGM * WGN;
+  static_assert(!R128 || KCH == 2, "128-byte rows hold exactly two MFMA K chunks");
+  constexpr int NWC = WGM * WGN;                    // consumer (compute) waves
+  constexpr int NW = NPROD > 0 ? NPROD : NWC;       // waves that issue the LDS-DMA
   constexpr int EPC = MM::EPC, EPR = 4 * EPC, KSTEP = KCH * EPR;
   constexpr int ESZ = (int)sizeof(T);
   constexpr int WMS = BM / WGM, WNS = BN / WGN, TM = WMS / 16, TN = WNS / 16;
@@ -287,8 +303,12 @@ __global__ void __launch_bounds__(WGM* WGN * 64) k_igemm2(ConvP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WGN, wn = wave % WGN;
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_producer = NPROD > 0 ? wave_all >= NWC : true;
+  const bool is_consumer = NPROD > 0 ? wave_all < NWC : true;
+  const int wave = NPROD > 0 ? (is_producer ? wave_all - NWC : 0) : wave_all;   // index among the issuing waves
+  const int cw = NPROD > 0 ? (is_consumer ? wave_all : 0) : wave_all;           // index among the compute waves
+  const int wm = cw / WGN, wn = cw % WGN;
   const int li = lane & 15, lg = lane >> 4;
 
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -312,17 +332,19 @@ __global__ void __launch_bounds__(WGM* WGN * 64) k_igemm2(ConvP p) {
   // per-lane source coordinates.  Instruction j (0..XI-1) of a stage covers plane kc = j / XG, row
   // group g = j % XG; this wave issues j = wave + NW * i.  Lane l: row 16 g + (l >> 2), source
   // chunk (l & 3) ^ swz(row)  [swz(row) depends only on (l >> 4)].
-  const int lrow = lane >> 2;
+  // R128: instruction j covers rows 8 j .. 8 j + 7; lane l: row 8 j + (l >> 3), position l & 7 holds
+  // source chunk (l & 7) ^ ((row >> 1) & 7) = (l & 7) ^ ((4 j + (l >> 4)) & 7).
+  const int lrow = R128 ? lane >> 3 : lane >> 2;
   const int lchunk = (lane & 3) ^ ((4 - (lane >> 4)) & 3);
-  int xoh[XPW], xow[XPW], xkc[XPW];
+  int xoh[XPW], xow[XPW], xcin[XPW];   // xcin: element offset of this lane's chunk inside the K step
   unsigned xbase[XPW];  // byte offset of pixel (b, oh, ow) channel 0 in a tensor with C channels = 1 (scaled later)
   bool xok[XPW];
 #pragma unroll
   for (int i = 0; i < XPW; ++i) {
     const int j = wave + NW * i;
     const int g = j % XG;
-    xkc[i] = j / XG;
-    const int m = m0 + 16 * g + lrow;
+    xcin[i] = R128 ? (((lane & 7) ^ ((4 * j + (lane >> 4)) & 7)) * EPC) : ((j / XG) * EPR + lchunk * EPC);
+    const int m = R128 ? m0 + 8 * j + lrow : m0 + 16 * g + lrow;
     xok[i] = m < p.M;
     const int mm = xok[i] ? m : 0;
     const int b = mm / HW, pix = mm - b * HW;
@@ -331,29 +353,39 @@ __global__ void __launch_bounds__(WGM* WGN * 64) k_igemm2(ConvP p) {
     xbase[i] = (unsigned)mm;  // pixel index; multiplied by the channel count of the source tensor at issue time
   }
   unsigned wrow[WPW];
-  int wkc[WPW];
+  int wcin[WPW];
   bool wok[WPW];
 #pragma unroll
   for (int i = 0; i < WPW; ++i) {
     const int j = wave + NW * i;
     const int g = j % WG_;
-    wkc[i] = j / WG_;
-    const int n = n0 + 16 * g + lrow;
+    wcin[i] = R128 ? (((lane & 7) ^ ((4 * j + (lane >> 4)) & 7)) * EPC) : ((j / WG_) * EPR + lchunk * EPC);
+    const int n = R128 ? n0 + 8 * j + lrow : n0 + 16 * g + lrow;
     wok[i] = n < p.Cout;
     wrow[i] = (unsigned)(wok[i] ? n : 0) * (unsigned)(p.KS * p.KS);
   }
 
   // K cursor of the NEXT step to issue (wave-uniform scalars, advanced incrementally: no division
-  // in the loop).  Per-lane voffsets are recomputed only when the filter tap changes; inside a tap
-  // the channel block advances through the SGPR soffset of the buffer load, so a K step costs no
-  // VALU address arithmetic (weights: never; pixels: once per tap).
-  int is_kt = kbeg, is_tap = kbeg / cblocks, is_ci0 = (kbeg - is_tap * cblocks) * KSTEP;
+  // in the loop).  Two K orders (p.tap_inner):
+  //   0: tap outer, channel block inner.  Per-lane voffsets are recomputed only when the filter tap
+  //      changes; inside a tap the channel block advances through the SGPR soffset of the buffer
+  //      load, so a K step costs no VALU address arithmetic.
+  //   1: channel block outer, tap inner: the KS*KS taps of one 128-byte channel block re-read the
+  //      same pixels shifted by a row / column (L1 / L2 hits; the DMA-only time of the 32x32 level
+  //      drops 126 -> 81-98 us) at the price of a retap per K step.  Measured a wash at 32x32 and a
+  //      loss at 16x16 / 8x8 where the tile's pixels are L2-resident anyway
+  //      (profiles/r01/conv_dma_mfma_decomposition.log), so the planner keeps order 0.
+  const int taps = p.KS * p.KS;
+  const bool tap_inner = p.tap_inner && taps > 1;
+  int is_kt = kbeg;
+  int is_tap = tap_inner ? kbeg % taps : kbeg / cblocks;
+  int is_ci0 = tap_inner ? (kbeg / taps) * KSTEP : (kbeg - is_tap * cblocks) * KSTEP;
   int is_kh = is_tap / p.KS, is_kw = is_tap - is_kh * p.KS;
   unsigned xoff1[XPW], xoff2[XPW];   // byte voffset of (pixel + tap shift, channel kc*EPR + chunk) in x1 / x2, or OOB
   unsigned woff[WPW];                 // byte voffset of (cout row, tap 0, channel kc*EPR + chunk), or OOB
 #pragma unroll
   for (int i = 0; i < WPW; ++i)
-    woff[i] = wok[i] ? (wrow[i] * (unsigned)Ct + (unsigned)(wkc[i] * EPR + lchunk * EPC)) * ESZ : OOB;
+    woff[i] = wok[i] ? (wrow[i] * (unsigned)Ct + (unsigned)wcin[i]) * ESZ : OOB;
   auto retap = [&]() {
     const int dh = is_kh - pad, dw = is_kw - pad;
     const int dpix = dh * p.W + dw;
@@ -362,7 +394,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) k_igemm2(ConvP p) {
       const int ih = xoh[i] + dh, iw = xow[i] + dw;
       const bool ok = xok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
       const unsigned pixel = (unsigned)((int)xbase[i] + dpix);
-      const unsigned cin = (unsigned)(xkc[i] * EPR + lchunk * EPC);
+      const unsigned cin = (unsigned)xcin[i];
       xoff1[i] = ok ? (pixel * (unsigned)p.C1 + cin) * ESZ : OOB;
       xoff2[i] = ok ? (pixel * (unsigned)p.C2 + cin) * ESZ : OOB;
     }
@@ -392,13 +424,27 @@ __global__ void __launch_bounds__(WGM* WGN * 64) k_igemm2(ConvP p) {
     }
     // advance the cursor
     ++is_kt;
-    is_ci0 += KSTEP;
-    if (is_ci0 >= Ct) {
-      is_ci0 = 0;
+    if (!tap_inner) {
+      is_ci0 += KSTEP;
+      if (is_ci0 >= Ct) {
+        is_ci0 = 0;
+        ++is_tap;
+        if (++is_kw == p.KS) {
+          is_kw = 0;
+          ++is_kh;
+        }
+        if (is_kt < kend) retap();
+      }
+    } else {
       ++is_tap;
       if (++is_kw == p.KS) {
         is_kw = 0;
         ++is_kh;
+      }
+      if (is_tap == taps) {
+        is_tap = 0;
+        is_kh = 0;
+        is_ci0 += KSTEP;
       }
       if (is_kt < kend) retap();
     }
@@ -410,19 +456,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) k_igemm2(ConvP p) {
 #pragma unroll
     for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // prologue: STAGES-1 K steps in flight (slots past kend are filled with zeros: uniform counts)
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s) issue(s);
-
-  int slot = 0;
-  for (int kt = kbeg; kt < kend; ++kt) {
-    // the oldest group in flight is K step kt: wait for it, leave the younger STAGES-2 in flight
-    wait_vmcnt<(STAGES - 2) * LPS>();
-    __builtin_amdgcn_s_barrier();
-    // every wave has finished reading the slot of step kt-1 -> refill it with step kt+STAGES-1
-    int nslot = slot + STAGES - 1;
-    if (nslot >= STAGES) nslot -= STAGES;
-    issue(nslot);
+  auto compute = [&](int slot) {
     const char* sX = smem + slot * STAGE;
     const char* sW = sX + X_STAGE;
 #pragma unroll
@@ -431,21 +465,66 @@ __global__ void __launch_bounds__(WGM* WGN * 64) k_igemm2(ConvP p) {
 #pragma unroll
       for (int t = 0; t < TN; ++t) {
         const int row = wn * WNS + t * 16 + li;
-        a[t] = ld16<Chunk>(sW + (kc * BN + row) * 64 + ((lg ^ swz(row)) << 4));
+        a[t] = R128 ? ld16<Chunk>(sW + row * 128 + (((kc * 4 + lg) ^ ((row >> 1) & 7)) << 4))
+                    : ld16<Chunk>(sW + (kc * BN + row) * 64 + ((lg ^ swz(row)) << 4));
       }
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
         const int row = wm * WMS + t * 16 + li;
-        b[t] = ld16<Chunk>(sX + (kc * BM + row) * 64 + ((lg ^ swz(row)) << 4));
+        b[t] = R128 ? ld16<Chunk>(sX + row * 128 + (((kc * 4 + lg) ^ ((row >> 1) & 7)) << 4))
+                    : ld16<Chunk>(sX + (kc * BM + row) * 64 + ((lg ^ swz(row)) << 4));
       }
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) MM::mma(acc[tn][tm], a[tn], b[tm]);
     }
-    slot = slot + 1 == STAGES ? 0 : slot + 1;
+  };
+
+  // Protocol per K step kt (all waves meet at ONE s_barrier):
+  //   issuing waves: wait until their LDS-DMA of step kt has landed (counted vmcnt, younger stages
+  //                  stay in flight) -> barrier -> refill the slot of step kt-1 with step kt+STAGES-1
+  //   compute waves: barrier -> fragments + MFMA of step kt
+  // With NPROD > 0 the two roles run separate loops (disjoint register live ranges) that meet at
+  // the same barrier count; with NPROD == 0 every wave does both.
+  if (NPROD > 0) {
+    if (is_producer) {
+#pragma unroll
+      for (int s = 0; s < STAGES - 1; ++s) issue(s);
+      int slot = 0;
+      for (int kt = kbeg; kt < kend; ++kt) {
+        wait_vmcnt<(STAGES - 2) * LPS>();
+        __builtin_amdgcn_s_barrier();
+        int nslot = slot + STAGES - 1;
+        if (nslot >= STAGES) nslot -= STAGES;
+        if (!(p.dbg & 1)) issue(nslot);
+        slot = slot + 1 == STAGES ? 0 : slot + 1;
+      }
+      wait_vmcnt<0>();  // drain the zero-fill tail before the workgroup's LDS can be re-assigned
+      return;
+    }
+    int slot = 0;
+    for (int kt = kbeg; kt < kend; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      if (!(p.dbg & 2)) compute(slot);
+      slot = slot + 1 == STAGES ? 0 : slot + 1;
+    }
+  } else {
+    // prologue: STAGES-1 K steps in flight (slots past kend are filled with zeros: uniform counts)
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) issue(s);
+    int slot = 0;
+    for (int kt = kbeg; kt < kend; ++kt) {
+      wait_vmcnt<(STAGES - 2) * LPS>();
+      __builtin_amdgcn_s_barrier();
+      int nslot = slot + STAGES - 1;
+      if (nslot >= STAGES) nslot -= STAGES;
+      if (!(p.dbg & 1)) issue(nslot);
+      if (!(p.dbg & 2)) compute(slot);
+      slot = slot + 1 == STAGES ? 0 : slot + 1;
+    }
+    wait_vmcnt<0>();  // drain the zero-fill tail before the workgroup's LDS can be re-assigned
   }
-  wait_vmcnt<0>();  // drain the zero-fill tail before the workgroup's LDS can be re-assigned
 
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
@@ -623,89 +702,6 @@ struct Plan {
 
 constexpr int KCH_DEFAULT = 2;
 
-template <typename T>
-static int epr() { return 4 * Mma<T>::EPC; }
-
-static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
-  Plan pl{0, 0, 1};
-  const int Ct = a->C1 + a->C2;
-  const int kstep = KCH_DEFAULT * elems_per_row;
-  const bool gemm_ok = (Ct % kstep == 0) && (a->C2 == 0 || a->C1 % kstep == 0);
-  if (!gemm_ok) {
-    pl.kind = (a->Cout <= 8) ? 2 : 1;
-    return pl;
-  }
-  const long long M = (long long)a->B * a->H * a->W;
-  // Variant choice from the MI355X sweep (tools/bench_kernels.py conv, profiles/r01/conv_sweep*.log):
-  //   M >= 32768 and Cout % 192 == 0 : 128x192 LDS-DMA tile (840-1050 TF on the 32x32 level)
-  //   M >= 4096                      : 128x128 (Cout % 128 == 0) else 128x64, LDS-DMA, 2 stages
-  //   1024 <= M < 4096               : 128x64 LDS-DMA
-  //   M < 1024                       : 64x64 LDS-DMA, 4 stages (short K loops are latency bound)
-  // and split-K so that tiles * splitk ~ 2-3 workgroups per CU.
-  int vid, bm, bn;
-  const int ksteps_all = a->KS * a->KS * (Ct / kstep);
-  const long long tiles64 = ((M + 63) / 64) * ((a->Cout + 63) / 64);
-  if (M <= 4096 && ksteps_all <= 64 && tiles64 >= 256) { vid = 11; bm = 64; bn = 64; }  // short-K GEMMs: many small tiles, no split-K
-  else if (M >= 32768 && a->Cout % 192 == 0) { vid = 12; bm = 128; bn = 192; }
-  else if (M >= 4096 && a->Cout % 128 == 0) { vid = 4; bm = 128; bn = 128; }
-  else if (M >= 1024) { vid = 6; bm = 128; bn = 64; }
-  else { vid = 11; bm = 64; bn = 64; }
-  if (g_force_variant >= 0 && g_force_variant < 21) {
-    static const int fbm[21] = {128, 128, 64, 64, 128, 128, 128, 128, 128, 64, 64, 64, 128, 256, 256, 64, 128, 128, 128, 128, 128};
-    static const int fbn[21] = {128, 64, 128, 64, 128, 128, 64, 64, 64, 128, 128, 64, 192, 64, 64, 64, 192, 128, 192, 192, 128};
-    vid = g_force_variant; bm = fbm[vid]; bn = fbn[vid];
-  }
-  pl.cfg = vid;
-  const long long tiles = ((M + bm - 1) / bm) * ((a->Cout + bn - 1) / bn);
-  const int ksteps = a->KS * a->KS * (Ct / kstep);
-  int sk = 1;
-  if (tiles < 256) {   // measured: ~320 workgroups and at most 4 K slices is the sweet spot (conv_variant_sweep2.log)
-    sk = (int)((320 + tiles - 1) / tiles);
-    int maxsk = ksteps / 4;
-    if (maxsk < 1) maxsk = 1;
-    if (sk > maxsk) sk = maxsk;
-    if (sk > 4) sk = 4;
-    if (sk < 1) sk = 1;
-  }
-  pl.splitk = sk;
-  if (g_force_splitk >= 1) pl.splitk = g_force_splitk;
-  return pl;
-}
-
-template <typename T, int BM, int BN, int WGM, int WGN>
-static void launch_igemm(const ConvP& p0, hipStream_t st) {
-  ConvP p = p0;
-  constexpr int KCH = KCH_DEFAULT;
-  p.tiles_n = (p.Cout + BN - 1) / BN;
-  const int tiles_m = (p.M + BM - 1) / BM;
-  dim3 grid(tiles_m * p.tiles_n, 1, p.splitk);
-  constexpr int lds = 2 * KCH * (BM + BN) * 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_igemm<T, BM, BN, WGM, WGN, KCH>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
-  k_igemm<T, BM, BN, WGM, WGN, KCH><<<grid, WGM * WGN * 64, lds, st>>>(p);
-}
-
-template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int KCH = KCH_DEFAULT>
-static void launch_igemm2(const ConvP& p0, hipStream_t st) {
-  ConvP p = p0;
-  p.ksteps = p0.ksteps * KCH_DEFAULT / KCH;     // p0.ksteps counts KCH_DEFAULT-wide steps
-  p.tiles_n = (p.Cout + BN - 1) / BN;
-  const int tiles_m = (p.M + BM - 1) / BM;
-  dim3 grid(tiles_m * p.tiles_n, 1, p.splitk);
-  constexpr int lds = STAGES * KCH * (BM + BN) * 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_igemm2<T, BM, BN, WGM, WGN, KCH, STAGES>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
-  k_igemm2<T, BM, BN, WGM, WGN, KCH, STAGES><<<grid, WGM * WGN * 64, lds, st>>>(p);
-}
-
 struct Variant {
   int bm, bn, ver, stages;
 };
@@ -732,8 +728,118 @@ static const Variant kVariants[] = {
     {128, 192, 2, 3},  // 18  (KCH = 1)
     {128, 192, 2, 2},  // 19  (KCH = 1: 40 KB LDS -> 4 workgroups per CU)
     {128, 128, 2, 2},  // 20  (KCH = 1: 32 KB LDS)
+    {128, 192, 3, 2},  // 21  wave-specialised: 4 consumer + 4 producer waves
+    {128, 192, 3, 3},  // 22
+    {128, 128, 3, 2},  // 23
+    {128, 128, 3, 3},  // 24
+    {128, 192, 3, 2},  // 25  4 consumers + 2 producers
+    {256, 192, 3, 2},  // 26  8 consumers (4x2) + 4 producers, 112 KB LDS
+    {256, 128, 3, 2},  // 27  8 consumers (4x2) + 4 producers, 96 KB LDS
+    {128, 64, 3, 3},   // 28  4 consumers + 2 producers
+    {128, 192, 4, 2},  // 29  ver 4 = 128-byte LDS rows (full-line LDS-DMA)
+    {128, 128, 4, 2},  // 30
+    {128, 64, 4, 2},   // 31
+    {64, 64, 4, 4},    // 32
+    {128, 192, 4, 3},  // 33  + 4 producer waves
+    {128, 128, 4, 2},  // 34  + 4 producer waves
+    {128, 128, 4, 3},  // 35
+    {256, 64, 4, 2},   // 36
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
+
+template <typename T>
+static int epr() { return 4 * Mma<T>::EPC; }
+
+static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
+  Plan pl{0, 0, 1};
+  const int Ct = a->C1 + a->C2;
+  const int kstep = KCH_DEFAULT * elems_per_row;
+  const bool gemm_ok = (Ct % kstep == 0) && (a->C2 == 0 || a->C1 % kstep == 0);
+  if (!gemm_ok) {
+    pl.kind = (a->Cout <= 8) ? 2 : 1;
+    return pl;
+  }
+  const long long M = (long long)a->B * a->H * a->W;
+  // Variant choice from the MI355X sweeps (tools/bench_kernels.py conv; profiles/r01/conv_variant_sweep*.log).
+  // All picks use 128-byte LDS rows (full-line LDS-DMA, variants 29-33):
+  //   short K (<= 16 steps) or M <= 4096 with <= 64 steps : 64x64, 4 stages, no split-K
+  //   M >= 32768, Cout % 192 == 0                          : 128x192, 2 workgroups per CU      (~1000-1080 TF)
+  //   1024 <= M < 32768, Cout % 192 == 0, >= 27 K steps    : 128x192 + 4 producer waves, 3 stages, 1 workgroup
+  //                                                          per CU (256 tiles = one full wave at 16x16; +15-25 %)
+  //   M >= 4096, Cout % 128 == 0                           : 128x128
+  //   M >= 1024                                            : 128x64
+  // and split-K so that tiles * splitk ~ one resident set of workgroups.
+  int vid, bm, bn;
+  const int ksteps_all = a->KS * a->KS * (Ct / kstep);
+  const long long tiles64 = ((M + 63) / 64) * ((a->Cout + 63) / 64);
+  if (M <= 4096 && ((ksteps_all <= 64 && tiles64 >= 256) || (ksteps_all <= 16 && tiles64 >= 128))) { vid = 32; bm = 64; bn = 64; }
+  else if (M >= 32768 && a->Cout % 192 == 0) { vid = 29; bm = 128; bn = 192; }
+  else if (M >= 4096 && a->Cout % 192 == 0 && ksteps_all >= 27) { vid = 33; bm = 128; bn = 192; }
+  else if (M >= 4096 && a->Cout % 128 == 0 && a->KS > 1) { vid = 30; bm = 128; bn = 128; }
+  else if (M >= 1024) { vid = 31; bm = 128; bn = 64; }
+  else { vid = 32; bm = 64; bn = 64; }
+  if (g_force_variant >= 0 && g_force_variant < kNumVariants) {
+    vid = g_force_variant; bm = kVariants[vid].bm; bn = kVariants[vid].bn;
+  }
+  pl.cfg = vid;
+  const long long tiles = ((M + bm - 1) / bm) * ((a->Cout + bn - 1) / bn);
+  const int ksteps = a->KS * a->KS * (Ct / kstep);
+  int sk = 1;
+  if (kVariants[vid].ver == 4 && kVariants[vid].stages == 3 && bn == 192) {
+    // one 8-wave workgroup per CU: aim at 256 workgroups (measured best: 64 tiles -> 4, 128 tiles -> 2)
+    sk = (int)((256 + tiles / 2) / tiles);
+    int maxsk = ksteps / 8;
+    if (sk > maxsk) sk = maxsk;
+    if (sk > 4) sk = 4;
+    if (sk < 1) sk = 1;
+  } else if (tiles < 256) {   // measured: ~320 workgroups is the sweet spot (conv_variant_sweep2/4.log)
+    sk = (int)((320 + tiles - 1) / tiles);
+    int maxsk = ksteps / 4;
+    if (maxsk < 1) maxsk = 1;
+    if (sk > maxsk) sk = maxsk;
+    const int cap = ksteps >= 192 ? 8 : 4;      // very long K (L4 concat convs): 8 slices measured +12 %
+    if (sk > cap) sk = cap;
+    if (sk < 1) sk = 1;
+  }
+  pl.splitk = sk;
+  if (g_force_splitk >= 1) pl.splitk = g_force_splitk;
+  return pl;
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN>
+static void launch_igemm(const ConvP& p0, hipStream_t st) {
+  ConvP p = p0;
+  constexpr int KCH = KCH_DEFAULT;
+  p.tiles_n = (p.Cout + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  dim3 grid(tiles_m * p.tiles_n, 1, p.splitk);
+  constexpr int lds = 2 * KCH * (BM + BN) * 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_igemm<T, BM, BN, WGM, WGN, KCH>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  k_igemm<T, BM, BN, WGM, WGN, KCH><<<grid, WGM * WGN * 64, lds, st>>>(p);
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int KCH = KCH_DEFAULT, int NPROD = 0, bool R128 = false>
+static void launch_igemm2(const ConvP& p0, hipStream_t st) {
+  ConvP p = p0;
+  p.ksteps = p0.ksteps * KCH_DEFAULT / KCH;     // p0.ksteps counts KCH_DEFAULT-wide steps
+  p.tiles_n = (p.Cout + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  dim3 grid(tiles_m * p.tiles_n, 1, p.splitk);
+  constexpr int lds = STAGES * KCH * (BM + BN) * 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_igemm2<T, BM, BN, WGM, WGN, KCH, STAGES, NPROD, R128>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  k_igemm2<T, BM, BN, WGM, WGN, KCH, STAGES, NPROD, R128><<<grid, (WGM * WGN + NPROD) * 64, lds, st>>>(p);
+}
+
 
 template <typename T>
 static bool launch_variant(int id, const ConvP& p, hipStream_t st) {
@@ -759,6 +865,22 @@ static bool launch_variant(int id, const ConvP& p, hipStream_t st) {
     case 18: launch_igemm2<T, 128, 192, 2, 2, 3, 1>(p, st); return true;
     case 19: launch_igemm2<T, 128, 192, 2, 2, 2, 1>(p, st); return true;
     case 20: launch_igemm2<T, 128, 128, 2, 2, 2, 1>(p, st); return true;
+    case 21: launch_igemm2<T, 128, 192, 2, 2, 2, 2, 4>(p, st); return true;
+    case 22: launch_igemm2<T, 128, 192, 2, 2, 3, 2, 4>(p, st); return true;
+    case 23: launch_igemm2<T, 128, 128, 2, 2, 2, 2, 4>(p, st); return true;
+    case 24: launch_igemm2<T, 128, 128, 2, 2, 3, 2, 4>(p, st); return true;
+    case 25: launch_igemm2<T, 128, 192, 2, 2, 2, 2, 2>(p, st); return true;
+    case 26: launch_igemm2<T, 256, 192, 4, 2, 2, 2, 4>(p, st); return true;
+    case 27: launch_igemm2<T, 256, 128, 4, 2, 2, 2, 4>(p, st); return true;
+    case 28: launch_igemm2<T, 128, 64, 2, 2, 3, 2, 2>(p, st); return true;
+    case 29: launch_igemm2<T, 128, 192, 2, 2, 2, 2, 0, true>(p, st); return true;
+    case 30: launch_igemm2<T, 128, 128, 2, 2, 2, 2, 0, true>(p, st); return true;
+    case 31: launch_igemm2<T, 128, 64, 2, 2, 2, 2, 0, true>(p, st); return true;
+    case 32: launch_igemm2<T, 64, 64, 2, 2, 4, 2, 0, true>(p, st); return true;
+    case 33: launch_igemm2<T, 128, 192, 2, 2, 3, 2, 4, true>(p, st); return true;
+    case 34: launch_igemm2<T, 128, 128, 2, 2, 2, 2, 4, true>(p, st); return true;
+    case 35: launch_igemm2<T, 128, 128, 2, 2, 3, 2, 0, true>(p, st); return true;
+    case 36: launch_igemm2<T, 256, 64, 4, 1, 2, 2, 0, true>(p, st); return true;
   }
   return false;
 }
@@ -773,6 +895,10 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
   p.temb_stride = a->temb_stride; p.res_ld = a->res_ld; p.y_ld = a->y_ld; p.out_mode = a->out_mode;
   p.M = a->B * a->H * a->W;
   p.splitk = 1; p.tiles_n = 1; p.ksteps = 0;
+  static const int s_dbg = getenv("AFLDM_CONV_DBG") ? atoi(getenv("AFLDM_CONV_DBG")) : 0;
+  p.dbg = s_dbg;
+  static const int s_tapin = getenv("AFLDM_CONV_TAPINNER") ? atoi(getenv("AFLDM_CONV_TAPINNER")) : 0;
+  p.tap_inner = s_tapin;
   p.vec_ok = ((a->out_mode == 1 || a->y_ld % 4 == 0) && (!a->residual || a->res_ld % 4 == 0) &&
               (!a->temb || a->temb_stride % 4 == 0)) ? 1 : 0;
   Plan pl = make_plan(a, epr<T>());
@@ -808,7 +934,7 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
   const bool v2_ok = (long long)p.M * (a->C1 > a->C2 ? a->C1 : a->C2) * (long long)sizeof(T) < (1ll << 31) &&
                      (long long)a->Cout * a->KS * a->KS * Ct * (long long)sizeof(T) < (1ll << 31);
   int vid = pl.cfg;
-  if (kVariants[vid].ver == 2 && !v2_ok) vid = kVariants[vid].bm == 128 ? (kVariants[vid].bn >= 128 ? 0 : 1) : 3;
+  if (kVariants[vid].ver >= 2 && !v2_ok) vid = kVariants[vid].bm == 128 ? (kVariants[vid].bn >= 128 ? 0 : 1) : 3;
   launch_variant<T>(vid, p, st);
   int rc = check_launch("afldm_conv2d(igemm)");
   if (rc) return rc;

@@ -192,6 +192,36 @@ def test_conv2d(dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_conv2d_every_gemm_variant(dtype):
+    """Force each implicit-GEMM tile / pipeline variant (afldm_conv2d_tune) on one ragged shape:
+    M = 2*12*12 = 288 (not a tile multiple), virtual concat, Cout = 200 (ragged N), split-K 1 and 3."""
+    from afldm_amd import _lib
+    ops = _ops()
+    B, H, W, C1, C2, Cout, KS = 2, 12, 12, 128, 64, 200, 3
+    g = torch.Generator().manual_seed(14)
+    x = rnd(dtype, torch.randn(B, C1 + C2, H, W, generator=g))
+    w = rnd(dtype, torch.randn(Cout, C1 + C2, KS, KS, generator=g) / (KS * (C1 + C2) ** 0.5))
+    b = torch.randn(Cout, generator=g)
+    res = rnd(dtype, torch.randn(B, Cout, H, W, generator=g))
+    ref = F.conv2d(x, w, b, padding=1) + res
+    x1, x2, wp, rp = nhwc(x[:, :C1], dtype), nhwc(x[:, C1:], dtype), ops.pack_weight(w.cuda(), dtype), nhwc(res, dtype)
+    ws = torch.empty(4 * B * H * W * Cout, dtype=torch.float32, device="cuda")
+    nvar = 0
+    try:
+        for v in range(64):
+            if _lib.lib.afldm_conv2d_tune(v, 1) != 0:
+                break
+            nvar += 1
+            for sk in (1, 3):
+                _lib.check(_lib.lib.afldm_conv2d_tune(v, sk), "tune")
+                y = ops.conv2d(x1, wp, b.cuda(), x2=x2, residual=rp, workspace=ws)
+                close(back(y), ref, dtype, f"conv variant {v} splitk {sk}", bf16_rms=6e-3)
+    finally:
+        _lib.lib.afldm_conv2d_tune(-1, -1)
+    assert nvar >= 37
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv2d_channel_major_output(dtype):
     ops = _ops()
     g = torch.Generator().manual_seed(5)

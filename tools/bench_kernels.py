@@ -51,9 +51,13 @@ CONV_SHAPES = [
 
 
 def bench_conv(dtype=torch.bfloat16):
-    nvar = 21
+    # CONV_VARIANTS=4,12,21  CONV_SHAPES=L32,L16  restrict the sweep
+    variants = [int(v) for v in os.environ.get("CONV_VARIANTS", ",".join(map(str, range(37)))).split(",")]
+    only = [t for t in os.environ.get("CONV_SHAPES", "").split(",") if t]
     out = {}
     for name, B, H, W, C1, C2, Cout, KS in CONV_SHAPES:
+        if only and not any(name.startswith(t) for t in only):
+            continue
         x1 = torch.randn(B, H, W, C1, device="cuda").to(dtype)
         x2 = torch.randn(B, H, W, C2, device="cuda").to(dtype) if C2 else None
         w = (torch.randn(Cout, KS, KS, C1 + C2, device="cuda") / (KS * (C1 + C2) ** 0.5)).to(dtype)
@@ -64,7 +68,7 @@ def bench_conv(dtype=torch.bfloat16):
         M = B * H * W
         res = {}
         ref = None
-        for v in list(range(nvar)):
+        for v in variants:
             for sk in ((-1,) if M >= 16384 else (1, 2, 4, 8, 16)):
                 _lib.check(_lib.lib.afldm_conv2d_tune(v, sk), "tune")
                 try:
@@ -80,7 +84,8 @@ def bench_conv(dtype=torch.bfloat16):
                     res[f"v{v}/sk{sk}"] = ("ERR", str(e)[:60])
         _lib.lib.afldm_conv2d_tune(-1, -1)
         auto = timeit(lambda: ops.conv2d(x1, w, bias, x2=x2, out=y, workspace=ws))
-        best = sorted((v for v in res.items() if v[1][0] != "ERR"), key=lambda kv: kv[1][0])[:4]
+        best = sorted((v for v in res.items() if v[1][0] != "ERR"), key=lambda kv: kv[1][0])
+        best = best if os.environ.get("CONV_ALL") else best[:4]
         print(f"{name:30s} auto {auto:8.1f}us {flops/auto/1e6:7.0f} TF | best: " +
               "  ".join(f"{k}:{v[0]}us/{v[1]:.0f}TF" for k, v in best), flush=True)
         bad = [k for k, v in res.items() if v[0] == "ERR" or v[2] > 2e-2]
