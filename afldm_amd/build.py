@@ -15,6 +15,12 @@ LIB = os.path.join(OUT_DIR, "libafldm_hip.so")
 SOURCES = ["api.hip", "misc.hip", "gn.hip", "af.hip", "sep.hip", "conv.hip", "attn.hip"]
 ARCH = "gfx950"
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# Kernels whose MFMA accumulators are post-processed by VALU code (softmax, SiLU, GroupNorm affine):
+# keep the accumulators in architectural VGPRs.  By default the compiler parks them in AGPRs and
+# pays a v_accvgpr_read/write per element around every VALU use (144 of them per 64-key chunk of
+# the attention loop: as many cycles as the exponentials).  AFLDM_VGPR_FORM=all|none overrides.
+VGPR_FORM = {"attn.hip", "af.hip", "sep.hip"}
+VGPR_FORM_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _hipcc():
@@ -45,7 +51,9 @@ def build(force=False, verbose=True):
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        mode = os.environ.get("AFLDM_VGPR_FORM", "")
+        vg = mode == "all" or (mode != "none" and os.path.basename(src) in VGPR_FORM)
+        cmd = [hipcc] + FLAGS + (VGPR_FORM_FLAGS if vg else []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -1,17 +1,26 @@
 // attn.hip — scaled-dot-product attention (softmax(q k^T * scale) v) on MFMA, flash-style
 // (online softmax, S never materialised), tuned for the UNet's shape: head_dim 24, T <= 1024.
-// With d = 24 the kernel is softmax(VALU)-bound, not MFMA-bound (T^2 exponentials per head vs
-// 4 T^2 d flops), so the structure minimises VALU work per score and LDS/global traffic per MFMA:
 //
+// Measured character (MI355X, T = 1024, 8 heads of 24, batch 64): NOT softmax/VALU bound.  With the
+// exponentials, the maxima and every MFMA removed the first version still took 172 of its 150-210 us:
+// the time goes into fetching K / V^T (K rows of one head are 48-byte runs at a 1152-byte stride: a
+// 128-byte line fill per key for 48 useful bytes, ~60 B/clk/CU of L1 fill with 128 queries per
+// workgroup) and into the per-chunk barrier.  Hence:
+//
+//  * a workgroup = NW waves (8 for T >= 256) x 32 queries of one (batch, head): every staged K / V^T
+//    chunk is reused by 256 queries, halving the fill traffic and the barriers per query;
+//  * K and V^T are staged per 64-key chunk through LDS (double-buffered) with a TWO-chunk register
+//    prefetch (chunk c+2 is in flight while chunk c is computed), in fragment order: every A
+//    fragment is one conflict-free 16-byte LDS read (64-B rows, chunk index XOR-swizzled by the row);
 //  * one wave owns 32 queries (two 16-query B fragments sharing every K / V^T A fragment);
-//    a workgroup = up to 4 waves = 128 queries of one (batch, head);
 //  * S^T = K Q^T (A = K rows, B = Q rows): lane (j = query, g) holds the scores of ITS query for
-//    keys {4g + r} of each 16-key tile -> the row max / row sum are 16 local values + 2 shuffles,
-//    and P^T is already the B operand of the second MFMA, O^T = V^T P^T (A = V^T rows);
-//  * scale * log2(e) is folded into Q once, so a score costs max + sub + exp2 + add (+ cvt);
-//  * K and V^T are staged per 64-key chunk through LDS (double-buffered, global -> VGPR -> LDS,
-//    next chunk's loads in flight during the MFMAs) in fragment order: every A fragment is one
-//    conflict-free 16-byte LDS read (64-B rows, chunk index XOR-swizzled by the row);
+//    keys {4g + r} of each 16-key tile -> the row max is 16 local values + 2 shuffles, and P^T is
+//    already the B operand of the second MFMA, O^T = V^T P^T (A = V^T rows);
+//  * scale * log2(e) is folded into Q once; the running reference max is subtracted BY THE MFMA
+//    (K carries a constant 1, Q carries -m_run in the first padding channel of head_dim) and only
+//    moved when a row max outgrows it by 2^10 (lazy rescale: exact up to rounding, numerator and
+//    denominator share the reference); the row sums come out of the second MFMA through a row of
+//    ones appended to V^T.  A score costs max + exp2 + cvt on the VALU;
 //  * V arrives channel-major (vt[b][c][t], written by afldm_conv2d out_mode 1), so V^T rows are
 //    contiguous key runs and O^T leaves 4 consecutive head channels of one query per lane.
 #include "common.hpp"
@@ -32,10 +41,12 @@ struct AttnP {
 
 __device__ __forceinline__ int aswz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 
-constexpr int KC = 64;  // keys per chunk
+constexpr int KC = 64;              // keys per chunk
+constexpr float LAZY_TAU = 10.0f;   // rescale only when a row max grows by more than 2^10
 
-template <typename T, int ND /* 16-wide tiles of head_dim */, int NKF /* chunk pairs covering head_dim in QK^T */>
-__global__ void __launch_bounds__(256) k_attn(AttnP<T> p) {
+template <typename T, int ND /* 16-row tiles of V^T: head_dim rows + the row of ones */,
+          int NKF /* chunk pairs covering head_dim + the -m_run channel in QK^T */, int NW /* waves */>
+__global__ void __launch_bounds__(NW * 64) k_attn(AttnP<T> p) {
   typedef Mma<T> MM;
   typedef typename MM::Chunk Chunk;
   constexpr int EPC = MM::EPC, KPF = MM::KPF;
@@ -43,13 +54,14 @@ __global__ void __launch_bounds__(256) k_attn(AttnP<T> p) {
   constexpr int NPV = KC / KPF;                  // chunk pairs covering the 64 keys in P V (2 bf16 / 4 fp32)
   constexpr int KT_BYTES = NKF * KC * 64;        // K tile:  [kf][key][64 B]
   constexpr int VT_BYTES = NPV * ND * 16 * 64;   // V^T tile: [pv][d row][64 B] (fragment-ordered keys)
-  __shared__ __attribute__((aligned(16))) char smem[2 * (KT_BYTES + VT_BYTES)];
+  constexpr int SMEM_BYTES = 2 * (KT_BYTES + VT_BYTES);
+  constexpr int NT = NW * 64;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
   char* sK = smem;
   char* sV = smem + 2 * KT_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  constexpr int nthreads = 256, waves = 4;   // always 4 waves: idle ones still help staging
 
   int bid = blockIdx.x;
   const int qb = bid % p.qblocks;
@@ -57,8 +69,31 @@ __global__ void __launch_bounds__(256) k_attn(AttnP<T> p) {
   const int h = bid % p.heads;
   const int b = bid / p.heads;
   const int kb = b / (p.B / p.Bk);
-  const int q0 = (qb * waves + wave) * 32;
+  const int q0 = (qb * NW + wave) * 32;
   const int C = p.heads * p.d;
+
+  // ---- LDS padding is written ONCE: K pieces beyond head_dim and V^T rows beyond head_dim stay
+  // zero in both buffers, V^T row `d` is all ones (-> row d of O^T accumulates the softmax
+  // denominator on the MFMA pipe, no VALU adds), K channel slot `d` is a constant 1 (Q carries
+  // -m_run there); the chunk loop only rewrites the live pieces.
+  for (int idx = tid; idx < SMEM_BYTES / 16; idx += NT) st16<Chunk>(smem + idx * 16, MM::zero());
+  __syncthreads();
+  const int kf_pad = p.d / KPF, lg_pad = (p.d % KPF) / EPC;
+  for (int idx = tid; idx < 2 * NPV * 4 + 2 * KC; idx += NT) {
+    if (idx < 2 * NPV * 4) {
+      Chunk ones;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) ones[e] = from_f32<T>(1.0f);
+      const int bsel = idx / (NPV * 4), rem = idx % (NPV * 4);
+      st16<Chunk>(sV + bsel * VT_BYTES + ((rem >> 2) * ND * 16 + p.d) * 64 + ((rem & 3) << 4), ones);
+    } else {
+      Chunk one0 = MM::zero();
+      one0[0] = from_f32<T>(1.0f);
+      const int r2 = idx - 2 * NPV * 4;
+      const int bsel = r2 / KC, row = r2 % KC;
+      st16<Chunk>(sK + bsel * KT_BYTES + (kf_pad * KC + row) * 64 + ((lg_pad ^ aswz(row)) << 4), one0);
+    }
+  }
 
   // ---- Q fragments (pre-scaled), two 16-query tiles
   Chunk qf[2][NKF];
@@ -77,72 +112,117 @@ __global__ void __launch_bounds__(256) k_attn(AttnP<T> p) {
     }
   }
 
-  // ---- staging assignment: 16-byte pieces of the K chunk and of the V^T chunk
-  //   K : NKF * KC rows x 4 pieces;   V^T: ND*16 d-rows x (KC*sizeof(T)/16) pieces
+  // ---- staging assignment: 16-byte pieces of the K chunk and of the V^T chunk.  Every predicate
+  // and address component that does not depend on the chunk is computed here, once:
+  //   K : NKF * KC rows x 4 pieces, live when the piece lies inside head_dim
+  //   V^T: ND*16 d-rows x (KC*sizeof(T)/16) pieces, live when the row is a head channel
+  // (with 8 waves the K pieces go to the lower half of the workgroup and the V^T pieces to the upper)
   constexpr int KPIECES = NKF * KC * 4;
   constexpr int VPR = KC * (int)sizeof(T) / 16;   // 16-B pieces per V^T row per chunk
   constexpr int VPIECES = ND * 16 * VPR;
-  constexpr int MAXP = (KPIECES + 255) / 256 > (VPIECES + 255) / 256 ? (KPIECES + 255) / 256 : (VPIECES + 255) / 256;
+  constexpr int KPT = (KPIECES + NT - 1) / NT, VPT = (VPIECES + NT - 1) / NT;
+  constexpr int VROT = (KPIECES <= NT / 2 && VPIECES <= NT / 2) ? NT / 2 : 0;
   const T* kbase = p.k + (size_t)kb * p.Tk * p.ldk + h * p.d;
   const T* vbase = p.vt + ((size_t)kb * C + h * p.d) * p.Tk;
-  Chunk rk[MAXP], rv[MAXP];
+  const bool ragged = (p.Tk % KC) != 0;      // only the levels with Tk < 64
+  const bool tiny = p.Tk < EPC;              // Tk = 4 in bf16: less than one 16-byte piece per V^T row
+  bool kact[KPT], vact[VPT];
+  int krow[KPT], ksrc[KPT], kdst[KPT], vkey[VPT], vsrc[VPT], vdst[VPT], vswz[VPT];
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) {
+    const int id = tid + i * NT;
+    const int piece = id & 3, row = (id >> 2) % KC, kf = (id >> 2) / KC;
+    const int e0 = kf * KPF + piece * EPC;
+    kact[i] = id < KPIECES && e0 + EPC <= p.d;
+    krow[i] = row;
+    ksrc[i] = row * p.ldk + e0;
+    kdst[i] = (kf * KC + row) * 64 + ((piece ^ aswz(row)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int id = (tid + VROT) % NT + i * NT;
+    const int piece = id % VPR, drow = id / VPR;
+    vact[i] = id < VPIECES && drow < p.d;
+    vkey[i] = piece * EPC;
+    vsrc[i] = drow * p.Tk + piece * EPC;
+    vswz[i] = aswz(drow);
+    if constexpr (BF) {
+      // 8 consecutive keys 8j..8j+7 of a 32-key half: keys 8j..8j+3 -> group g = 2(j&1), keys
+      // 8j+4..8j+7 -> g = 2(j&1)+1; element offset 0 for j < 2 (keys < 16), 4 otherwise.
+      const int half = piece >> 2, j = piece & 3;
+      vdst[i] = (half * ND * 16 + drow) * 64 + (j >> 1) * 8;
+      vswz[i] = ((2 * (j & 1)) ^ aswz(drow)) << 4;          // byte offset of group g0; g0 + 1 is (that ^ 16)
+    } else {
+      // fp32: 4 consecutive keys = chunk g of 16-key tile t
+      const int t = piece >> 2, g = piece & 3;
+      vdst[i] = (t * ND * 16 + drow) * 64 + ((g ^ aswz(drow)) << 4);
+    }
+  }
+  const T* kp[KPT];     // chunk-aligned levels: per-piece source pointers, advanced by one chunk per load
+  const T* vp[VPT];
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) kp[i] = kbase + ksrc[i];
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) vp[i] = vbase + vsrc[i];
 
-  auto load_chunk = [&](int key0) {
+  auto load_chunk = [&](int key0, Chunk (&rk)[KPT], Chunk (&rv)[VPT]) {
+    if (!ragged) {
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i) {
-      const int id = tid + i * nthreads;
-      rk[i] = MM::zero();
-      rv[i] = MM::zero();
-      if (id < KPIECES) {
-        const int piece = id & 3, row = (id >> 2) % KC, kf = (id >> 2) / KC;
-        const int key = key0 + row, e0 = kf * KPF + piece * EPC;
-        if (key < p.Tk && e0 + EPC <= p.d) rk[i] = ld16<Chunk>(kbase + (size_t)key * p.ldk + e0);
+      for (int i = 0; i < KPT; ++i) {
+        if (kact[i]) rk[i] = ld16<Chunk>(kp[i]);
+        kp[i] += KC * p.ldk;
       }
-      if (id < VPIECES) {
-        const int piece = id % VPR, drow = id / VPR;
-        const int key = key0 + piece * EPC;
-        if (drow < p.d && key < p.Tk) {
-          const T* vsrc = vbase + (size_t)drow * p.Tk + key;
-          if (key + EPC <= p.Tk) {
-            rv[i] = ld16<Chunk>(vsrc);
-          } else {  // Tk < one piece (the 2x2 level, Tk = 4): element-wise, zero tail
 #pragma unroll
-            for (int e = 0; e < EPC; ++e)
-              if (key + e < p.Tk) rv[i][e] = vsrc[e];
-          }
+      for (int i = 0; i < VPT; ++i) {
+        if (vact[i]) rv[i] = ld16<Chunk>(vp[i]);
+        vp[i] += KC;
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      if (kact[i]) {
+        // ragged last chunk: clamp to a valid key (its scores are masked below; the value only has to be finite)
+        int off = key0 * p.ldk + ksrc[i];
+        if (key0 + krow[i] >= p.Tk) off = (p.Tk - 1) * p.ldk + ksrc[i] - krow[i] * p.ldk;
+        rk[i] = ld16<Chunk>(kbase + off);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      if (vact[i]) {
+        if (tiny) {   // element-wise, zero tail
+          rv[i] = MM::zero();
+#pragma unroll
+          for (int e = 0; e < EPC; ++e)
+            if (key0 + vkey[i] + e < p.Tk) rv[i][e] = vbase[vsrc[i] + key0 + e];
+        } else {
+          int off = vsrc[i] + key0;
+          if (key0 + vkey[i] + EPC > p.Tk) off = vsrc[i] - vkey[i] + p.Tk - EPC;   // masked keys: any finite data
+          rv[i] = ld16<Chunk>(vbase + off);
         }
       }
     }
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, const Chunk (&rk)[KPT], const Chunk (&rv)[VPT]) {
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i) {
-      const int id = tid + i * nthreads;
-      if (id < KPIECES) {
-        const int piece = id & 3, row = (id >> 2) % KC, kf = (id >> 2) / KC;
-        st16<Chunk>(sK + buf * KT_BYTES + (kf * KC + row) * 64 + ((piece ^ aswz(row)) << 4), rk[i]);
-      }
-      if (id < VPIECES) {
-        const int piece = id % VPR, drow = id / VPR;
-        char* base = sV + buf * VT_BYTES;
+    for (int i = 0; i < KPT; ++i)
+      if (kact[i]) st16<Chunk>(sK + buf * KT_BYTES + kdst[i], rk[i]);
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      if (vact[i]) {
+        char* base = sV + buf * VT_BYTES + vdst[i];
         if constexpr (BF) {
-          // 8 consecutive keys 8j..8j+7 of a 32-key half: keys 8j..8j+3 -> group g = 2(j&1), keys
-          // 8j+4..8j+7 -> g = 2(j&1)+1; element offset 0 for j < 2 (keys < 16), 4 otherwise.
-          const int half = piece >> 2, j = piece & 3;
-          const int g0 = 2 * (j & 1), eoff = (j >> 1) * 4;
           bf16x4 lo, hi;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             lo[e] = rv[i][e];
             hi[e] = rv[i][4 + e];
           }
-          char* rowp = base + (half * ND * 16 + drow) * 64;
-          *reinterpret_cast<bf16x4*>(rowp + (((g0) ^ aswz(drow)) << 4) + eoff * 2) = lo;
-          *reinterpret_cast<bf16x4*>(rowp + (((g0 + 1) ^ aswz(drow)) << 4) + eoff * 2) = hi;
+          *reinterpret_cast<bf16x4*>(base + vswz[i]) = lo;
+          *reinterpret_cast<bf16x4*>(base + (vswz[i] ^ 16)) = hi;
         } else {
-          // fp32: 4 consecutive keys = chunk g of 16-key tile t
-          const int t = piece >> 2, g = piece & 3;
-          st16<Chunk>(base + (t * ND * 16 + drow) * 64 + ((g ^ aswz(drow)) << 4), rv[i]);
+          st16<Chunk>(base, rv[i]);
         }
       }
     }
@@ -153,17 +233,11 @@ __global__ void __launch_bounds__(256) k_attn(AttnP<T> p) {
   for (int u = 0; u < 2; ++u)
 #pragma unroll
     for (int t = 0; t < ND; ++t) oacc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
+  // m_run: the reference point the exponentials are taken against (log2 units, representable in T).
+  float m_run[2] = {0.f, 0.f};
 
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-  int buf = 0;
-  for (int key0 = 0; key0 < p.Tk; key0 += KC, buf ^= 1) {
-    const bool more = key0 + KC < p.Tk;
-    if (more) load_chunk(key0 + KC);
-
-    // ---- S^T: 4 key tiles x 2 query tiles
+  auto compute = [&](int key0, int buf) {
+    // ---- S^T - m_run: 4 key tiles x 2 query tiles
     f32x4 s[2][4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -189,33 +263,46 @@ __global__ void __launch_bounds__(256) k_attn(AttnP<T> p) {
           for (int r = 0; r < 4; ++r)
             if (key0 + 16 * t + 4 * lg + r >= p.Tk) s[u][t][r] = -1e30f;
     }
-    // ---- online softmax (scores are already in log2 units)
+    // ---- row maxima of the shifted scores
+    float mloc[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      float mloc = s[u][0][0];
+      float m = s[u][0][0];
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, s[u][t][r]);
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-      const float m_new = fmaxf(m_run[u], mloc);
-      const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);
-      m_run[u] = m_new;
-      float psum = 0.f;
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(s[u][t][r] - m_new);
-          s[u][t][r] = pv;
-          psum += pv;
-        }
-      l_run[u] = l_run[u] * alpha + psum;  // lane-partial; the 4 lane groups are combined at the end
-#pragma unroll
-      for (int t = 0; t < ND; ++t) oacc[u][t] *= alpha;
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, s[u][t][r]);
+      m = fmaxf(m, __shfl_xor(m, 16, 64));
+      mloc[u] = fmaxf(m, __shfl_xor(m, 32, 64));
     }
-    // ---- O^T += V^T P^T
+    const bool first = key0 == 0;
+    if (first || __any((mloc[0] > LAZY_TAU) || (mloc[1] > LAZY_TAU))) {   // wave-uniform, rare after chunk 0
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        // the new reference is rounded to T (it travels in Q); any value works as long as the
+        // scores, the numerator and the denominator all use the same one
+        const float m_new = to_f32(from_f32<T>(m_run[u] + (first ? mloc[u] : fmaxf(mloc[u], 0.f))));
+        const float delta = m_new - m_run[u];
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        m_run[u] = m_new;
+#pragma unroll
+        for (int kf = 0; kf < NKF; ++kf)
+          if (kf == kf_pad && lg == lg_pad) qf[u][kf][0] = from_f32<T>(-m_new);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[u][t][r] -= delta;
+#pragma unroll
+        for (int t = 0; t < ND; ++t) oacc[u][t] *= alpha;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[u][t][r] = __builtin_amdgcn_exp2f(s[u][t][r]);
+    // ---- O^T += V^T P^T   (row d of V^T is ones: O^T row d = running softmax denominator)
 #pragma unroll
     for (int pv = 0; pv < NPV; ++pv) {
       Chunk pb[2];
@@ -239,16 +326,42 @@ __global__ void __launch_bounds__(256) k_attn(AttnP<T> p) {
         for (int u = 0; u < 2; ++u) MM::mma(oacc[u][td], va, pb[u]);
       }
     }
-    if (more) store_chunk(buf ^ 1);
+  };
+
+  // ---- chunk loop, two register stages: while chunk c is computed from LDS buffer c & 1, chunk
+  // c + 1 waits in registers (stored to the other buffer at the end of the step) and chunk c + 2 is
+  // in flight from global memory.
+  Chunk rkA[KPT], rvA[VPT], rkB[KPT], rvB[VPT];
+  const int nchunks = (p.Tk + KC - 1) / KC;
+  load_chunk(0, rkA, rvA);
+  __syncthreads();       // zero fill / constant rows complete before the live pieces land
+  store_chunk(0, rkA, rvA);
+  if (nchunks > 1) load_chunk(KC, rkB, rvB);
+  __syncthreads();
+  for (int c = 0; c < nchunks; c += 2) {
+    // even step: B holds chunk c+1, A receives chunk c+2
+    if (c + 2 < nchunks) load_chunk((c + 2) * KC, rkA, rvA);
+    compute(c * KC, 0);
+    if (c + 1 < nchunks) store_chunk(1, rkB, rvB);
+    __syncthreads();
+    if (c + 1 >= nchunks) break;
+    // odd step: A holds chunk c+2, B receives chunk c+3
+    if (c + 3 < nchunks) load_chunk((c + 3) * KC, rkB, rvB);
+    compute((c + 1) * KC, 1);
+    if (c + 2 < nchunks) store_chunk(0, rkA, rvA);
     __syncthreads();
   }
 
-  // ---- finish: combine lane-partial row sums, normalise, store 4 consecutive channels per lane
+  // ---- finish: the denominator sits in O^T row d = tile d/16, lane group (d%16)/4, element 0
+  // (head_dim is a multiple of 8); normalise, store 4 consecutive channels per lane
+  const int ltile = p.d >> 4, lsrc = li + 16 * ((p.d & 15) >> 2);
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    float l = l_run[u];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    float lsel = 0.f;
+#pragma unroll
+    for (int td = 0; td < ND; ++td)
+      if (td == ltile) lsel = oacc[u][td][0];
+    const float l = __shfl(lsel, lsrc, 64);
     const float inv = 1.0f / l;
     const int qrow = q0 + 16 * u + li;
     if (qrow < p.Tq) {
@@ -263,6 +376,17 @@ __global__ void __launch_bounds__(256) k_attn(AttnP<T> p) {
   }
 }
 
+template <typename T, int NW>
+static bool attn_launch_nw(const AttnP<T>& p, int nd, int nkf, int grid, hipStream_t st) {
+  if (nd == 1 && nkf == 1) k_attn<T, 1, 1, NW><<<grid, NW * 64, 0, st>>>(p);
+  else if (nd == 2 && nkf == 1) k_attn<T, 2, 1, NW><<<grid, NW * 64, 0, st>>>(p);
+  else if (nd == 2 && nkf == 2) k_attn<T, 2, 2, NW><<<grid, NW * 64, 0, st>>>(p);
+  else if (nd == 3 && nkf == 2) k_attn<T, 3, 2, NW><<<grid, NW * 64, 0, st>>>(p);
+  else if (nd == 3 && nkf == 3) k_attn<T, 3, 3, NW><<<grid, NW * 64, 0, st>>>(p);
+  else return false;
+  return true;
+}
+
 template <typename T>
 static int attn_launch(const void* q, int ldq, const void* k, int ldk, const void* vt, void* o, int ldo, int B, int Bk,
                        int heads, int Tq, int Tk, int d, float scale, hipStream_t st) {
@@ -271,15 +395,15 @@ static int attn_launch(const void* q, int ldq, const void* k, int ldk, const voi
   p.ldq = ldq; p.ldk = ldk; p.ldo = ldo;
   p.B = B; p.Bk = Bk; p.heads = heads; p.Tq = Tq; p.Tk = Tk; p.d = d;
   p.scale_log2e = scale * 1.4426950408889634f;
-  const int waves = 4;
+  // 8 waves (256 queries share every staged chunk) once a (batch, head) has that many queries,
+  // 4 waves below; a wave always owns 32 queries
+  const int waves = Tq >= 256 ? 8 : 4;
   p.qblocks = (Tq + 32 * waves - 1) / (32 * waves);
   const int grid = B * heads * p.qblocks;
   constexpr int KPF = Mma<T>::KPF;
-  const int nkf = (d + KPF - 1) / KPF, nd = (d + 15) / 16;
-  if (nd == 1 && nkf == 1) k_attn<T, 1, 1><<<grid, waves * 64, 0, st>>>(p);
-  else if (nd == 2 && nkf == 1) k_attn<T, 2, 1><<<grid, waves * 64, 0, st>>>(p);
-  else if (nd == 2 && nkf == 2) k_attn<T, 2, 2><<<grid, waves * 64, 0, st>>>(p);
-  else {
+  const int nkf = d / KPF + 1, nd = d / 16 + 1;    // + 1: room for the -m_run channel / the row of ones
+  const bool ok = waves == 8 ? attn_launch_nw<T, 8>(p, nd, nkf, grid, st) : attn_launch_nw<T, 4>(p, nd, nkf, grid, st);
+  if (!ok) {
     set_error("afldm_attention: unsupported head_dim %d", d);
     return AFLDM_ESHAPE;
   }
