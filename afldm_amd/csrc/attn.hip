@@ -23,6 +23,8 @@
 //    ones appended to V^T.  A score costs max + exp2 + cvt on the VALU;
 //  * V arrives channel-major (vt[b][c][t], written by afldm_conv2d out_mode 1), so V^T rows are
 //    contiguous key runs and O^T leaves 4 consecutive head channels of one query per lane.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace afldm {
@@ -45,7 +47,10 @@ constexpr int KC = 64;              // keys per chunk
 constexpr float LAZY_TAU = 10.0f;   // rescale only when a row max grows by more than 2^10
 
 template <typename T, int ND /* 16-row tiles of V^T: head_dim rows + the row of ones */,
-          int NKF /* chunk pairs covering head_dim + the -m_run channel in QK^T */, int NW /* waves */>
+          int NKF /* chunk pairs covering head_dim + the -m_run channel in QK^T */, int NW /* waves */,
+          bool RAGGED /* Tk % 64 != 0: clamped / element-wise staging and key masking */,
+          int DBG = 0 /* timing decomposition (AFLDM_ATTN_DBG): 1 no exp2, 2 no P V MFMA, 4 no S MFMA, 8 no max,
+                         16 no per-chunk staging, 32 no per-chunk barrier; results are garbage */>
 __global__ void __launch_bounds__(NW * 64) k_attn(AttnP<T> p) {
   typedef Mma<T> MM;
   typedef typename MM::Chunk Chunk;
@@ -63,7 +68,9 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnP<T> p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
 
-  int bid = blockIdx.x;
+  // XCD-aware order: the query blocks of one (batch, head) - and neighbouring heads, which share
+  // K's cache lines - run on the same XCD and hit its L2
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int qb = bid % p.qblocks;
   bid /= p.qblocks;
   const int h = bid % p.heads;
@@ -124,8 +131,7 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnP<T> p) {
   constexpr int VROT = (KPIECES <= NT / 2 && VPIECES <= NT / 2) ? NT / 2 : 0;
   const T* kbase = p.k + (size_t)kb * p.Tk * p.ldk + h * p.d;
   const T* vbase = p.vt + ((size_t)kb * C + h * p.d) * p.Tk;
-  const bool ragged = (p.Tk % KC) != 0;      // only the levels with Tk < 64
-  const bool tiny = p.Tk < EPC;              // Tk = 4 in bf16: less than one 16-byte piece per V^T row
+  const bool tiny = RAGGED && p.Tk < EPC;    // Tk = 4 in bf16: less than one 16-byte piece per V^T row
   bool kact[KPT], vact[VPT];
   int krow[KPT], ksrc[KPT], kdst[KPT], vkey[VPT], vsrc[VPT], vdst[VPT], vswz[VPT];
 #pragma unroll
@@ -160,25 +166,30 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnP<T> p) {
   }
   const T* kp[KPT];     // chunk-aligned levels: per-piece source pointers, advanced by one chunk per load
   const T* vp[VPT];
+  // (lanes without a live piece still load - from a valid address - so that the chunk loop has
+  //  no control flow around its global loads: with branches there the compiler's s_waitcnt
+  //  insertion fell back to vmcnt(0) right after the loads and the prefetch was fully exposed)
 #pragma unroll
-  for (int i = 0; i < KPT; ++i) kp[i] = kbase + ksrc[i];
+  for (int i = 0; i < KPT; ++i) kp[i] = kbase + (kact[i] ? ksrc[i] : krow[i] * p.ldk);
 #pragma unroll
-  for (int i = 0; i < VPT; ++i) vp[i] = vbase + vsrc[i];
+  for (int i = 0; i < VPT; ++i) vp[i] = vbase + (vact[i] ? vsrc[i] : vkey[i]);
 
-  auto load_chunk = [&](int key0, Chunk (&rk)[KPT], Chunk (&rv)[VPT]) {
-    if (!ragged) {
+  auto load_chunk = [&](int key0, bool advance, Chunk (&rk)[KPT], Chunk (&rv)[VPT]) {
+    if constexpr (!RAGGED) {
+      const int kstep = advance ? KC * p.ldk : 0, vstep = advance ? KC : 0;   // past the end: reload the last chunk
 #pragma unroll
       for (int i = 0; i < KPT; ++i) {
-        if (kact[i]) rk[i] = ld16<Chunk>(kp[i]);
-        kp[i] += KC * p.ldk;
+        rk[i] = ld16<Chunk>(kp[i]);
+        kp[i] += kstep;
       }
 #pragma unroll
       for (int i = 0; i < VPT; ++i) {
-        if (vact[i]) rv[i] = ld16<Chunk>(vp[i]);
-        vp[i] += KC;
+        rv[i] = ld16<Chunk>(vp[i]);
+        vp[i] += vstep;
       }
       return;
     }
+    if (key0 >= p.Tk) return;
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
       if (kact[i]) {
@@ -251,10 +262,11 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnP<T> p) {
       for (int u = 0; u < 2; ++u) {
         s[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kf = 0; kf < NKF; ++kf) MM::mma(s[u][t], kfz[kf], qf[u][kf]);
+        for (int kf = 0; kf < NKF; ++kf)
+          if (!(DBG & 4)) MM::mma(s[u][t], kfz[kf], qf[u][kf]);
       }
     }
-    if (key0 + KC > p.Tk) {  // ragged last chunk: mask keys >= Tk (wave-uniform branch)
+    if (RAGGED && key0 + KC > p.Tk) {  // ragged last chunk: mask keys >= Tk (wave-uniform branch)
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -271,7 +283,8 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnP<T> p) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) m = fmaxf(m, s[u][t][r]);
+        for (int r = 0; r < 4; ++r)
+          if (!(DBG & 8)) m = fmaxf(m, s[u][t][r]);
       m = fmaxf(m, __shfl_xor(m, 16, 64));
       mloc[u] = fmaxf(m, __shfl_xor(m, 32, 64));
     }
@@ -301,7 +314,8 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnP<T> p) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[u][t][r] = __builtin_amdgcn_exp2f(s[u][t][r]);
+        for (int r = 0; r < 4; ++r)
+          if (!(DBG & 1)) s[u][t][r] = __builtin_amdgcn_exp2f(s[u][t][r]);
     // ---- O^T += V^T P^T   (row d of V^T is ones: O^T row d = running softmax denominator)
 #pragma unroll
     for (int pv = 0; pv < NPV; ++pv) {
@@ -323,7 +337,8 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnP<T> p) {
         const int row = 16 * td + li;
         Chunk va = ld16<Chunk>(sV + buf * VT_BYTES + (pv * ND * 16 + row) * 64 + ((lg ^ aswz(row)) << 4));
 #pragma unroll
-        for (int u = 0; u < 2; ++u) MM::mma(oacc[u][td], va, pb[u]);
+        for (int u = 0; u < 2; ++u)
+          if (!(DBG & 2)) MM::mma(oacc[u][td], va, pb[u]);
       }
     }
   };
@@ -333,23 +348,23 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnP<T> p) {
   // in flight from global memory.
   Chunk rkA[KPT], rvA[VPT], rkB[KPT], rvB[VPT];
   const int nchunks = (p.Tk + KC - 1) / KC;
-  load_chunk(0, rkA, rvA);
+  load_chunk(0, 1 < nchunks, rkA, rvA);     // pointers now at chunk 1 (if there is one)
   __syncthreads();       // zero fill / constant rows complete before the live pieces land
   store_chunk(0, rkA, rvA);
-  if (nchunks > 1) load_chunk(KC, rkB, rvB);
+  load_chunk(KC, 2 < nchunks, rkB, rvB);    // chunk 1 (or chunk 0 again when there is only one)
   __syncthreads();
   for (int c = 0; c < nchunks; c += 2) {
     // even step: B holds chunk c+1, A receives chunk c+2
-    if (c + 2 < nchunks) load_chunk((c + 2) * KC, rkA, rvA);
+    if (!(DBG & 16)) load_chunk((c + 2) * KC, c + 3 < nchunks, rkA, rvA);
     compute(c * KC, 0);
-    if (c + 1 < nchunks) store_chunk(1, rkB, rvB);
-    __syncthreads();
+    if (!(DBG & 16) && c + 1 < nchunks) store_chunk(1, rkB, rvB);
+    if (!(DBG & 32)) __syncthreads();
     if (c + 1 >= nchunks) break;
     // odd step: A holds chunk c+2, B receives chunk c+3
-    if (c + 3 < nchunks) load_chunk((c + 3) * KC, rkB, rvB);
+    if (!(DBG & 16)) load_chunk((c + 3) * KC, c + 4 < nchunks, rkB, rvB);
     compute((c + 1) * KC, 1);
-    if (c + 2 < nchunks) store_chunk(0, rkA, rvA);
-    __syncthreads();
+    if (!(DBG & 16) && c + 2 < nchunks) store_chunk(0, rkA, rvA);
+    if (!(DBG & 32)) __syncthreads();
   }
 
   // ---- finish: the denominator sits in O^T row d = tile d/16, lane group (d%16)/4, element 0
@@ -376,13 +391,29 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnP<T> p) {
   }
 }
 
-template <typename T, int NW>
+template <typename T, int NW, bool RAGGED>
 static bool attn_launch_nw(const AttnP<T>& p, int nd, int nkf, int grid, hipStream_t st) {
-  if (nd == 1 && nkf == 1) k_attn<T, 1, 1, NW><<<grid, NW * 64, 0, st>>>(p);
-  else if (nd == 2 && nkf == 1) k_attn<T, 2, 1, NW><<<grid, NW * 64, 0, st>>>(p);
-  else if (nd == 2 && nkf == 2) k_attn<T, 2, 2, NW><<<grid, NW * 64, 0, st>>>(p);
-  else if (nd == 3 && nkf == 2) k_attn<T, 3, 2, NW><<<grid, NW * 64, 0, st>>>(p);
-  else if (nd == 3 && nkf == 3) k_attn<T, 3, 3, NW><<<grid, NW * 64, 0, st>>>(p);
+  if (nd == 1 && nkf == 1) k_attn<T, 1, 1, NW, RAGGED><<<grid, NW * 64, 0, st>>>(p);
+  else if (nd == 2 && nkf == 1) {
+    static const int dbg = getenv("AFLDM_ATTN_DBG") ? atoi(getenv("AFLDM_ATTN_DBG")) : 0;
+    if (sizeof(T) == 2 && NW == 8 && !RAGGED && dbg) {
+      switch (dbg) {
+        case 1: k_attn<T, 2, 1, NW, RAGGED, 1><<<grid, NW * 64, 0, st>>>(p); break;
+        case 8: k_attn<T, 2, 1, NW, RAGGED, 8><<<grid, NW * 64, 0, st>>>(p); break;
+        case 9: k_attn<T, 2, 1, NW, RAGGED, 9><<<grid, NW * 64, 0, st>>>(p); break;
+        case 16: k_attn<T, 2, 1, NW, RAGGED, 16><<<grid, NW * 64, 0, st>>>(p); break;
+        case 48: k_attn<T, 2, 1, NW, RAGGED, 48><<<grid, NW * 64, 0, st>>>(p); break;
+        case 57: k_attn<T, 2, 1, NW, RAGGED, 57><<<grid, NW * 64, 0, st>>>(p); break;
+        case 63: k_attn<T, 2, 1, NW, RAGGED, 63><<<grid, NW * 64, 0, st>>>(p); break;
+        default: k_attn<T, 2, 1, NW, RAGGED><<<grid, NW * 64, 0, st>>>(p); break;
+      }
+    } else {
+      k_attn<T, 2, 1, NW, RAGGED><<<grid, NW * 64, 0, st>>>(p);
+    }
+  }
+  else if (nd == 2 && nkf == 2) k_attn<T, 2, 2, NW, RAGGED><<<grid, NW * 64, 0, st>>>(p);
+  else if (nd == 3 && nkf == 2) k_attn<T, 3, 2, NW, RAGGED><<<grid, NW * 64, 0, st>>>(p);
+  else if (nd == 3 && nkf == 3) k_attn<T, 3, 3, NW, RAGGED><<<grid, NW * 64, 0, st>>>(p);
   else return false;
   return true;
 }
@@ -402,7 +433,9 @@ static int attn_launch(const void* q, int ldq, const void* k, int ldk, const voi
   const int grid = B * heads * p.qblocks;
   constexpr int KPF = Mma<T>::KPF;
   const int nkf = d / KPF + 1, nd = d / 16 + 1;    // + 1: room for the -m_run channel / the row of ones
-  const bool ok = waves == 8 ? attn_launch_nw<T, 8>(p, nd, nkf, grid, st) : attn_launch_nw<T, 4>(p, nd, nkf, grid, st);
+  const bool ragged = Tk % KC != 0;
+  const bool ok = waves == 8 ? (ragged ? attn_launch_nw<T, 8, true>(p, nd, nkf, grid, st) : attn_launch_nw<T, 8, false>(p, nd, nkf, grid, st))
+                             : (ragged ? attn_launch_nw<T, 4, true>(p, nd, nkf, grid, st) : attn_launch_nw<T, 4, false>(p, nd, nkf, grid, st));
   if (!ok) {
     set_error("afldm_attention: unsupported head_dim %d", d);
     return AFLDM_ESHAPE;
