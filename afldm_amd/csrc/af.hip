@@ -6,14 +6,10 @@
 // matrices built from the reference's masks (afldm_filter_matrix); WarpedNonlinearity
 // (reference af_blocks.py:19-28) is  D silu(U X U^T) D^T  per (sample, channel) plane.
 //
-// k_af_act_mfma (N = 16, 32): one workgroup = one sample x 16 channels, NHWC.  The MFMA column
-// index j is the channel, so every pass is "constant matrix x data" (A = U or D rows from LDS,
-// B = data).  Four passes:  P1 (h -> h', U)  -> LDS ->  P2 (w -> w', U), SiLU, P3 (w' -> w, D)
-// chained IN REGISTERS (the accumulator layout of P2 is a legal B operand for P3 once D's
-// columns are permuted to match, see Mma<T>)  -> LDS ->  P4 (h' -> h, D).  The 2N x 2N
-// upsampled plane therefore never exists in memory: HBM traffic is one read + one write of the
-// tensor (the reference: ~30x that).  GroupNorm-apply is fused into the load.
-// The h' axis is processed in slabs of SL rows to bound LDS (P4 accumulates across slabs).
+// k_af_act_plane (N = 16, 32): one workgroup = one sample x 16 channels, NHWC; every wave carries
+// whole channel planes through the four separable passes on MFMA with the upsampled 2N x 2N plane
+// living only in accumulator registers (see the kernel).  HBM traffic is one read + one write of
+// the tensor (the reference: ~30x that).  GroupNorm-apply is fused into the load.
 //
 // k_af_act_small (N = 2, 4, 8): one thread per (sample, channel) plane held in registers;
 // lanes = channels, so the matrix coefficients are wave-uniform scalar operands.  HBM-bound.
@@ -52,134 +48,157 @@ __device__ __forceinline__ bf16x8 pack_chain<bf16>(const f32x4& lo, const f32x4&
   return v;
 }
 
-constexpr int af_nw(int N) { return N == 32 ? 8 : 4; }
-
-template <typename T, int N>
-struct AfCfg {
+// ----------------------------------------------------------------------------- plane kernel (N = 16, 32)
+template <typename T, int N, int CH = 16 /* channels per item: 16, or 8 when that fills the CUs more evenly */>
+struct PlaneCfg {
   typedef Mma<T> MM;
   static constexpr int EPC = MM::EPC, KPF = MM::KPF;
   static constexpr int H2 = 2 * N;
   static constexpr int KH = ((N + KPF - 1) / KPF) * KPF;  // K extent for contractions over an N-long axis
-  static constexpr int SL = (sizeof(T) == 2) ? 32 : 16;   // h' rows per slab
-  static constexpr int NSLAB = H2 / SL;
-  static constexpr int NW = af_nw(N);                      // waves per workgroup
-  static constexpr int WPW = N / NW;                       // w columns per wave in P1 / P4 (4)
-  static constexpr int RPW = SL / NW;                      // h' rows per wave in P2/P3
-  static constexpr int RG = RPW < 4 ? RPW : 4;             // rows processed together (packed V writes)
-  static constexpr bool PERM = sizeof(T) == 2;             // P3's matrix needs chain-permuted columns
-  // Every LDS array is a set of K-contiguous rows read as 16-byte chunks by 16 lanes at a time.
-  // Power-of-two row strides (64 / 128 B) put those lanes on the same banks (up to 8-way on the
-  // packed writes), so rows are padded by one chunk (guide G4).  fp32 N = 32 has no LDS to spare.
-  static constexpr int PAD = (sizeof(T) == 2 && N == 32) ? EPC : 0;   // (N = 16 keeps 2 workgroups per CU unpadded)
-  static constexpr int KHP = KH + PAD;                     // row stride of Xs / T1 / Us
-  static constexpr int H2P = H2 + PAD;                     // row stride of Ds / Dp
-  static constexpr int SLP = SL + PAD;                     // row stride of Vs
-  // packed constants (= LDS image, elements of T): Us [H2][KHP] | Ds [N][H2P] | Dp [N][H2P] (bf16 only)
-  static constexpr int US = H2 * KHP;
-  static constexpr int DS = N * H2P;
-  static constexpr int DPS = PERM ? N * H2P : 0;
-  static constexpr int CONST_ELEMS = US + DS + DPS;
-  // LDS carve (elements of T)
-  static constexpr int XS = N * 16 * KHP;                  // also re-used as the output staging tile
-  static constexpr int T1S = SL * 16 * KHP;
-  static constexpr int VS = N * 16 * SLP;
-  static constexpr int LDS_BYTES = (CONST_ELEMS + XS + T1S + VS) * (int)sizeof(T) + 2 * 16 * (int)sizeof(float);
-  static_assert(WPW == 4, "P1 packs 4 consecutive w columns per store");
-  static_assert(N * N * 16 <= XS, "output staging tile must fit in the X region");
+  static constexpr int NKF1 = KH / KPF;                    // K steps over an N-long axis (h, w)
+  static constexpr int NKF3 = H2 / KPF;                    // K steps over a 2N-long axis (h', w')
+  static constexpr int TN = N / 16, TH = H2 / 16;          // 16-row tiles of an N / 2N axis
+  static constexpr int NW = 4;                             // waves per workgroup
+  static constexpr int CPW = CH / NW;                      // channel planes per wave
+  static constexpr bool PERM = sizeof(T) == 2;             // chained operands permute K (see Mma<T>)
+  static constexpr bool CREG = sizeof(T) == 2;             // constant fragments cached in registers
+  // LDS rows are K-contiguous runs read as 16-byte chunks by 16 lanes at a time; one chunk of
+  // padding per row makes the 16 row starts hit 16 distinct 4-bank groups (guide G4).
+  static constexpr int KHP = KH + EPC;                     // Xs row stride   [c][w][h]
+  static constexpr int H2P = H2 + EPC;                     // Vt row stride   [w][h']
+  static constexpr int YRP = N * CH + 8;                   // Ys row stride   [h][w*CH + c]
+  // constant fragments, each 64 lanes x EPC elements in lane order (one conflict-free 16-byte read):
+  //   ufB[th][kf]  U rows 16th+li, k = h standard          (B operand of P1)
+  //   upA[t2][f]   U rows 16t2+li, k = w chain-permuted     (A operand of P2)
+  //   dpA[t3][f]   D rows 16t3+li, k = w' chain-permuted    (A operand of P3)
+  //   dA [t4][kf]  D rows 16t4+li, k = h' standard          (A operand of P4)
+  static constexpr int NF_U = TH * NKF1, NF_D = TN * NKF3;
+  static constexpr int F_UFB = 0, F_UPA = NF_U, F_DPA = 2 * NF_U, F_DA = 2 * NF_U + NF_D;
+  static constexpr int NFRAG = 2 * NF_U + 2 * NF_D;
+  static constexpr int CONST_ELEMS = NFRAG * 64 * EPC;
+  static constexpr int XS = CH * N * KHP;                  // X tile; re-used as the output staging tile Ys
+  static constexpr int VT = N * H2P;                       // per wave: V^T of one plane
+  static constexpr int LDS_BYTES = (CONST_ELEMS + XS + NW * VT) * (int)sizeof(T) + 2 * 16 * (int)sizeof(float);
+  static_assert(N * YRP <= XS, "output staging tile must fit in the X region");
+  static_assert(NW * 16 * 2 * 8 <= NW * VT * (int)sizeof(T), "GroupNorm reduction scratch aliases Vt");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-  static_assert(CONST_ELEMS % EPC == 0, "constant image must be whole chunks");
 };
 
-// Builds the LDS image of the filter matrices once (host calls it once per (N, dtype)).
+// K index of element e of the chunk held by lane group g in K step f.  Standard operands (read
+// from LDS / memory): consecutive.  Chained operands (an MFMA accumulator re-used as the B operand
+// of the next MFMA): fp32 accumulators are already in standard order; two bf16 accumulator tiles
+// pack into one chunk as (lo = tile 2f rows 4g..4g+3, hi = tile 2f+1 rows 4g..4g+3).
+template <typename T>
+__host__ __device__ constexpr int af_kidx(int f, int g, int e, bool chained) {
+  return (chained && sizeof(T) == 2) ? 32 * f + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4))
+                                     : f * Mma<T>::KPF + g * Mma<T>::EPC + e;
+}
+
+// z' / (1 + exp2(-z')) on 4 accumulator values (z' = z log2(e); the caller's next matrix carries the
+// ln(2)): two packed adds / multiplies and 8 transcendentals instead of 12 + 8 scalar operations.
+__device__ __forceinline__ f32x4 silu_log2_x4(const f32x4& z) {
+  f32x4 d;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) d[r] = __builtin_amdgcn_exp2f(-z[r]);
+  d = d + 1.0f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) d[r] = __builtin_amdgcn_rcpf(d[r]);
+  return z * d;
+}
+
+// Builds the constant-fragment image once (host calls it once per (N, dtype)).
 template <typename T, int N>
 __global__ void k_af_pack(const float* __restrict__ U, const float* __restrict__ D, T* __restrict__ out) {
-  typedef AfCfg<T, N> CF;
-  constexpr int H2 = CF::H2, KHP = CF::KHP, H2P = CF::H2P;
+  typedef PlaneCfg<T, N> CF;
+  constexpr int EPC = CF::EPC, H2 = CF::H2;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < CF::CONST_ELEMS; i += gridDim.x * blockDim.x) {
+    const int frag = i / (64 * EPC), lane = (i / EPC) % 64, e = i % EPC;
+    const int li = lane & 15, g = lane >> 4;
     float v = 0.f;
-    if (i < CF::US) {
-      const int r = i / KHP, k = i - r * KHP;
-      if (k < N) v = U[r * N + k];
-    } else if (i < CF::US + CF::DS) {
-      const int j = i - CF::US;
-      const int r = j / H2P, k = j - r * H2P;
-      if (k < H2) v = D[r * H2 + k];
+    if (frag < CF::F_UPA) {
+      const int th = frag / CF::NKF1, kf = frag % CF::NKF1, k = af_kidx<T>(kf, g, e, false);
+      if (k < N) v = U[(16 * th + li) * N + k];
+    } else if (frag < CF::F_DPA) {
+      // (P2's matrix carries log2(e) and P3's ln(2): the SiLU in between works on z' = z log2(e),
+      //  z sigmoid(z) = ln(2) z' / (1 + exp2(-z')), one multiply and the negation free)
+      const int q = frag - CF::F_UPA, t2 = q / CF::NKF1, f = q % CF::NKF1, k = af_kidx<T>(f, g, e, true);
+      if (k < N) v = U[(16 * t2 + li) * N + k] * 1.4426950408889634f;
+    } else if (frag < CF::F_DA) {
+      const int q = frag - CF::F_DPA, t3 = q / CF::NKF3, f = q % CF::NKF3, k = af_kidx<T>(f, g, e, true);
+      if (k < H2) v = D[(16 * t3 + li) * H2 + k] * 0.6931471805599453f;
     } else {
-      // column 32f + 8g + e of Dp  <-  column 32f + (e < 4 ? 4g + e : 16 + 4g + e - 4) of D
-      const int j = i - CF::US - CF::DS;
-      const int r = j / H2P, k = j - r * H2P;
-      if (k < H2) {
-        const int f = k >> 5, g = (k >> 3) & 3, e = k & 7;
-        v = D[r * H2 + 32 * f + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4))];
-      }
+      const int q = frag - CF::F_DA, t4 = q / CF::NKF3, kf = q % CF::NKF3, k = af_kidx<T>(kf, g, e, false);
+      if (k < H2) v = D[(16 * t4 + li) * H2 + k];
     }
     out[i] = from_f32<T>(v);
   }
 }
 
-template <typename T, int RG>
-__device__ __forceinline__ void store_run(T* p, const float* v);
-template <>
-__device__ __forceinline__ void store_run<bf16, 4>(bf16* p, const float* v) { store4<bf16>(p, v[0], v[1], v[2], v[3]); }
-template <>
-__device__ __forceinline__ void store_run<float, 4>(float* p, const float* v) { store4<float>(p, v[0], v[1], v[2], v[3]); }
-template <>
-__device__ __forceinline__ void store_run<float, 2>(float* p, const float* v) {
-  *reinterpret_cast<f32x2*>(p) = f32x2{v[0], v[1]};
-}
-
-template <typename T, int N>
-__global__ void __launch_bounds__(af_nw(N) * 64) k_af_act_mfma(AfP<T> p) {
-  typedef AfCfg<T, N> CF;
+// k_af_act_plane: one workgroup = 4 waves, one item = one sample x 16 channels (NHWC, so the 16
+// channels of a pixel are one 32/64-byte run).  The tile is transposed into per-channel planes
+// Xs[c][w][h] in LDS (GroupNorm applied on the way); then EACH WAVE OWNS WHOLE CHANNEL PLANES and
+// carries a plane through all four passes without meeting the other waves:
+//   P1  T1^T[w][h'] = sum_h  X^T[w][h]  U[h'][h]      A = X^T rows from LDS, B = U (registers)
+//   P2  Z^T [w'][h'] = sum_w  U[w'][w]   T1^T[w][h']   A = U (chain-permuted), B = P1's accumulator
+//       SiLU on the accumulator
+//   P3  V^T [w][h']  = sum_w' D[w][w']   Z^T[w'][h']   A = D (chain-permuted), B = P2's accumulator
+//       V^T -> wave-private LDS (the only transpose: h' must become the K index)
+//   P4  Y   [h][w]   = sum_h' D[h][h']   V[h'][w]      A = D, B = V^T rows from LDS
+// (an MFMA accumulator - rows 4g+r, column = lane - is a legal B operand for the next MFMA once the
+// constant A matrix has its columns permuted to match: the 2N x 2N upsampled plane lives only in
+// registers).  Barriers per item: 3 (tile staged / all planes done / output staged) instead of 6
+// per slab; MFMA work of one wave overlaps the SiLU VALU work of another; 2 workgroups per CU.
+template <typename T, int N, int CH>
+__global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
+  typedef PlaneCfg<T, N, CH> CF;
   typedef Mma<T> MM;
   typedef typename MM::Chunk Chunk;
-  constexpr int EPC = CF::EPC, KPF = CF::KPF, H2 = CF::H2, KH = CF::KH, SL = CF::SL, WPW = CF::WPW;
-  constexpr int KHP = CF::KHP, H2P = CF::H2P, SLP = CF::SLP;
-  constexpr int NT = CF::NW * 64, RPW = CF::RPW, RG = CF::RG;
-  constexpr int NKF1 = KH / KPF;   // chunk pairs when contracting an N-long axis
-  constexpr int NKF3 = H2 / KPF;   // ... a 2N-long axis
-  constexpr int NKF4 = SL / KPF;   // ... one slab of h'
+  constexpr int EPC = CF::EPC, KPF = CF::KPF, KH = CF::KH;
+  constexpr int KHP = CF::KHP, H2P = CF::H2P, YRP = CF::YRP;
+  constexpr int NT = CF::NW * 64, TN = CF::TN, TH = CF::TH, NKF1 = CF::NKF1, NKF3 = CF::NKF3, CPW = CF::CPW;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* Us = reinterpret_cast<T*>(smem);
-  T* Ds = Us + CF::US;
-  T* Dp = CF::PERM ? Ds + CF::DS : Ds;
-  T* Xs = Us + CF::CONST_ELEMS;
-  T* T1 = Xs + CF::XS;
-  T* Vs = T1 + CF::T1S;
-  float* gsc = reinterpret_cast<float*>(Vs + CF::VS);
-  float* gsh = gsc + 16;
+  T* Cs = reinterpret_cast<T*>(smem);
+  T* Xs = Cs + CF::CONST_ELEMS;
+  T* Vt = Xs + CF::XS;
+  float* gsc = reinterpret_cast<float*>(Vt + CF::NW * CF::VT);
+  float* gsh = gsc + 16;   // (16 slots, CH used)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int Ct = p.C1 + p.C2;
-  const int ctiles = Ct / 16;
+  const int ctiles = Ct / CH;
   const int nitems = p.B * ctiles;
   const int cpg = p.stats ? Ct / p.G : 1;
+  T* Vw = Vt + wave * CF::VT;
 
-  // ---- once per (persistent) workgroup: packed constants (16-byte copies) + K padding of T1
+  // ---- once per (persistent) workgroup: constant fragments -> LDS (-> registers for bf16)
   {
     const Chunk* src = reinterpret_cast<const Chunk*>(p.packed);
-    Chunk* dst = reinterpret_cast<Chunk*>(Us);
+    Chunk* dst = reinterpret_cast<Chunk*>(Cs);
     for (int i = tid; i < CF::CONST_ELEMS / EPC; i += NT) dst[i] = src[i];
   }
-  if constexpr (KH > N) {
-    for (int i = tid; i < SL * 16 * (KH - N); i += NT) {
-      const int row = i / (KH - N), k = N + (i - row * (KH - N));
-      T1[row * KHP + k] = from_f32<T>(0.f);
-    }
+  __syncthreads();
+  Chunk creg[CF::CREG ? CF::NFRAG : 1];
+  if constexpr (CF::CREG) {
+#pragma unroll
+    for (int f = 0; f < CF::NFRAG; ++f) creg[f] = ld16<Chunk>(Cs + (f * 64 + lane) * EPC);
   }
+  auto cfrag = [&](int f) -> Chunk {
+    if constexpr (CF::CREG) return creg[f];
+    else return ld16<Chunk>(Cs + (f * 64 + lane) * EPC);
+  };
 
   // X tile staging units: unit u = (cq, w, hq) reads EPC pixels (h = hq*EPC + e) x EPC channels and
   // writes them transposed (h contiguous).  UPT units per thread live in registers so that the NEXT
   // item's tile is fetched from HBM while the current one is being computed.
-  constexpr int CQ = 16 / EPC, HQ = N / EPC, UNITS = N * CQ * HQ, UPT = (UNITS + NT - 1) / NT;
+  constexpr int CQ = CH / EPC, HQ = N / EPC, UNITS = N * CQ * HQ, UPT = (UNITS + NT - 1) / NT;
   Chunk pre[UPT][EPC];
   auto fetch = [&](int item) {
-    const int b = item / ctiles, c0 = (item - b * ctiles) * 16;
+    const int b = item / ctiles, c0 = (item - b * ctiles) * CH;
     const bool second = c0 >= p.C1;
     const T* xsrc = second ? p.x2 : p.x1;
-    const int Cs = second ? p.C2 : p.C1, cs0 = second ? c0 - p.C1 : c0;
+    const int Cs_ = second ? p.C2 : p.C1, cs0 = second ? c0 - p.C1 : c0;
 #pragma unroll
     for (int k = 0; k < UPT; ++k) {
       const int u = tid + k * NT;
@@ -187,12 +206,12 @@ __global__ void __launch_bounds__(af_nw(N) * 64) k_af_act_mfma(AfP<T> p) {
         const int cq = u % CQ, w = (u / CQ) % N, hq = u / (CQ * N);
 #pragma unroll
         for (int e = 0; e < EPC; ++e)
-          pre[k][e] = ld16<Chunk>(xsrc + ((size_t)(b * N + hq * EPC + e) * N + w) * Cs + cs0 + cq * EPC);
+          pre[k][e] = ld16<Chunk>(xsrc + ((size_t)(b * N + hq * EPC + e) * N + w) * Cs_ + cs0 + cq * EPC);
       }
     }
   };
 
-  // contiguous item range per workgroup: the 4 channel tiles that share a 128-byte line of a pixel
+  // contiguous item range per workgroup: the channel tiles that share a 128-byte line of a pixel
   // are processed back-to-back by one workgroup (and neighbouring workgroups sit on one XCD)
   const int wl = xcd_remap(blockIdx.x, gridDim.x);
   const int ipw = (nitems + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -201,33 +220,34 @@ __global__ void __launch_bounds__(af_nw(N) * 64) k_af_act_mfma(AfP<T> p) {
   if (item < item_end) fetch(item);
   for (; item < item_end; ++item) {
     const int b = item / ctiles;
-    const int c0 = (item - b * ctiles) * 16;
+    const int c0 = (item - b * ctiles) * CH;
 
     // ---- GroupNorm scale / shift of the 16 channels: the S partial sums are added by 16 x S lanes
-    if (tid < 16) {
+    if (tid < CH) {
       gsc[tid] = 1.f;
       gsh[tid] = 0.f;
     }
     if (p.stats) {
-      // thread (c = tid & 15, s = tid >> 4), s < S (S <= 32 <= NT / 16)
-      const int c = tid & 15, sidx = tid >> 4;
+      // thread (c = tid & 15, s = tid >> 4); S <= 32 > NT / 16 = 16: two partial sums per thread
+      // (CH = 8: lanes with c >= 8 read the neighbouring channels' groups and are ignored)
+      const int c = (tid & 15) < CH ? (tid & 15) : 0;
       double s1 = 0.0, s2 = 0.0;
-      if (sidx < p.S) {
+      for (int sidx = tid >> 4; sidx < p.S; sidx += NT / 16) {
         const f32x2 v = *reinterpret_cast<const f32x2*>(p.stats + (((size_t)b * p.S + sidx) * p.G + (c0 + c) / cpg) * 2);
-        s1 = (double)v[0];
-        s2 = (double)v[1];
+        s1 += (double)v[0];
+        s2 += (double)v[1];
       }
       s1 += __shfl_xor(s1, 16, 64);
       s2 += __shfl_xor(s2, 16, 64);
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
-      double* red = reinterpret_cast<double*>(Vs);  // Vs is free here (next written in P3, after 2 barriers)
+      double* red = reinterpret_cast<double*>(Vt);  // Vt is idle here (the previous item's planes are done)
       if (lane < 16) {
         red[(wave * 16 + lane) * 2 + 0] = s1;
         red[(wave * 16 + lane) * 2 + 1] = s2;
       }
       __syncthreads();
-      if (tid < 16) {
+      if (tid < CH) {
         double a1 = 0.0, a2 = 0.0;
 #pragma unroll
         for (int wv = 0; wv < CF::NW; ++wv) {
@@ -245,12 +265,12 @@ __global__ void __launch_bounds__(af_nw(N) * 64) k_af_act_mfma(AfP<T> p) {
     }
     __syncthreads();  // gsc/gsh ready; also: the previous item's output copy out of the X region is done
     if constexpr (KH > N) {  // the output staging of the previous item overwrote the X region: re-zero its K padding
-      for (int i = tid; i < N * 16 * (KH - N); i += NT) {
+      for (int i = tid; i < N * CH * (KH - N); i += NT) {
         const int row = i / (KH - N), k = N + (i - row * (KH - N));
         Xs[row * KHP + k] = from_f32<T>(0.f);
       }
     }
-    // ---- prefetched tile -> Xs[w][c][h] (h K-contiguous), GroupNorm applied
+    // ---- prefetched tile -> Xs[c][w][h] (h K-contiguous), GroupNorm applied
 #pragma unroll
     for (int k = 0; k < UPT; ++k) {
       const int u = tid + k * NT;
@@ -262,125 +282,107 @@ __global__ void __launch_bounds__(af_nw(N) * 64) k_af_act_mfma(AfP<T> p) {
           Chunk o;
 #pragma unroll
           for (int e = 0; e < EPC; ++e) o[e] = from_f32<T>(to_f32(pre[k][e][cc]) * sc + sh);
-          st16<Chunk>(Xs + ((size_t)(w * 16 + cq * EPC + cc)) * KHP + hq * EPC, o);
+          st16<Chunk>(Xs + ((size_t)((cq * EPC + cc) * N + w)) * KHP + hq * EPC, o);
         }
       }
     }
     __syncthreads();
     if (item + 1 < item_end) fetch(item + 1);  // in flight during the MFMA passes
 
-  f32x4 yacc[WPW][N / 16];
+    // ---- this wave's CPW channel planes, each carried through P1..P4 without a workgroup barrier
+    f32x4 yacc[CPW][TN][TN];
 #pragma unroll
-  for (int a = 0; a < WPW; ++a)
+    for (int pl = 0; pl < CPW; ++pl) {
+      const int c = wave * CPW + pl;
+      Chunk xa[TN][NKF1];
 #pragma unroll
-    for (int t = 0; t < N / 16; ++t) yacc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  for (int s = 0; s < CF::NSLAB; ++s) {
-    // ---- P1: T1[h'][c][w] = sum_h U[h'][h] X[h][w][c]   (this wave: its 4 columns w)
-#pragma unroll
-    for (int ti = 0; ti < SL / 16; ++ti) {
-      Chunk uf[NKF1];
-#pragma unroll
-      for (int kf = 0; kf < NKF1; ++kf) uf[kf] = ld16<Chunk>(Us + (s * SL + 16 * ti + li) * KHP + kf * KPF + lg * EPC);
-      f32x4 acc[WPW];
-#pragma unroll
-      for (int wi = 0; wi < WPW; ++wi) {
-        acc[wi] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int w = wave * WPW + wi;
+      for (int tw = 0; tw < TN; ++tw)
 #pragma unroll
         for (int kf = 0; kf < NKF1; ++kf)
-          MM::mma(acc[wi], uf[kf], ld16<Chunk>(Xs + (w * 16 + li) * KHP + kf * KPF + lg * EPC));
-      }
+          xa[tw][kf] = ld16<Chunk>(Xs + ((size_t)(c * N + 16 * tw + li)) * KHP + kf * KPF + lg * EPC);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        store4<T>(T1 + ((16 * ti + 4 * lg + r) * 16 + li) * KHP + wave * WPW, acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
-    }
-    __syncthreads();
-
-    // ---- P2 -> SiLU -> P3 for this wave's rows h' of the slab, RG rows at a time, chained in registers
+      for (int th = 0; th < TH; ++th) {
+        // P1: rows w, columns h' (tile th)
+        f32x4 a1[TN];
 #pragma unroll
-    for (int rg = 0; rg < RPW / RG; ++rg) {
-      const int hl0 = wave * RPW + rg * RG;
-      f32x4 v[RG][N / 16];
+        for (int tw = 0; tw < TN; ++tw) {
+          a1[tw] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int q = 0; q < RG; ++q) {
-        const int hl = hl0 + q;
-        Chunk tf[NKF1];
-#pragma unroll
-        for (int kf = 0; kf < NKF1; ++kf) tf[kf] = ld16<Chunk>(T1 + (hl * 16 + li) * KHP + kf * KPF + lg * EPC);
-        f32x4 z[H2 / 16];
-#pragma unroll
-        for (int t2 = 0; t2 < H2 / 16; ++t2) {
-          z[t2] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int kf = 0; kf < NKF1; ++kf)
-            MM::mma(z[t2], ld16<Chunk>(Us + (16 * t2 + li) * KHP + kf * KPF + lg * EPC), tf[kf]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) z[t2][r] = silu_f(z[t2][r]);
+          for (int kf = 0; kf < NKF1; ++kf) MM::mma(a1[tw], xa[tw][kf], cfrag(CF::F_UFB + th * NKF1 + kf));
         }
-        Chunk pb[NKF3];
+        Chunk b2[NKF1];
         if constexpr (CF::PERM) {
 #pragma unroll
-          for (int f = 0; f < NKF3; ++f) pb[f] = pack_chain<T>(z[2 * f], z[2 * f + 1]);
+          for (int f = 0; f < NKF1; ++f)
+            b2[f] = pack_chain<T>(a1[2 * f], 2 * f + 1 < TN ? a1[2 * f + 1 < TN ? 2 * f + 1 : 0] : f32x4{0.f, 0.f, 0.f, 0.f});
         } else {
 #pragma unroll
-          for (int f = 0; f < NKF3; ++f) pb[f] = z[f];
+          for (int f = 0; f < NKF1; ++f) b2[f] = a1[f];
         }
+        // P2 + SiLU: rows w' (TH tiles), columns h'
+        f32x4 z[TH];
 #pragma unroll
-        for (int t3 = 0; t3 < N / 16; ++t3) {
-          v[q][t3] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t2 = 0; t2 < TH; ++t2) {
+          z[t2] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int f = 0; f < NKF3; ++f)
-            MM::mma(v[q][t3], ld16<Chunk>(Dp + (16 * t3 + li) * H2P + f * KPF + lg * EPC), pb[f]);
+          for (int f = 0; f < NKF1; ++f) MM::mma(z[t2], cfrag(CF::F_UPA + t2 * NKF1 + f), b2[f]);
+          z[t2] = silu_log2_x4(z[t2]);
+        }
+        Chunk b3[NKF3];
+        if constexpr (CF::PERM) {
+#pragma unroll
+          for (int f = 0; f < NKF3; ++f) b3[f] = pack_chain<T>(z[2 * f], z[2 * f + 1]);
+        } else {
+#pragma unroll
+          for (int f = 0; f < NKF3; ++f) b3[f] = z[f];
+        }
+        // P3: rows w (TN tiles), columns h' -> V^T[w][h'] in this wave's LDS plane
+#pragma unroll
+        for (int t3 = 0; t3 < TN; ++t3) {
+          f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int f = 0; f < NKF3; ++f) MM::mma(v, cfrag(CF::F_DPA + t3 * NKF3 + f), b3[f]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Vw[(16 * t3 + 4 * lg + r) * H2P + 16 * th + li] = from_f32<T>(v[r]);
         }
       }
-      // V[w][c][h'] with the RG rows of this group contiguous -> one 8/16-byte LDS store each
+      // P4: rows h, columns w; B = V^T rows (this wave's own LDS writes: same-wave LDS ops are ordered)
+      Chunk vb[TN][NKF3];
 #pragma unroll
-      for (int t3 = 0; t3 < N / 16; ++t3)
+      for (int tw = 0; tw < TN; ++tw)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float run[RG];
+        for (int kf = 0; kf < NKF3; ++kf) vb[tw][kf] = ld16<Chunk>(Vw + (16 * tw + li) * H2P + kf * KPF + lg * EPC);
 #pragma unroll
-          for (int q = 0; q < RG; ++q) run[q] = v[q][t3][r];
-          store_run<T, RG>(Vs + ((16 * t3 + 4 * lg + r) * 16 + li) * SLP + hl0, run);
+      for (int t4 = 0; t4 < TN; ++t4)
+#pragma unroll
+        for (int tw = 0; tw < TN; ++tw) {
+          yacc[pl][t4][tw] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kf = 0; kf < NKF3; ++kf) MM::mma(yacc[pl][t4][tw], cfrag(CF::F_DA + t4 * NKF3 + kf), vb[tw][kf]);
         }
     }
+    __syncthreads();  // every wave has finished reading the X planes: the region becomes the output tile
+
+    // ---- output: stage the [N][N][16] tile through LDS -> coalesced 16-byte stores
+    T* Ys = Xs;
+#pragma unroll
+    for (int pl = 0; pl < CPW; ++pl)
+#pragma unroll
+      for (int t4 = 0; t4 < TN; ++t4)
+#pragma unroll
+        for (int tw = 0; tw < TN; ++tw)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            Ys[(16 * t4 + 4 * lg + r) * YRP + (16 * tw + li) * CH + wave * CPW + pl] = from_f32<T>(yacc[pl][t4][tw][r]);
     __syncthreads();
-
-    // ---- P4: Y[h][w][c] += sum_{h' in slab} D[h][h'] V[h'][w][c]
-#pragma unroll
-    for (int wi = 0; wi < WPW; ++wi) {
-      const int w = wave * WPW + wi;
-#pragma unroll
-      for (int kf = 0; kf < NKF4; ++kf) {
-        Chunk vf = ld16<Chunk>(Vs + (w * 16 + li) * SLP + kf * KPF + lg * EPC);
-#pragma unroll
-        for (int t4 = 0; t4 < N / 16; ++t4)
-          MM::mma(yacc[wi][t4], ld16<Chunk>(Ds + (16 * t4 + li) * H2P + s * SL + kf * KPF + lg * EPC), vf);
+    {
+      constexpr int CPP = CH / EPC;  // 16-byte chunks per pixel
+      for (int i = tid; i < N * N * CPP; i += NT) {
+        const int pix = i / CPP, q = i - pix * CPP;
+        const int h = pix / N, w = pix - h * N;
+        st16<Chunk>(p.y + ((size_t)b * N * N + pix) * Ct + c0 + q * EPC, ld16<Chunk>(Ys + h * YRP + w * CH + q * EPC));
       }
     }
-    // no barrier needed here (see the slab protocol in the header comment): the next slab's P1
-    // writes T1 only, and its P3 writes Vs after the next barrier.
-  }
-
-  // ---- output: stage the [N][N][16] tile through LDS (the X region is dead) -> 16-byte stores
-  T* Ys = Xs;
-#pragma unroll
-  for (int wi = 0; wi < WPW; ++wi) {
-    const int w = wave * WPW + wi;
-#pragma unroll
-    for (int t4 = 0; t4 < N / 16; ++t4)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Ys[((16 * t4 + 4 * lg + r) * N + w) * 16 + li] = from_f32<T>(yacc[wi][t4][r]);
-  }
-  __syncthreads();
-  {
-    constexpr int CPP = 16 / EPC;  // 16-byte chunks per pixel
-    for (int i = tid; i < N * N * CPP; i += NT) {
-      const int pix = i / CPP, q = i - pix * CPP;
-      st16<Chunk>(p.y + ((size_t)b * N * N + pix) * Ct + c0 + q * EPC, ld16<Chunk>(Ys + pix * 16 + q * EPC));
-    }
-  }
   }  // persistent item loop
 }
 
@@ -707,16 +709,32 @@ __global__ void __launch_bounds__(256) k_axis_contract_reg(const TI* __restrict_
 }
 
 // ----------------------------------------------------------------------------- launchers
-template <typename T, int N>
-static int launch_af_mfma(const AfP<T>& p, hipStream_t st) {
-  typedef AfCfg<T, N> CF;
+// resident (persistent) workgroups of the plane kernel per CU: LDS-bound, and at most 2 (N = 32) /
+// 4 (N = 16) four-wave workgroups by the register budget
+template <typename T, int N, int CH>
+static int af_plane_wgs_per_cu() {
+  const int by_lds = (160 * 1024) / PlaneCfg<T, N, CH>::LDS_BYTES;
+  const int by_regs = N == 32 ? 2 : 4;
+  return by_lds < 1 ? 1 : (by_lds < by_regs ? by_lds : by_regs);
+}
+template <typename T, int N, int CH>
+static int launch_af_plane(const AfP<T>& p, int cus, hipStream_t st) {
+  typedef PlaneCfg<T, N, CH> CF;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_af_act_mfma<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)k_af_act_plane<T, N, CH>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               CF::LDS_BYTES);
     attr_set = true;
   }
-  const int nitems = p.B * ((p.C1 + p.C2) / 16);
+  const int nitems = p.B * ((p.C1 + p.C2) / CH);
+  int grid = cus * af_plane_wgs_per_cu<T, N, CH>();
+  if (grid > nitems) grid = nitems;
+  k_af_act_plane<T, N, CH><<<grid, CF::NW * 64, CF::LDS_BYTES, st>>>(p);
+  return check_launch("afldm_af_act(plane)");
+}
+
+template <typename T, int N>
+static int launch_af_mfma(const AfP<T>& p, hipStream_t st) {
   static int cus = 0;
   if (!cus) {
     hipDeviceProp_t prop;
@@ -724,11 +742,14 @@ static int launch_af_mfma(const AfP<T>& p, hipStream_t st) {
     (void)hipGetDevice(&dev);
     cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
   }
-  const int per_cu = (160 * 1024) / CF::LDS_BYTES > 0 ? (160 * 1024) / CF::LDS_BYTES : 1;   // persistent workgroups per CU
-  int grid = cus * (per_cu > 2 ? 2 : per_cu);
-  if (grid > nitems) grid = nitems;
-  k_af_act_mfma<T, N><<<grid, CF::NW * 64, CF::LDS_BYTES, st>>>(p);
-  return check_launch("afldm_af_act(mfma)");
+  // Items are indivisible, so a launch takes ceil(items / resident workgroups) item times: pick the
+  // item size (16 or 8 channels) with the smaller makespan (an 8-channel item measured 0.62-0.82 of a 16-channel one).
+  const int Ct = p.C1 + p.C2;
+  const long long slots16 = (long long)cus * af_plane_wgs_per_cu<T, N, 16>(), slots8 = (long long)cus * af_plane_wgs_per_cu<T, N, 8>();
+  const long long items16 = (long long)p.B * (Ct / 16), items8 = 2 * items16;
+  const double t16 = (double)((items16 + slots16 - 1) / slots16), t8 = 0.65 * (double)((items8 + slots8 - 1) / slots8);
+  if (t8 < t16 && p.C1 % 8 == 0) return launch_af_plane<T, N, 8>(p, cus, st);
+  return launch_af_plane<T, N, 16>(p, cus, st);
 }
 template <typename T, int N>
 static int launch_af_kron(const AfP<T>& p, hipStream_t st) {
@@ -836,8 +857,8 @@ extern "C" int afldm_af_act(const void* x1, int C1, const void* x2, int C2, cons
 extern "C" size_t afldm_af_pack_bytes(int N, int dtype) {
   if (N == 4) return dtype == AFLDM_F32 ? KronCfg<float, 4>::CONST_ELEMS * 4 : KronCfg<bf16, 4>::CONST_ELEMS * 2;
   if (N == 8) return dtype == AFLDM_F32 ? KronCfg<float, 8>::CONST_ELEMS * 4 : KronCfg<bf16, 8>::CONST_ELEMS * 2;
-  if (N == 16) return dtype == AFLDM_F32 ? AfCfg<float, 16>::CONST_ELEMS * 4 : AfCfg<bf16, 16>::CONST_ELEMS * 2;
-  if (N == 32) return dtype == AFLDM_F32 ? AfCfg<float, 32>::CONST_ELEMS * 4 : AfCfg<bf16, 32>::CONST_ELEMS * 2;
+  if (N == 16) return dtype == AFLDM_F32 ? PlaneCfg<float, 16>::CONST_ELEMS * 4 : PlaneCfg<bf16, 16>::CONST_ELEMS * 2;
+  if (N == 32) return dtype == AFLDM_F32 ? PlaneCfg<float, 32>::CONST_ELEMS * 4 : PlaneCfg<bf16, 32>::CONST_ELEMS * 2;
   return 0;
 }
 
