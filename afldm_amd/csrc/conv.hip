@@ -41,6 +41,7 @@ struct ConvP {
   int tiles_n;
   int vec_ok;   // leading dims allow 4-element vector epilogue accesses
   int tap_inner;  // K order of the LDS-DMA kernel (see k_igemm2)
+  int stage_ok;   // leading dimensions / splits allow the LDS-staged 16-byte epilogue
   int dbg;      // AFLDM_CONV_DBG (timing decomposition only): bit 0 skip the LDS-DMA, bit 1 skip the MFMA phase
 };
 
@@ -282,8 +283,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 // 64-byte pieces the DMA stream ALONE took 93 % of the kernel time at ~13 TB/s of requested bytes
 // (each line requested twice, by the kc = 0 and kc = 1 instructions).  Row r keeps source chunk c
 // at position c ^ ((r >> 1) & 7): conflict-free for the 16-lane groups of ds_read_b128.
-template <typename T, int BM, int BN, int WGM, int WGN, int KCH, int STAGES, int NPROD = 0, bool R128 = false>
-__global__ void __launch_bounds__((WGM * WGN + NPROD) * 64) k_igemm2(ConvP p) {
+// MINW: waves per SIMD the register allocator must leave room for (the 128x192 tile needs 151 + 96
+// registers in its main loop = 2 waves per SIMD = 2 workgroups per CU; left alone the allocator
+// spends 30 more on the epilogue and halves the occupancy).
+template <typename T, int BM, int BN, int WGM, int WGN, int KCH, int STAGES, int NPROD = 0, bool R128 = false, int MINW = 1>
+__global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP p) {
   typedef Mma<T> MM;
   typedef typename MM::Chunk Chunk;
   static_assert(!R128 || KCH == 2, "128-byte rows hold exactly two MFMA K chunks");
@@ -526,20 +530,142 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64) k_igemm2(ConvP p) {
     wait_vmcnt<0>();  // drain the zero-fill tail before the workgroup's LDS can be re-assigned
   }
 
+  // ---- LDS-staged epilogue.  An accumulator lane holds 4 consecutive couts of ONE pixel, so direct
+  // stores are 8-byte pieces of 16 different rows per instruction (and 2-byte scatters for the
+  // channel-major V^T output): the short-K 1x1 GEMMs (q/k/v, to_out at 32x32) ran at ~1.5 TB/s of
+  // output.  Instead the fp32 tile goes through the (now idle) pipeline buffers and leaves as full
+  // rows: 16 B per lane, bias / temb / residual added in fp32 on the way (same order as
+  // epilogue_store, so the result is bit-identical to the direct and split-K paths).
+  {
+    constexpr int SROW = BN + 8;                         // fp32 row stride: 8 mod 64 banks -> conflict-free 16-byte writes
+    constexpr int LDS_TOTAL = STAGES * STAGE;
+    constexpr int TMP = (WGM * TM * 16 * SROW * 4 <= LDS_TOTAL) ? TM
+                      : (WGM * (TM / 2) * 16 * SROW * 4 <= LDS_TOTAL && TM % 2 == 0) ? TM / 2
+                      : (WGM * (TM / 4) * 16 * SROW * 4 <= LDS_TOTAL && TM % 4 == 0) ? TM / 4 : 0;
+    static_assert(TMP > 0, "staging tile does not fit the pipeline buffers");
+    constexpr int PASSES = TM / TMP, PROWS = WGM * TMP * 16;   // rows staged per pass
+    constexpr int NTC = NWC * 64;                        // threads in the epilogue (producer waves have exited)
+    constexpr int EO = 16 / ESZ;                         // output elements per 16-byte store
+    float* sC = reinterpret_cast<float*>(smem);
+    const T* temb = (const T*)p.temb;
+    const T* res = (const T*)p.residual;
+    const int etid = cw * 64 + lane;
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
+    for (int ps = 0; ps < PASSES; ++ps) {
+      __syncthreads();   // pipeline buffers idle (first pass) / previous pass copied out
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      const int m = m0 + wm * WMS + tm * 16 + li;
-      const int n = n0 + wn * WNS + tn * 16 + 4 * lg;
-      if (m >= p.M || n >= p.Cout) continue;
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int t = 0; t < TMP; ++t) {
+          const int row = (wm * TMP + t) * 16 + li;      // staged row  <->  tile row wm*WMS + (ps*TMP + t)*16 + li
+          *reinterpret_cast<f32x4*>(sC + row * SROW + wn * WNS + tn * 16 + 4 * lg) = acc[tn][ps * TMP + t];
+          __builtin_amdgcn_sched_barrier(0);   // one tile at a time: keeps the accumulator -> VGPR copies from piling up
+        }
+      __syncthreads();
       if (p.splitk > 1) {
-        float* dst = p.ws + ((size_t)ks * p.M + m) * p.Cout + n;
-        if (n + 3 < p.Cout) *reinterpret_cast<f32x4*>(dst) = acc[tn][tm];
-        else
-          for (int r = 0; r < 4 && n + r < p.Cout; ++r) dst[r] = acc[tn][tm][r];
-      } else {
-        epilogue_store<T>(p, m, n, acc[tn][tm]);
+        // split-K slab: fp32 rows, 16 bytes per lane
+        constexpr int QPR = BN / 4;
+        const bool v4 = (p.Cout & 3) == 0;
+#pragma unroll 1
+        for (int i = etid; i < PROWS * QPR; i += NTC) {
+          const int row = i / QPR, q = i - row * QPR;
+          const int n = n0 + 4 * q;
+          const int mt = row / (TMP * 16), rr = row - mt * (TMP * 16);
+          const int m = m0 + mt * WMS + ps * TMP * 16 + rr;
+          if (m >= p.M || n >= p.Cout) continue;
+          const f32x4 a = *reinterpret_cast<const f32x4*>(sC + row * SROW + 4 * q);
+          float* dst = p.ws + ((size_t)ks * p.M + m) * p.Cout + n;
+          if (v4 && n + 3 < p.Cout) *reinterpret_cast<f32x4*>(dst) = a;
+          else
+            for (int r = 0; r < 4 && n + r < p.Cout; ++r) dst[r] = a[r];
+        }
+        continue;
+      }
+      // (a) NHWC part: couts [n0, min(n0 + BN, nhwc_end)), 16 bytes of one pixel per lane
+      const int nhwc_end = p.out_mode == 1 ? 0 : (p.y2 ? p.split_n : p.Cout);
+      constexpr int CPR = BN / EO;                       // 16-byte chunks per staged row
+#pragma unroll 1
+      for (int i = etid; i < PROWS * CPR; i += NTC) {
+        const int row = i / CPR, ch = i - row * CPR;
+        const int n = n0 + ch * EO;
+        const int mt = row / (TMP * 16), rr = row - mt * (TMP * 16);
+        const int m = m0 + mt * WMS + ps * TMP * 16 + rr;
+        if (m >= p.M || n >= nhwc_end) continue;
+        float v[EO];
+#pragma unroll
+        for (int q = 0; q < EO / 4; ++q) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(sC + row * SROW + ch * EO + 4 * q);
+          v[4 * q] = a[0]; v[4 * q + 1] = a[1]; v[4 * q + 2] = a[2]; v[4 * q + 3] = a[3];
+        }
+        const int b = m / HW;
+        if (p.stage_ok && n + EO <= nhwc_end) {
+          if (p.bias) {
+#pragma unroll
+            for (int q = 0; q < EO / 4; ++q) {
+              const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n + 4 * q);
+              v[4 * q] += bv[0]; v[4 * q + 1] += bv[1]; v[4 * q + 2] += bv[2]; v[4 * q + 3] += bv[3];
+            }
+          }
+          if (temb) {
+            const Chunk tv = ld16<Chunk>(temb + (size_t)b * p.temb_stride + n);
+#pragma unroll
+            for (int e = 0; e < EO; ++e) v[e] += to_f32(tv[e]);
+          }
+          if (res) {
+            const Chunk rv = ld16<Chunk>(res + (size_t)m * p.res_ld + n);
+#pragma unroll
+            for (int e = 0; e < EO; ++e) v[e] += to_f32(rv[e]);
+          }
+          Chunk o;
+#pragma unroll
+          for (int e = 0; e < EO; ++e) o[e] = from_f32<T>(v[e]);
+          st16<Chunk>((T*)p.y + (size_t)m * p.y_ld + n, o);
+        } else {   // ragged cout tail
+          for (int e = 0; e < EO && n + e < nhwc_end; ++e) {
+            float sv = v[e];
+            if (p.bias) sv += p.bias[n + e];
+            if (temb) sv += to_f32(temb[(size_t)b * p.temb_stride + n + e]);
+            if (res) sv += to_f32(res[(size_t)m * p.res_ld + n + e]);
+            ((T*)p.y)[(size_t)m * p.y_ld + n + e] = from_f32<T>(sv);
+          }
+        }
+      }
+      // (b) channel-major part (out_mode 1, or the V^T third of a fused QKV GEMM): EO consecutive
+      // pixels of one cout per lane; lanes = 16 couts x 4 pixel groups (64-byte runs per cout row)
+      const int cm_beg = p.out_mode == 1 ? 0 : (p.y2 ? p.split_n : p.Cout);
+      if (n0 + BN > cm_beg && cm_beg < p.Cout) {
+        T* yc = p.out_mode == 1 ? (T*)p.y : (T*)p.y2;
+        const int cch = p.Cout - cm_beg;                 // channels of the channel-major tensor
+        constexpr int RG = PROWS / EO;                   // pixel groups per pass
+#pragma unroll 1
+        for (int i = etid; i < BN * RG; i += NTC) {
+          const int nl = (i & 15) + 16 * (i / (16 * RG)), g = (i >> 4) % RG;
+          const int n = n0 + nl;
+          if (n < cm_beg || n >= p.Cout) continue;
+          const int row0 = g * EO;
+          const int mt = row0 / (TMP * 16), rr = row0 - mt * (TMP * 16);
+          const int m = m0 + mt * WMS + ps * TMP * 16 + rr;
+          if (m >= p.M) continue;
+          const int b = m / HW, pix = m - b * HW;
+          const float bsv = p.bias ? p.bias[n] : 0.f;
+          const float tsv = temb ? to_f32(temb[(size_t)b * p.temb_stride + n]) : 0.f;
+          Chunk o;
+#pragma unroll
+          for (int e = 0; e < EO; ++e) {
+            float sv = sC[(row0 + e) * SROW + nl] + bsv;
+            if (temb && m + e < p.M) sv += p.stage_ok ? tsv : to_f32(temb[(size_t)((m + e) / HW) * p.temb_stride + n]);
+            if (res && m + e < p.M) sv += to_f32(res[(size_t)(m + e) * p.res_ld + n]);
+            o[e] = from_f32<T>(sv);
+          }
+          if (p.stage_ok && m + EO <= p.M) {
+            st16<Chunk>(yc + ((size_t)b * cch + (n - cm_beg)) * HW + pix, o);
+          } else {
+            for (int e = 0; e < EO && m + e < p.M; ++e) {   // (odd H*W: the run may cross into the next sample)
+              const int me = m + e, be = me / HW;
+              yc[((size_t)be * cch + (n - cm_beg)) * HW + (me - be * HW)] = o[e];
+            }
+          }
+        }
       }
     }
   }
@@ -793,11 +919,11 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
     if (sk > 4) sk = 4;
     if (sk < 1) sk = 1;
   } else if (tiles < 256) {   // measured: ~320 workgroups is the sweet spot (conv_variant_sweep2/4.log)
-    sk = (int)((320 + tiles - 1) / tiles);
+    const int cap = ksteps >= 192 ? 8 : 4;      // very long K (L4 / L2 concat convs): 8 slices measured +10 %
+    sk = (int)(((cap == 8 ? 768 : 320) + tiles - 1) / tiles);
     int maxsk = ksteps / 4;
     if (maxsk < 1) maxsk = 1;
     if (sk > maxsk) sk = maxsk;
-    const int cap = ksteps >= 192 ? 8 : 4;      // very long K (L4 concat convs): 8 slices measured +12 %
     if (sk > cap) sk = cap;
     if (sk < 1) sk = 1;
   }
@@ -823,7 +949,7 @@ static void launch_igemm(const ConvP& p0, hipStream_t st) {
   k_igemm<T, BM, BN, WGM, WGN, KCH><<<grid, WGM * WGN * 64, lds, st>>>(p);
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int KCH = KCH_DEFAULT, int NPROD = 0, bool R128 = false>
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, int KCH = KCH_DEFAULT, int NPROD = 0, bool R128 = false, int MINW = 1>
 static void launch_igemm2(const ConvP& p0, hipStream_t st) {
   ConvP p = p0;
   p.ksteps = p0.ksteps * KCH_DEFAULT / KCH;     // p0.ksteps counts KCH_DEFAULT-wide steps
@@ -833,11 +959,11 @@ static void launch_igemm2(const ConvP& p0, hipStream_t st) {
   constexpr int lds = STAGES * KCH * (BM + BN) * 64;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_igemm2<T, BM, BN, WGM, WGN, KCH, STAGES, NPROD, R128>,
+    (void)hipFuncSetAttribute((const void*)k_igemm2<T, BM, BN, WGM, WGN, KCH, STAGES, NPROD, R128, MINW>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  k_igemm2<T, BM, BN, WGM, WGN, KCH, STAGES, NPROD, R128><<<grid, (WGM * WGN + NPROD) * 64, lds, st>>>(p);
+  k_igemm2<T, BM, BN, WGM, WGN, KCH, STAGES, NPROD, R128, MINW><<<grid, (WGM * WGN + NPROD) * 64, lds, st>>>(p);
 }
 
 
@@ -856,7 +982,7 @@ static bool launch_variant(int id, const ConvP& p, hipStream_t st) {
     case 9: launch_igemm2<T, 64, 128, 2, 2, 3>(p, st); return true;
     case 10: launch_igemm2<T, 64, 128, 2, 2, 4>(p, st); return true;
     case 11: launch_igemm2<T, 64, 64, 2, 2, 4>(p, st); return true;
-    case 12: launch_igemm2<T, 128, 192, 2, 2, 2>(p, st); return true;
+    case 12: launch_igemm2<T, 128, 192, 2, 2, 2, KCH_DEFAULT, 0, false, 2>(p, st); return true;
     case 13: launch_igemm2<T, 256, 64, 4, 1, 2>(p, st); return true;
     case 14: launch_igemm2<T, 256, 64, 4, 1, 3>(p, st); return true;
     case 15: launch_igemm2<T, 64, 64, 2, 2, 6>(p, st); return true;
@@ -873,9 +999,9 @@ static bool launch_variant(int id, const ConvP& p, hipStream_t st) {
     case 26: launch_igemm2<T, 256, 192, 4, 2, 2, 2, 4>(p, st); return true;
     case 27: launch_igemm2<T, 256, 128, 4, 2, 2, 2, 4>(p, st); return true;
     case 28: launch_igemm2<T, 128, 64, 2, 2, 3, 2, 2>(p, st); return true;
-    case 29: launch_igemm2<T, 128, 192, 2, 2, 2, 2, 0, true>(p, st); return true;
-    case 30: launch_igemm2<T, 128, 128, 2, 2, 2, 2, 0, true>(p, st); return true;
-    case 31: launch_igemm2<T, 128, 64, 2, 2, 2, 2, 0, true>(p, st); return true;
+    case 29: launch_igemm2<T, 128, 192, 2, 2, 2, 2, 0, true, 2>(p, st); return true;
+    case 30: launch_igemm2<T, 128, 128, 2, 2, 2, 2, 0, true, 2>(p, st); return true;
+    case 31: launch_igemm2<T, 128, 64, 2, 2, 2, 2, 0, true, 3>(p, st); return true;
     case 32: launch_igemm2<T, 64, 64, 2, 2, 4, 2, 0, true>(p, st); return true;
     case 33: launch_igemm2<T, 128, 192, 2, 2, 3, 2, 4, true>(p, st); return true;
     case 34: launch_igemm2<T, 128, 128, 2, 2, 2, 2, 4, true>(p, st); return true;
@@ -901,6 +1027,18 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
   p.tap_inner = s_tapin;
   p.vec_ok = ((a->out_mode == 1 || a->y_ld % 4 == 0) && (!a->residual || a->res_ld % 4 == 0) &&
               (!a->temb || a->temb_stride % 4 == 0)) ? 1 : 0;
+  {
+    // 16-byte epilogue accesses: every leading dimension a multiple of the 16-byte element count,
+    // channel-major outputs need whole 16-byte pixel runs inside one sample
+    const int eo = 16 / (int)sizeof(T);
+    const int hw = a->H * a->W;
+    const bool cm = a->out_mode == 1 || a->y2;
+    p.stage_ok = ((a->out_mode == 1 || a->y_ld % eo == 0) && (!a->residual || a->res_ld % eo == 0) &&
+                  (!a->temb || a->temb_stride % eo == 0) && (!cm || hw % eo == 0) && (!a->y2 || a->split_n % eo == 0) &&
+                  !(cm && a->residual)) ? 1 : 0;
+    static const int s_nostage = getenv("AFLDM_CONV_NOSTAGE") ? atoi(getenv("AFLDM_CONV_NOSTAGE")) : 0;
+    if (s_nostage) p.stage_ok = 0;
+  }
   Plan pl = make_plan(a, epr<T>());
   if (pl.kind == 1 && a->C1 == 4 && a->C2 == 0 && a->KS == 3 && a->Cout % 16 == 0 && a->Cout * 36 * 4 <= 64 * 1024 &&
       !a->temb && !a->residual && a->out_mode == 0 && a->y_ld % 4 == 0) {
