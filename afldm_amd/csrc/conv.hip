@@ -41,6 +41,7 @@ struct ConvP {
   int tiles_n;
   int vec_ok;   // leading dims allow 4-element vector epilogue accesses
   int tap_inner;  // K order of the LDS-DMA kernel (see k_igemm2)
+  int m_fast;     // tile order of the LDS-DMA kernel: 1 = tile_m fastest (weights outweigh pixels)
   int stage_ok;   // leading dimensions / splits allow the LDS-staged 16-byte epilogue
   int dbg;      // AFLDM_CONV_DBG (timing decomposition only): bit 0 skip the LDS-DMA, bit 1 skip the MFMA phase
 };
@@ -316,7 +317,13 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
   const int li = lane & 15, lg = lane >> 4;
 
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
+  // tile order: consecutive tiles run on one XCD (xcd_remap) and should share their LARGER operand
+  // there: the pixel rows when X outweighs W (n fastest), the weight slice when W outweighs X (the
+  // 4x4 / 2x2 levels: 10-21 MB of weights against 1-3 MB of pixels; m fastest).  With n fastest at
+  // those levels every XCD's L2 fetched the whole weight tensor (PMC: 3.3x the algorithmic bytes).
+  const int tiles_m_ = (p.M + BM - 1) / BM;
+  const int tile_m = p.m_fast ? tile % tiles_m_ : tile / p.tiles_n;
+  const int tile_n = p.m_fast ? tile / tiles_m_ : tile % p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int Ct = p.C1 + p.C2;
   const int cblocks = Ct / KSTEP;
@@ -900,7 +907,7 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
   const long long tiles64 = ((M + 63) / 64) * ((a->Cout + 63) / 64);
   if (M <= 4096 && ((ksteps_all <= 64 && tiles64 >= 256) || (ksteps_all <= 16 && tiles64 >= 128))) { vid = 32; bm = 64; bn = 64; }
   else if (M >= 32768 && a->Cout % 192 == 0) { vid = 29; bm = 128; bn = 192; }
-  else if (M >= 4096 && a->Cout % 192 == 0 && ksteps_all >= 27) { vid = 33; bm = 128; bn = 192; }
+  else if (a->Cout % 192 == 0 && ((M >= 4096 && ksteps_all >= 27) || (M >= 1024 && ksteps_all >= 100))) { vid = 33; bm = 128; bn = 192; }
   else if (M >= 4096 && a->Cout % 128 == 0 && a->KS > 1) { vid = 30; bm = 128; bn = 128; }
   else if (M >= 1024) { vid = 31; bm = 128; bn = 64; }
   else { vid = 32; bm = 64; bn = 64; }
@@ -916,9 +923,9 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
     sk = (int)((256 + tiles / 2) / tiles);
     int maxsk = ksteps / 8;
     if (sk > maxsk) sk = maxsk;
-    if (sk > 4) sk = 4;
+    if (sk > 8) sk = 8;
     if (sk < 1) sk = 1;
-  } else if (tiles < 256) {   // measured: ~320 workgroups is the sweet spot (conv_variant_sweep2/4.log)
+  } else if (tiles < 256 && ksteps > 16) {   // (short K: a split only adds the reduction pass)   // measured: ~320 workgroups is the sweet spot (conv_variant_sweep2/4.log)
     const int cap = ksteps >= 192 ? 8 : 4;      // very long K (L4 / L2 concat convs): 8 slices measured +10 %
     sk = (int)(((cap == 8 ? 768 : 320) + tiles - 1) / tiles);
     int maxsk = ksteps / 4;
@@ -1038,6 +1045,10 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
                   !(cm && a->residual)) ? 1 : 0;
     static const int s_nostage = getenv("AFLDM_CONV_NOSTAGE") ? atoi(getenv("AFLDM_CONV_NOSTAGE")) : 0;
     if (s_nostage) p.stage_ok = 0;
+  }
+  {
+    static const int s_mfast = getenv("AFLDM_CONV_MFAST") ? atoi(getenv("AFLDM_CONV_MFAST")) : -1;
+    p.m_fast = s_mfast >= 0 ? s_mfast : ((long long)a->Cout * a->KS * a->KS > (long long)p.M ? 1 : 0);
   }
   Plan pl = make_plan(a, epr<T>());
   if (pl.kind == 1 && a->C1 == 4 && a->C2 == 0 && a->KS == 3 && a->Cout % 16 == 0 && a->Cout * 36 * 4 <= 64 * 1024 &&

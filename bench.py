@@ -62,15 +62,25 @@ def roofline_pass(unet, batch, dtype):
                       gbs=round(d["bytes"] / d["ms"] / 1e6, 1) if d["ms"] > 0 else 0.0)
     dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
     name, d = dom
+    # HBM bytes per launch of the dominant family from the PMC counters (FETCH_SIZE / WRITE_SIZE in
+    # separate rocprofv3 passes, gfx950 x2 read correction): collected offline by
+    # profiles/run_pmc_conv3x3.sh (a PMC pass cannot run inside the timed process) and committed.
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "conv3x3_traffic.json")))
+        if tj.get("family") == name and batch == 64 and dtype == torch.bfloat16:
+            traffic = round(tj["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        traffic = None
     mfma_bound = name.startswith("conv") or name == "linear" or name == "attention" or name.startswith("af_act_N3") \
         or name.startswith("af_act_N16")
     if mfma_bound:
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
         achieved = d["flops"] / d["ms"] / 1e9
         roof = dict(kernel=name, bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
-                    frac=round(achieved / peak, 4), traffic=None,
+                    frac=round(achieved / peak, 4), traffic=traffic,
                     launches_per_step=d["launches"] // 3, avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
-                    flops_per_launch=d["flops"] / d["launches"])
+                    flops_per_launch=d["flops"] / d["launches"], algorithmic_bytes_per_launch=round(d["bytes"] / d["launches"]))
     else:
         achieved = d["bytes"] / d["ms"] / 1e6
         roof = dict(kernel=name, bound="hbm", achieved=round(achieved, 1), peak=PEAK_HBM_GBS, unit="GB/s",
