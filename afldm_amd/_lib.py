@@ -22,6 +22,7 @@ class ConvArgs(Structure):
         ("C1", c_int), ("C2", c_int), ("B", c_int), ("H", c_int), ("W", c_int), ("Cout", c_int),
         ("KS", c_int), ("temb_stride", c_int), ("res_ld", c_int), ("y_ld", c_int),
         ("out_mode", c_int), ("dtype", c_int), ("y2", c_void_p), ("split_n", c_int),
+        ("stats_out", c_void_p),
     ]
 
 
@@ -55,19 +56,20 @@ def _load():
         "afldm_timestep_embedding": ([vp, vp, ip, ip, ip, fp, ip, vp], c_int),
         "afldm_silu": ([vp, vp, c_size_t, ip, vp], c_int),
         "afldm_gn_stats_splits": ([ip], c_int),
-        "afldm_gn_stats": ([vp, ip, vp, ip, vp, ip, ip, ip, ip, vp], c_int),
-        "afldm_gn_apply": ([vp, ip, vp, ip, vp, vp, vp, vp, ip, ip, ip, fp, ip, ip, vp], c_int),
-        "afldm_af_act": ([vp, ip, vp, ip, vp, vp, vp, ip, fp, vp, vp, vp, vp, ip, ip, ip, vp], c_int),
+        "afldm_gn_stats": ([vp, ip, vp, ip, ip, ip, vp], c_int),
+        "afldm_gn_apply": ([vp, ip, vp, ip, vp, ip, vp, ip, vp, vp, vp, ip, ip, ip, fp, ip, ip, vp], c_int),
+        "afldm_af_act": ([vp, ip, vp, ip, vp, ip, vp, ip, vp, vp, ip, fp, vp, vp, vp, vp, ip, ip, ip, vp], c_int),
         "afldm_af_pack_bytes": ([ip, ip], c_size_t),
         "afldm_af_pack": ([vp, vp, ip, ip, vp, vp], c_int),
         "afldm_af_up2": ([vp, vp, vp, vp, ip, ip, ip, ip, vp], c_int),
         "afldm_af_lpf_down2": ([vp, vp, vp, vp, ip, ip, ip, ip, vp], c_int),
         "afldm_af_resample": ([vp, vp, vp, vp, ip, ip, ip, ip, ip, vp], c_int),
         "afldm_sep_pass": ([POINTER(SepArgs), vp], c_int),
-        "afldm_gn_table": ([vp, vp, vp, vp, ip, ip, ip, ip, fp, vp], c_int),
+        "afldm_gn_table": ([vp, ip, vp, vp, vp, ip, ip, ip, ip, fp, vp], c_int),
         "afldm_softmax_rows": ([vp, vp, ctypes.c_longlong, ip, fp, ip, vp], c_int),
         "afldm_conv2d": ([POINTER(ConvArgs), vp], c_int),
         "afldm_conv2d_workspace": ([POINTER(ConvArgs)], c_size_t),
+        "afldm_conv2d_stats_splits": ([POINTER(ConvArgs)], c_int),
         "afldm_conv2d_tune": ([ip, ip], c_int),
         "afldm_attention": ([vp, ip, vp, ip, vp, vp, ip, ip, ip, ip, ip, ip, ip, fp, ip, vp], c_int),
         "afldm_ddim_step": ([vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, vp], c_int),

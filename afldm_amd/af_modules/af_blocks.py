@@ -45,7 +45,8 @@ class AliasFreeUpsample2D(Upsample2D):
         if self.interpolate:
             hidden_states = ops.af_up2(hidden_states)            # filters stay fp32-accumulated in any dtype
         if self.use_conv:
-            hidden_states = conv_forward(self.conv if self.name == "conv" else self.Conv2d_0, hidden_states)
+            hidden_states = conv_forward(self.conv if self.name == "conv" else self.Conv2d_0, hidden_states,
+                                         want_stats=True)
         return hidden_states
 
 

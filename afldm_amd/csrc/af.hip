@@ -23,7 +23,7 @@ template <typename T>
 struct AfP {
   const T* x1;
   const T* x2;
-  const float* stats;
+  GnStats gs;          // per-channel GroupNorm partial sums (gs.st1 == nullptr: no normalisation)
   const float* gamma;
   const float* beta;
   const float* U;  // [2N][N]   (small-plane kernel)
@@ -31,7 +31,6 @@ struct AfP {
   const void* packed;  // LDS image of the matrices for the MFMA kernel (afldm_af_pack)
   T* y;
   int C1, C2, G, B;
-  int S;      // GroupNorm partial-sum splits (gn_splits(N*N))
   float eps;
 };
 
@@ -169,7 +168,7 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
   const int Ct = p.C1 + p.C2;
   const int ctiles = Ct / CH;
   const int nitems = p.B * ctiles;
-  const int cpg = p.stats ? Ct / p.G : 1;
+  const int cpg = p.gs.st1 ? Ct / p.G : 1;
   T* Vw = Vt + wave * CF::VT;
 
   // ---- once per (persistent) workgroup: constant fragments -> LDS (-> registers for bf16)
@@ -227,40 +226,27 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
       gsc[tid] = 1.f;
       gsh[tid] = 0.f;
     }
-    if (p.stats) {
-      // thread (c = tid & 15, s = tid >> 4); S <= 32 > NT / 16 = 16: two partial sums per thread
-      // (CH = 8: lanes with c >= 8 read the neighbouring channels' groups and are ignored)
-      const int c = (tid & 15) < CH ? (tid & 15) : 0;
-      double s1 = 0.0, s2 = 0.0;
-      for (int sidx = tid >> 4; sidx < p.S; sidx += NT / 16) {
-        const f32x2 v = *reinterpret_cast<const f32x2*>(p.stats + (((size_t)b * p.S + sidx) * p.G + (c0 + c) / cpg) * 2);
-        s1 += (double)v[0];
-        s2 += (double)v[1];
-      }
-      s1 += __shfl_xor(s1, 16, 64);
-      s2 += __shfl_xor(s2, 16, 64);
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      double* red = reinterpret_cast<double*>(Vt);  // Vt is idle here (the previous item's planes are done)
-      if (lane < 16) {
-        red[(wave * 16 + lane) * 2 + 0] = s1;
-        red[(wave * 16 + lane) * 2 + 1] = s2;
+    if (p.gs.st1) {
+      // one wave per group touched by the item's channels (usually 2-4): cpg x S partials strided
+      // over its lanes; the per-channel scale / shift follow from the group results in LDS
+      const int g_first = c0 / cpg, g_last = (c0 + CH - 1) / cpg;
+      float* gms = reinterpret_cast<float*>(Vt);  // Vt is idle here (the previous item's planes are done)
+      for (int g = g_first + wave; g <= g_last; g += CF::NW) {
+        double s1, s2;
+        gn_group_sums_wave(p.gs, b, g, cpg, lane, s1, s2);
+        if (lane == 0) {
+          float mean, rstd;
+          gn_mean_rstd(s1, s2, (double)N * N * cpg, p.eps, mean, rstd);
+          gms[2 * (g - g_first)] = mean;
+          gms[2 * (g - g_first) + 1] = rstd;
+        }
       }
       __syncthreads();
       if (tid < CH) {
-        double a1 = 0.0, a2 = 0.0;
-#pragma unroll
-        for (int wv = 0; wv < CF::NW; ++wv) {
-          a1 += red[(wv * 16 + tid) * 2 + 0];
-          a2 += red[(wv * 16 + tid) * 2 + 1];
-        }
-        const double inv_n = 1.0 / ((double)N * N * cpg);
-        const double m = a1 * inv_n;
-        const float var = fmaxf((float)(a2 * inv_n - m * m), 0.f);
-        const float rstd = rsqrtf(var + p.eps);
-        const float sc = rstd * p.gamma[c0 + tid];
+        const int gl = (c0 + tid) / cpg - g_first;
+        const float sc = gms[2 * gl + 1] * p.gamma[c0 + tid];
         gsc[tid] = sc;
-        gsh[tid] = p.beta[c0 + tid] - (float)m * sc;
+        gsh[tid] = p.beta[c0 + tid] - gms[2 * gl] * sc;
       }
     }
     __syncthreads();  // gsc/gsh ready; also: the previous item's output copy out of the X region is done
@@ -453,7 +439,7 @@ __global__ void __launch_bounds__(256) k_af_act_kron(AfP<T> p) {
   T* Xk = KD + CF::KD_ELEMS + wave * CF::XK;   // this wave's [16 c][PK] tile
   const int li = lane & 15, lg = lane >> 4;
   const int Ct = p.C1 + p.C2, ctiles = Ct / 16, nitems = p.B * ctiles;
-  const int cpg = p.stats ? Ct / p.G : 1;
+  const int cpg = p.gs.st1 ? Ct / p.G : 1;
 
   {
     const Chunk* src = reinterpret_cast<const Chunk*>(p.packed);
@@ -478,24 +464,13 @@ __global__ void __launch_bounds__(256) k_af_act_kron(AfP<T> p) {
     const T* xsrc = second ? p.x2 : p.x1;
     const int Cs = second ? p.C2 : p.C1, cs0 = second ? c0 - p.C1 : c0;
 
-    // ---- GroupNorm scale/shift of channel c0 + li: lane group lg adds split lg (S <= 4 here)
+    // ---- GroupNorm scale/shift of channel c0 + li: lane group lg adds every 4th channel of its group
     float sc = 1.f, sh = 0.f;
-    if (p.stats) {
-      double s1 = 0.0, s2 = 0.0;
-      for (int sidx = lg; sidx < p.S; sidx += 4) {
-        const f32x2 v = *reinterpret_cast<const f32x2*>(p.stats + (((size_t)b * p.S + sidx) * p.G + (c0 + li) / cpg) * 2);
-        s1 += (double)v[0];
-        s2 += (double)v[1];
-      }
-      s1 += __shfl_xor(s1, 16, 64);
-      s2 += __shfl_xor(s2, 16, 64);
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      const double inv_n = 1.0 / ((double)P * cpg);
-      const double m = s1 * inv_n;
-      const float var = fmaxf((float)(s2 * inv_n - m * m), 0.f);
-      sc = rsqrtf(var + p.eps) * p.gamma[c0 + li];
-      sh = p.beta[c0 + li] - (float)m * sc;
+    if (p.gs.st1) {   // (wave-uniform branch; idle waves of the last group take part with their clamped item)
+      float mean, rstd;
+      gn_wave_keys(p.gs, true, b, (c0 + li) / cpg, cpg, (double)P * cpg, p.eps, lane, mean, rstd);
+      sc = rstd * p.gamma[c0 + li];
+      sh = p.beta[c0 + li] - mean * sc;
     }
 
     // ---- X tile: [P px][16 c] -> Xk[c][px] (pixels K-contiguous), GroupNorm applied.
@@ -573,20 +548,23 @@ __global__ void __launch_bounds__(256) k_af_act_small(AfP<T> p) {
   const int total = p.B * Ct;
   const float* __restrict__ U = p.U;
   const float* __restrict__ D = p.D;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int b = i / Ct, c = i - b * Ct;
+  {   // (the launch covers `total` exactly once; a wave works out its lanes' GroupNorm keys together)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < total;
+    const int b = live ? i / Ct : 0, c = live ? i - b * Ct : 0;
     const bool second = c >= p.C1;
     const T* xs = second ? p.x2 : p.x1;
     const int Cs = second ? p.C2 : p.C1;
     const int cc = second ? c - p.C1 : c;
     float sc = 1.f, sh = 0.f;
-    if (p.stats) {
+    if (p.gs.st1) {
       const int cpg = Ct / p.G;
       float mean, rstd;
-      gn_finalize(p.stats, p.S, p.G, b, c / cpg, (double)N * N * cpg, p.eps, mean, rstd);
+      gn_wave_keys(p.gs, live, b, c / cpg, cpg, (double)N * N * cpg, p.eps, threadIdx.x & 63, mean, rstd);
       sc = rstd * p.gamma[c];
       sh = p.beta[c] - mean * sc;
     }
+    if (!live) return;
     float X[N][N], Y[N][N];
 #pragma unroll
     for (int h = 0; h < N; ++h)
@@ -777,14 +755,13 @@ static int launch_af_small(const AfP<T>& p, hipStream_t st) {
 }
 
 template <typename T>
-static int af_act_dispatch(const void* x1, int C1, const void* x2, int C2, const float* stats, const float* gamma,
+static int af_act_dispatch(const void* x1, int C1, const void* x2, int C2, const GnStats& gs, const float* gamma,
                            const float* beta, int G, float eps, const float* U, const float* D, const void* packed,
                            void* y, int B, int N, hipStream_t st) {
   AfP<T> p;
   p.packed = packed;
-  p.S = gn_splits(N * N);
   p.eps = eps;
-  p.x1 = (const T*)x1; p.x2 = (const T*)x2; p.stats = stats; p.gamma = gamma; p.beta = beta;
+  p.x1 = (const T*)x1; p.x2 = (const T*)x2; p.gs = gs; p.gamma = gamma; p.beta = beta;
   p.U = U; p.D = D; p.y = (T*)y; p.C1 = C1; p.C2 = C2; p.G = G; p.B = B;
   switch (N) {
     case 2: return launch_af_small<T, 2>(p, st);
@@ -831,25 +808,28 @@ static int resample_dispatch(const void* x, const float* M, void* y, float* ws, 
 
 using namespace afldm;
 
-extern "C" int afldm_af_act(const void* x1, int C1, const void* x2, int C2, const float* stats, const float* gamma,
-                            const float* beta, int G, float eps, const float* U, const float* D, const void* packed,
-                            void* y, int B, int N, int dtype, afldm_stream_t stream) {
+extern "C" int afldm_af_act(const void* x1, int C1, const void* x2, int C2, const float* stats1, int S1,
+                            const float* stats2, int S2, const float* gamma, const float* beta, int G, float eps,
+                            const float* U, const float* D, const void* packed, void* y, int B, int N, int dtype,
+                            afldm_stream_t stream) {
   AFLDM_REQUIRE(x1 && U && D && y, AFLDM_ENULL, "afldm_af_act: NULL pointer");
   AFLDM_REQUIRE(N < 16 || packed, AFLDM_ENULL, "afldm_af_act: N=%d needs the packed filter image (afldm_af_pack)", N);
   if ((N == 4 || N == 8) && packed && C1 % 16 == 0 && C2 % 16 == 0)
     AFLDM_REQUIRE(aligned16(x1) && aligned16(x2) && aligned16(y), AFLDM_EALIGN, "afldm_af_act: pointers must be 16-byte aligned");
   AFLDM_REQUIRE(C1 > 0 && C2 >= 0 && (C2 == 0 || x2), AFLDM_ESHAPE, "afldm_af_act: bad C1=%d C2=%d", C1, C2);
   AFLDM_REQUIRE(B > 0, AFLDM_ESHAPE, "afldm_af_act: B=%d", B);
-  AFLDM_REQUIRE(!stats || (gamma && beta && G > 0 && (C1 + C2) % G == 0), AFLDM_ESHAPE,
-                "afldm_af_act: GroupNorm fusion needs gamma/beta and C %% G == 0 (C=%d G=%d)", C1 + C2, G);
+  AFLDM_REQUIRE(!stats1 || (gamma && beta && G > 0 && (C1 + C2) % G == 0 && S1 > 0 && (C2 == 0 || (stats2 && S2 > 0))),
+                AFLDM_ESHAPE, "afldm_af_act: GroupNorm fusion needs gamma/beta, statistics of both tensors and C %% G == 0 (C=%d G=%d)",
+                C1 + C2, G);
   if (N >= 16) {
     AFLDM_REQUIRE(C1 % 16 == 0 && C2 % 16 == 0, AFLDM_ESHAPE, "afldm_af_act: C1=%d / C2=%d must be multiples of 16 for N=%d",
                   C1, C2, N);
     AFLDM_REQUIRE(aligned16(x1) && aligned16(x2) && aligned16(y), AFLDM_EALIGN, "afldm_af_act: pointers must be 16-byte aligned");
   }
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == AFLDM_F32) return af_act_dispatch<float>(x1, C1, x2, C2, stats, gamma, beta, G, eps, U, D, packed, y, B, N, st);
-  if (dtype == AFLDM_BF16) return af_act_dispatch<bf16>(x1, C1, x2, C2, stats, gamma, beta, G, eps, U, D, packed, y, B, N, st);
+  const GnStats gs{stats1, stats2, C1, C2, S1, S2};
+  if (dtype == AFLDM_F32) return af_act_dispatch<float>(x1, C1, x2, C2, gs, gamma, beta, G, eps, U, D, packed, y, B, N, st);
+  if (dtype == AFLDM_BF16) return af_act_dispatch<bf16>(x1, C1, x2, C2, gs, gamma, beta, G, eps, U, D, packed, y, B, N, st);
   set_error("afldm_af_act: unknown dtype %d", dtype);
   return AFLDM_EDTYPE;
 }

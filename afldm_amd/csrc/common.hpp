@@ -155,22 +155,93 @@ __host__ __device__ inline int gn_splits(int HW) {
   return HW >= 1024 ? 32 : HW >= 256 ? 16 : HW >= 64 ? 4 : 1;
 }
 
-// (mean, rstd) of group g of sample b from the S partial sums.  The sums are added in fp64 (the
-// E[x^2] - mean^2 cancellation is harmless there); everything else is fp32.
-__device__ __forceinline__ void gn_finalize(const float* __restrict__ part, int S, int G, int b, int g, double n,
-                                            float eps, float& mean, float& rstd) {
-  double s1 = 0.0, s2 = 0.0;
-  const float* q = part + ((size_t)b * S * G + g) * 2;
-  for (int s = 0; s < S; ++s) {
-    const f32x2 v = *reinterpret_cast<const f32x2*>(q + (size_t)s * G * 2);
+// GroupNorm statistics travel as PER-CHANNEL partial sums: a producer (afldm_gn_stats, or the
+// epilogue of afldm_conv2d / its split-K reduction) writes st[b][s][c] = (sum, sum of squares) of
+// channel c over row-split s of sample b of ITS tensor; S is the producer's split count.  A
+// consumer normalising the virtual channel-concat (x1 | x2) adds, for group g, the partials of the
+// channels [g cpg, (g+1) cpg) over all splits in a fixed order (no atomics: bit-reproducible) and
+// finishes mean / rstd itself - no finalize launch.  Per-channel (not per-group) partials let one
+// tensor's statistics serve both as the next block's input and, later, as half of a skip
+// concatenation whose groups straddle the two tensors.
+struct GnStats {
+  const float* st1;
+  const float* st2;
+  int C1, C2, S1, S2;
+};
+
+__device__ __forceinline__ void gn_channel_sums(const GnStats& s, int b, int c, double& s1, double& s2) {
+  const bool second = c >= s.C1;
+  const float* st = second ? s.st2 : s.st1;
+  const int Cs = second ? s.C2 : s.C1, S = second ? s.S2 : s.S1, cc = second ? c - s.C1 : c;
+  const float* q = st + ((size_t)b * S * Cs + cc) * 2;
+  for (int i = 0; i < S; ++i) {
+    const f32x2 v = *reinterpret_cast<const f32x2*>(q + (size_t)i * Cs * 2);
     s1 += (double)v[0];
     s2 += (double)v[1];
   }
+}
+
+// The sums are added in fp64 (the E[x^2] - mean^2 cancellation is harmless there); the rest is fp32.
+__device__ __forceinline__ void gn_mean_rstd(double s1, double s2, double n, float eps, float& mean, float& rstd) {
   const double inv_n = 1.0 / n;
   const double m = s1 * inv_n;
   const float var = fmaxf((float)(s2 * inv_n - m * m), 0.f);
   mean = (float)m;
   rstd = rsqrtf(var + eps);
+}
+
+// Wave-cooperative group sums (ALL 64 lanes of the calling wave must be active): the cpg x S
+// per-channel partials of group g are strided over the lanes (channel-major, fixed order) and
+// combined with xor-shuffles; every lane returns the totals.
+__device__ __forceinline__ void gn_group_sums_wave(const GnStats& s, int b, int g, int cpg, int lane, double& s1,
+                                                   double& s2) {
+  s1 = 0.0;
+  s2 = 0.0;
+  const int smax = s.S1 > s.S2 ? s.S1 : s.S2;
+  for (int j = lane; j < cpg * smax; j += 64) {
+    const int c = g * cpg + j / smax, sp = j - (j / smax) * smax;
+    const bool second = c >= s.C1;
+    const int S = second ? s.S2 : s.S1;
+    if (sp < S) {
+      const float* st = second ? s.st2 : s.st1;
+      const int Cs = second ? s.C2 : s.C1, cc = second ? c - s.C1 : c;
+      const f32x2 v = *reinterpret_cast<const f32x2*>(st + (((size_t)b * S + sp) * Cs + cc) * 2);
+      s1 += (double)v[0];
+      s2 += (double)v[1];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+}
+
+// Per-lane GroupNorm (mean, rstd) for a wave whose lanes each own one (sample b, group g) key
+// (`live` = the lane has one): the distinct keys are visited one at a time, wave-cooperatively.
+__device__ __forceinline__ void gn_wave_keys(const GnStats& s, bool live, int b, int g, int cpg, double n, float eps,
+                                             int lane, float& mean, float& rstd) {
+  bool done = !live;
+  mean = 0.f;
+  rstd = 1.f;
+  while (__any(!done)) {
+    const int leader = __ffsll((unsigned long long)__ballot(!done)) - 1;
+    const int kb = __shfl(b, leader, 64), kg = __shfl(g, leader, 64);
+    double s1, s2;
+    gn_group_sums_wave(s, kb, kg, cpg, lane, s1, s2);
+    if (!done && b == kb && g == kg) {
+      gn_mean_rstd(s1, s2, n, eps, mean, rstd);
+      done = true;
+    }
+  }
+}
+
+// (mean, rstd) of group g of sample b, serially by one thread.
+__device__ __forceinline__ void gn_finalize(const GnStats& s, int b, int g, int cpg, double n, float eps, float& mean,
+                                            float& rstd) {
+  double s1 = 0.0, s2 = 0.0;
+  for (int c = g * cpg; c < (g + 1) * cpg; ++c) gn_channel_sums(s, b, c, s1, s2);
+  gn_mean_rstd(s1, s2, n, eps, mean, rstd);
 }
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -41,6 +41,8 @@ struct ConvP {
   int tiles_n;
   int vec_ok;   // leading dims allow 4-element vector epilogue accesses
   int tap_inner;  // K order of the LDS-DMA kernel (see k_igemm2)
+  float* stats_out;  // per-channel GroupNorm partial sums of the output [B][stats_S][Cout][2], or NULL
+  int stats_S;
   int m_fast;     // tile order of the LDS-DMA kernel: 1 = tile_m fastest (weights outweigh pixels)
   int stage_ok;   // leading dimensions / splits allow the LDS-staged 16-byte epilogue
   int dbg;      // AFLDM_CONV_DBG (timing decomposition only): bit 0 skip the LDS-DMA, bit 1 skip the MFMA phase
@@ -557,6 +559,11 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
     const T* temb = (const T*)p.temb;
     const T* res = (const T*)p.residual;
     const int etid = cw * 64 + lane;
+    constexpr int CPR = BN / EO;                         // 16-byte chunks per staged row
+    constexpr int RPI = NTC / CPR;                       // rows the workgroup covers per sweep
+    float ss1[EO], ss2[EO];
+#pragma unroll
+    for (int e = 0; e < EO; ++e) ss1[e] = ss2[e] = 0.f;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       __syncthreads();   // pipeline buffers idle (first pass) / previous pass copied out
@@ -588,52 +595,63 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
         }
         continue;
       }
-      // (a) NHWC part: couts [n0, min(n0 + BN, nhwc_end)), 16 bytes of one pixel per lane
+      // (a) NHWC part: couts [n0, min(n0 + BN, nhwc_end)), 16 bytes of one pixel per lane.  A thread
+      // keeps ONE 16-byte column of the tile and walks down its rows, so the per-channel
+      // GroupNorm sums of the stored values (stats_out) accumulate in its registers.
       const int nhwc_end = p.out_mode == 1 ? 0 : (p.y2 ? p.split_n : p.Cout);
-      constexpr int CPR = BN / EO;                       // 16-byte chunks per staged row
-#pragma unroll 1
-      for (int i = etid; i < PROWS * CPR; i += NTC) {
-        const int row = i / CPR, ch = i - row * CPR;
+      if (etid < RPI * CPR) {
+        const int ch = etid % CPR;
         const int n = n0 + ch * EO;
-        const int mt = row / (TMP * 16), rr = row - mt * (TMP * 16);
-        const int m = m0 + mt * WMS + ps * TMP * 16 + rr;
-        if (m >= p.M || n >= nhwc_end) continue;
-        float v[EO];
+#pragma unroll 1
+        for (int row = etid / CPR; row < PROWS; row += RPI) {
+          const int mt = row / (TMP * 16), rr = row - mt * (TMP * 16);
+          const int m = m0 + mt * WMS + ps * TMP * 16 + rr;
+          if (m >= p.M || n >= nhwc_end) continue;
+          float v[EO];
 #pragma unroll
-        for (int q = 0; q < EO / 4; ++q) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(sC + row * SROW + ch * EO + 4 * q);
-          v[4 * q] = a[0]; v[4 * q + 1] = a[1]; v[4 * q + 2] = a[2]; v[4 * q + 3] = a[3];
-        }
-        const int b = m / HW;
-        if (p.stage_ok && n + EO <= nhwc_end) {
-          if (p.bias) {
+          for (int q = 0; q < EO / 4; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(sC + row * SROW + ch * EO + 4 * q);
+            v[4 * q] = a[0]; v[4 * q + 1] = a[1]; v[4 * q + 2] = a[2]; v[4 * q + 3] = a[3];
+          }
+          const int b = m / HW;
+          if (p.stage_ok && n + EO <= nhwc_end) {
+            if (p.bias) {
 #pragma unroll
-            for (int q = 0; q < EO / 4; ++q) {
-              const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n + 4 * q);
-              v[4 * q] += bv[0]; v[4 * q + 1] += bv[1]; v[4 * q + 2] += bv[2]; v[4 * q + 3] += bv[3];
+              for (int q = 0; q < EO / 4; ++q) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n + 4 * q);
+                v[4 * q] += bv[0]; v[4 * q + 1] += bv[1]; v[4 * q + 2] += bv[2]; v[4 * q + 3] += bv[3];
+              }
             }
-          }
-          if (temb) {
-            const Chunk tv = ld16<Chunk>(temb + (size_t)b * p.temb_stride + n);
+            if (temb) {
+              const Chunk tv = ld16<Chunk>(temb + (size_t)b * p.temb_stride + n);
 #pragma unroll
-            for (int e = 0; e < EO; ++e) v[e] += to_f32(tv[e]);
-          }
-          if (res) {
-            const Chunk rv = ld16<Chunk>(res + (size_t)m * p.res_ld + n);
+              for (int e = 0; e < EO; ++e) v[e] += to_f32(tv[e]);
+            }
+            if (res) {
+              const Chunk rv = ld16<Chunk>(res + (size_t)m * p.res_ld + n);
 #pragma unroll
-            for (int e = 0; e < EO; ++e) v[e] += to_f32(rv[e]);
-          }
-          Chunk o;
+              for (int e = 0; e < EO; ++e) v[e] += to_f32(rv[e]);
+            }
+            Chunk o;
 #pragma unroll
-          for (int e = 0; e < EO; ++e) o[e] = from_f32<T>(v[e]);
-          st16<Chunk>((T*)p.y + (size_t)m * p.y_ld + n, o);
-        } else {   // ragged cout tail
-          for (int e = 0; e < EO && n + e < nhwc_end; ++e) {
-            float sv = v[e];
-            if (p.bias) sv += p.bias[n + e];
-            if (temb) sv += to_f32(temb[(size_t)b * p.temb_stride + n + e]);
-            if (res) sv += to_f32(res[(size_t)m * p.res_ld + n + e]);
-            ((T*)p.y)[(size_t)m * p.y_ld + n + e] = from_f32<T>(sv);
+            for (int e = 0; e < EO; ++e) o[e] = from_f32<T>(v[e]);
+            st16<Chunk>((T*)p.y + (size_t)m * p.y_ld + n, o);
+            if (p.stats_out) {
+#pragma unroll
+              for (int e = 0; e < EO; ++e) {
+                const float vr = to_f32(o[e]);      // statistics of what the consumer will read
+                ss1[e] += vr;
+                ss2[e] = fmaf(vr, vr, ss2[e]);
+              }
+            }
+          } else {   // ragged cout tail / odd leading dimensions
+            for (int e = 0; e < EO && n + e < nhwc_end; ++e) {
+              float sv = v[e];
+              if (p.bias) sv += p.bias[n + e];
+              if (temb) sv += to_f32(temb[(size_t)b * p.temb_stride + n + e]);
+              if (res) sv += to_f32(res[(size_t)m * p.res_ld + n + e]);
+              ((T*)p.y)[(size_t)m * p.y_ld + n + e] = from_f32<T>(sv);
+            }
           }
         }
       }
@@ -674,6 +692,93 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
           }
         }
       }
+    }
+    if (p.stats_out) {
+      // per-channel sums of this tile (BM rows of ONE sample: the host only asks when H*W % BM == 0):
+      // the RPI row-interleaved partials of a column are added in a fixed order through LDS
+      float* sR = sC;   // [RPI][BN][2]
+      __syncthreads();
+      if (etid < RPI * CPR) {
+        const int ch = etid % CPR, tr = etid / CPR;
+#pragma unroll
+        for (int e = 0; e < EO; ++e)
+          *reinterpret_cast<f32x2*>(sR + ((tr * BN) + ch * EO + e) * 2) = f32x2{ss1[e], ss2[e]};
+      }
+      __syncthreads();
+      for (int c = etid; c < BN; c += NTC) {
+        if (n0 + c >= p.Cout) continue;
+        float a1 = 0.f, a2 = 0.f;
+        for (int tr = 0; tr < RPI; ++tr) {
+          const f32x2 v = *reinterpret_cast<const f32x2*>(sR + ((tr * BN) + c) * 2);
+          a1 += v[0];
+          a2 += v[1];
+        }
+        const int b = m0 / HW, sp = (m0 - b * HW) / BM;
+        *reinterpret_cast<f32x2*>(p.stats_out + (((size_t)b * p.stats_S + sp) * p.Cout + n0 + c) * 2) = f32x2{a1, a2};
+      }
+    }
+  }
+}
+
+// split-K reduction that also emits the per-channel GroupNorm partial sums of the output: one
+// workgroup = (sample, row split, 64 channel quads); thread (quad, row lane 0..3) owns 4 channels and
+// every 4th row of the split; the 4 row lanes are combined in a fixed order through LDS.
+template <typename T>
+__global__ void __launch_bounds__(256) k_splitk_reduce_stats(ConvP p, int rows_per_split) {
+  __shared__ float red[4][64][8];
+  const int HW = p.H * p.W, nq = p.Cout / 4, nqb = (nq + 63) / 64;
+  int bid = blockIdx.x;
+  const int qb = bid % nqb;
+  bid /= nqb;
+  const int sp = bid % p.stats_S, b = bid / p.stats_S;
+  const int tq = threadIdx.x & 63, tr = threadIdx.x >> 6;
+  const int q = qb * 64 + tq;
+  const bool live = q < nq;
+  const int n = 4 * q;
+  const int r0 = sp * rows_per_split, r1 = r0 + rows_per_split < HW ? r0 + rows_per_split : HW;
+  const T* temb = (const T*)p.temb;
+  const T* res = (const T*)p.residual;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    f32x4 bt = {0.f, 0.f, 0.f, 0.f};
+    const bool has_b = p.bias != nullptr;
+    if (has_b) bt = *reinterpret_cast<const f32x4*>(p.bias + n);
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    if (temb) load4<T>(temb + (size_t)b * p.temb_stride + n, t0, t1, t2, t3);
+    for (int pix = r0 + tr; pix < r1; pix += 4) {
+      const size_t m = (size_t)b * HW + pix;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      for (int sl = 0; sl < p.splitk; ++sl) v += *reinterpret_cast<const f32x4*>(p.ws + ((size_t)sl * p.M + m) * p.Cout + n);
+      // (same association as epilogue_store: ((acc + bias) + temb) + residual)
+      if (has_b) v += bt;
+      if (temb) { v[0] += t0; v[1] += t1; v[2] += t2; v[3] += t3; }
+      if (res) {
+        float a0, a1, a2, a3;
+        load4<T>(res + m * p.res_ld + n, a0, a1, a2, a3);
+        v[0] += a0; v[1] += a1; v[2] += a2; v[3] += a3;
+      }
+      float vr[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        vr[e] = to_f32(from_f32<T>(v[e]));      // statistics of what the consumer will read
+        s1[e] += vr[e];
+        s2[e] = fmaf(vr[e], vr[e], s2[e]);
+      }
+      store4<T>((T*)p.y + m * p.y_ld + n, vr[0], vr[1], vr[2], vr[3]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[tr][tq][2 * e] = s1[e];
+    red[tr][tq][2 * e + 1] = s2[e];
+  }
+  __syncthreads();
+  if (tr == 0 && live) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a1 = ((red[0][tq][2 * e] + red[1][tq][2 * e]) + red[2][tq][2 * e]) + red[3][tq][2 * e];
+      const float a2 = ((red[0][tq][2 * e + 1] + red[1][tq][2 * e + 1]) + red[2][tq][2 * e + 1]) + red[3][tq][2 * e + 1];
+      *reinterpret_cast<f32x2*>(p.stats_out + (((size_t)b * p.stats_S + sp) * p.Cout + n + e) * 2) = f32x2{a1, a2};
     }
   }
 }
@@ -1018,6 +1123,56 @@ static bool launch_variant(int id, const ConvP& p, hipStream_t st) {
   return false;
 }
 
+// How afldm_conv2d will run a problem (shared by the dispatch and the host-side queries).
+struct Exec {
+  Plan pl;
+  int vid;       // igemm variant actually launched
+  int splitk;    // after the workspace check
+};
+template <typename T>
+static Exec resolve_exec(const afldm_conv_args* a) {
+  Exec e;
+  e.pl = make_plan(a, epr<T>());
+  e.vid = e.pl.cfg;
+  e.splitk = e.pl.kind == 0 ? e.pl.splitk : 1;
+  if (e.pl.kind != 0) return e;
+  const long long M = (long long)a->B * a->H * a->W;
+  const int Ct = a->C1 + a->C2;
+  if (e.splitk > 1) {
+    const size_t need = (size_t)e.splitk * M * a->Cout * sizeof(float);
+    if (!a->workspace || a->workspace_bytes < need) e.splitk = 1;  // no workspace -> no split
+  }
+  const bool v2_ok = M * (a->C1 > a->C2 ? a->C1 : a->C2) * (long long)sizeof(T) < (1ll << 31) &&
+                     (long long)a->Cout * a->KS * a->KS * Ct * (long long)sizeof(T) < (1ll << 31);
+  if (kVariants[e.vid].ver >= 2 && !v2_ok) e.vid = kVariants[e.vid].bm == 128 ? (kVariants[e.vid].bn >= 128 ? 0 : 1) : 3;
+  return e;
+}
+
+// Where the GroupNorm partial sums of the output come from, and their split count S.
+enum { ST_EPILOGUE = 1, ST_REDUCE = 2, ST_STANDALONE = 3 };
+static int reduce_stats_splits(int HW) { return HW >= 64 ? (HW / 16 > 32 ? 32 : HW / 16) : 1; }
+template <typename T>
+static int stats_mode(const afldm_conv_args* a, const Exec& e, int* S) {
+  const int HW = a->H * a->W, eo = 16 / (int)sizeof(T);
+  const bool vec4 = a->y_ld % 4 == 0 && (!a->residual || a->res_ld % 4 == 0) && (!a->temb || a->temb_stride % 4 == 0) &&
+                    a->Cout % 4 == 0;
+  const bool vec16 = a->y_ld % eo == 0 && (!a->residual || a->res_ld % eo == 0) && (!a->temb || a->temb_stride % eo == 0) &&
+                     a->Cout % eo == 0;
+  if (e.pl.kind == 0 && e.splitk > 1 && vec4) {
+    *S = reduce_stats_splits(HW);
+    return ST_REDUCE;
+  }
+  if (e.pl.kind == 0 && e.splitk == 1 && kVariants[e.vid].ver >= 2 && HW % kVariants[e.vid].bm == 0 && vec16 &&
+      !getenv("AFLDM_CONV_NOSTAGE")) {
+    *S = HW / kVariants[e.vid].bm;
+    return ST_EPILOGUE;
+  }
+  *S = gn_splits(HW);
+  return ST_STANDALONE;
+}
+
+extern "C" int afldm_gn_stats(const void* x, int C, float* stats, int B, int HW, int dtype, afldm_stream_t stream);
+
 template <typename T>
 static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
   ConvP p;
@@ -1050,49 +1205,57 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
     static const int s_mfast = getenv("AFLDM_CONV_MFAST") ? atoi(getenv("AFLDM_CONV_MFAST")) : -1;
     p.m_fast = s_mfast >= 0 ? s_mfast : ((long long)a->Cout * a->KS * a->KS > (long long)p.M ? 1 : 0);
   }
-  Plan pl = make_plan(a, epr<T>());
+  const Exec ex = resolve_exec<T>(a);
+  const Plan& pl = ex.pl;
+  int smode = 0;
+  p.stats_out = nullptr;
+  p.stats_S = 1;
+  if (a->stats_out) smode = stats_mode<T>(a, ex, &p.stats_S);
+  int rc = AFLDM_OK;
   if (pl.kind == 1 && a->C1 == 4 && a->C2 == 0 && a->KS == 3 && a->Cout % 16 == 0 && a->Cout * 36 * 4 <= 64 * 1024 &&
       !a->temb && !a->residual && a->out_mode == 0 && a->y_ld % 4 == 0) {
     const int lds = a->Cout * 36 * (int)sizeof(float);
     k_conv_cin4<T, 4, 3><<<(p.M + 63) / 64, 256, lds, st>>>(p);
-    return check_launch("afldm_conv2d(cin4)");
-  }
-  if (pl.kind == 1) {
+    rc = check_launch("afldm_conv2d(cin4)");
+  } else if (pl.kind == 1) {
     AFLDM_REQUIRE(a->C2 == 0 && a->C1 <= 64, AFLDM_ESHAPE,
                   "afldm_conv2d: Cin=%d+%d is not a multiple of %d and too large for the direct kernel", a->C1,
                   a->C2, KCH_DEFAULT * epr<T>());
     size_t total = (size_t)p.M * p.Cout;
     int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     k_conv_small_cin<T><<<grid, 256, 0, st>>>(p);
-    return check_launch("afldm_conv2d(small_cin)");
-  }
-  if (pl.kind == 2) {
+    rc = check_launch("afldm_conv2d(small_cin)");
+  } else if (pl.kind == 2) {
     AFLDM_REQUIRE(a->C2 == 0 && a->Cout <= 8, AFLDM_ESHAPE, "afldm_conv2d: unsupported small-Cout shape (Cout=%d, C2=%d)",
                   a->Cout, a->C2);
     int grid = (p.M + 3) / 4 < 8192 ? (p.M + 3) / 4 : 8192;
     k_conv_small_cout<T, 8><<<grid, 256, 0, st>>>(p);
-    return check_launch("afldm_conv2d(small_cout)");
+    rc = check_launch("afldm_conv2d(small_cout)");
+  } else {
+    const int Ct = a->C1 + a->C2;
+    p.ksteps = a->KS * a->KS * (Ct / (KCH_DEFAULT * epr<T>()));
+    p.splitk = ex.splitk;
+    if (smode == ST_EPILOGUE) p.stats_out = a->stats_out;
+    launch_variant<T>(ex.vid, p, st);
+    rc = check_launch("afldm_conv2d(igemm)");
+    if (rc) return rc;
+    if (p.splitk > 1) {
+      if (smode == ST_REDUCE) {
+        p.stats_out = a->stats_out;
+        const int HW = a->H * a->W, nqb = (p.Cout / 4 + 63) / 64;
+        const int rows = (HW + p.stats_S - 1) / p.stats_S;
+        k_splitk_reduce_stats<T><<<a->B * p.stats_S * nqb, 256, 0, st>>>(p, rows);
+      } else {
+        size_t total = (size_t)p.M * ((p.Cout + 3) / 4);
+        int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        k_splitk_reduce<T><<<grid, 256, 0, st>>>(p);
+      }
+      rc = check_launch("afldm_conv2d(splitk_reduce)");
+    }
   }
-  const int Ct = a->C1 + a->C2;
-  p.ksteps = a->KS * a->KS * (Ct / (KCH_DEFAULT * epr<T>()));
-  p.splitk = pl.splitk;
-  if (p.splitk > 1) {
-    size_t need = (size_t)p.splitk * p.M * p.Cout * sizeof(float);
-    if (!a->workspace || a->workspace_bytes < need) p.splitk = 1;  // no workspace -> no split
-  }
-  const bool v2_ok = (long long)p.M * (a->C1 > a->C2 ? a->C1 : a->C2) * (long long)sizeof(T) < (1ll << 31) &&
-                     (long long)a->Cout * a->KS * a->KS * Ct * (long long)sizeof(T) < (1ll << 31);
-  int vid = pl.cfg;
-  if (kVariants[vid].ver >= 2 && !v2_ok) vid = kVariants[vid].bm == 128 ? (kVariants[vid].bn >= 128 ? 0 : 1) : 3;
-  launch_variant<T>(vid, p, st);
-  int rc = check_launch("afldm_conv2d(igemm)");
   if (rc) return rc;
-  if (p.splitk > 1) {
-    size_t total = (size_t)p.M * ((p.Cout + 3) / 4);
-    int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    k_splitk_reduce<T><<<grid, 256, 0, st>>>(p);
-    rc = check_launch("afldm_conv2d(splitk_reduce)");
-  }
+  if (smode == ST_STANDALONE)   // output of a kernel without a fused producer: one extra read of y
+    rc = afldm_gn_stats(a->y, a->Cout, a->stats_out, a->B, a->H * a->W, a->dtype, (afldm_stream_t)st);
   return rc;
 }
 
@@ -1111,6 +1274,8 @@ static int conv_validate(const afldm_conv_args* a) {
                 "afldm_conv2d: y_ld=%d too small for Cout=%d", a->y_ld, a->Cout);
   AFLDM_REQUIRE(!a->residual || a->res_ld >= a->Cout, AFLDM_ESHAPE, "afldm_conv2d: res_ld=%d < Cout=%d", a->res_ld, a->Cout);
   AFLDM_REQUIRE((long long)a->B * a->H * a->W < (1ll << 30), AFLDM_ESHAPE, "afldm_conv2d: M too large");
+  AFLDM_REQUIRE(!a->stats_out || (a->out_mode == 0 && !a->y2 && a->y_ld == a->Cout && a->Cout % 4 == 0), AFLDM_ESHAPE,
+                "afldm_conv2d: stats_out needs a dense NHWC output (out_mode 0, no y2, y_ld == Cout, Cout %% 4 == 0)");
   AFLDM_REQUIRE(aligned16(a->x1) && aligned16(a->w) && aligned16(a->y) && aligned16(a->x2) && aligned16(a->residual) &&
                     aligned16(a->temb) && aligned16(a->bias),
                 AFLDM_EALIGN, "afldm_conv2d: all pointers must be 16-byte aligned");
@@ -1126,6 +1291,14 @@ extern "C" int afldm_conv2d_tune(int variant, int splitk) {
   g_force_variant = variant;
   g_force_splitk = splitk;
   return AFLDM_OK;
+}
+
+extern "C" int afldm_conv2d_stats_splits(const afldm_conv_args* a) {
+  if (!a || (a->dtype != AFLDM_F32 && a->dtype != AFLDM_BF16)) return 0;
+  int S = 0;
+  if (a->dtype == AFLDM_F32) stats_mode<float>(a, resolve_exec<float>(a), &S);
+  else stats_mode<bf16>(a, resolve_exec<bf16>(a), &S);
+  return S;
 }
 
 extern "C" size_t afldm_conv2d_workspace(const afldm_conv_args* a) {

@@ -191,14 +191,14 @@ __global__ void __launch_bounds__(256) k_sep(SepP p) {
 }
 
 // (scale, shift) per (sample, channel) from GroupNorm partial sums: table[b][c] = (rstd*gamma, beta - mean*rstd*gamma)
-__global__ void __launch_bounds__(256) k_gn_table(const float* __restrict__ part, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(256) k_gn_table(GnStats gs, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, float* __restrict__ table, int B, int C,
-                                                  int G, int S, double n, float eps) {
+                                                  int G, double n, float eps) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * C) return;
   const int b = i / C, c = i - b * C, cpg = C / G;
   float mean, rstd;
-  gn_finalize(part, S, G, b, c / cpg, n, eps, mean, rstd);
+  gn_finalize(gs, b, c / cpg, cpg, n, eps, mean, rstd);
   const float k = rstd * gamma[c];
   table[2 * i + 0] = k;
   table[2 * i + 1] = beta[c] - mean * k;
@@ -288,13 +288,13 @@ extern "C" int afldm_sep_pass(const afldm_sep_args* a, afldm_stream_t stream) {
   return AFLDM_EDTYPE;
 }
 
-extern "C" int afldm_gn_table(const float* part, const float* gamma, const float* beta, float* table, int B, int C, int G,
-                              int HW, float eps, afldm_stream_t stream) {
-  AFLDM_REQUIRE(part && gamma && beta && table, AFLDM_ENULL, "afldm_gn_table: NULL pointer");
-  AFLDM_REQUIRE(B > 0 && C > 0 && G > 0 && C % G == 0 && HW > 0, AFLDM_ESHAPE, "afldm_gn_table: bad shape");
+extern "C" int afldm_gn_table(const float* stats, int S, const float* gamma, const float* beta, float* table, int B, int C,
+                              int G, int HW, float eps, afldm_stream_t stream) {
+  AFLDM_REQUIRE(stats && gamma && beta && table, AFLDM_ENULL, "afldm_gn_table: NULL pointer");
+  AFLDM_REQUIRE(B > 0 && C > 0 && G > 0 && C % G == 0 && HW > 0 && S > 0, AFLDM_ESHAPE, "afldm_gn_table: bad shape");
   const int n = B * C;
-  k_gn_table<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(part, gamma, beta, table, B, C, G, gn_splits(HW),
-                                                                 (double)HW * (C / G), eps);
+  const GnStats gs{stats, nullptr, C, 0, S, 0};
+  k_gn_table<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(gs, gamma, beta, table, B, C, G, (double)HW * (C / G), eps);
   return check_launch("afldm_gn_table");
 }
 

@@ -226,14 +226,15 @@ class ResnetBlock2D(nn.Module):
     def forward(self, input_tensor, temb_proj=None, temb_stride=0):
         x1, x2 = _pair(input_tensor)
         h = self._norm_act(self.norm1, input_tensor)
-        h = conv_forward(self.conv1, h, temb=temb_proj, temb_stride=temb_stride)
+        # (the convs whose outputs feed a GroupNorm emit its statistics from their epilogue)
+        h = conv_forward(self.conv1, h, temb=temb_proj, temb_stride=temb_stride, want_stats=True)
         h = self._norm_act(self.norm2, h)
         if self.conv_shortcut is not None:
             res = conv_forward(self.conv_shortcut, input_tensor)
         else:
             assert x2 is None
             res = x1
-        return conv_forward(self.conv2, h, residual=res)
+        return conv_forward(self.conv2, h, residual=res, want_stats=True)
 
 
 # ----------------------------------------------------------------------------- attention
@@ -259,8 +260,7 @@ class AttnProcessor2_0:
             k = linear_forward(attn.to_k, src)
             vt = linear_forward(attn.to_v, src, out_mode=1)
             o = ops.attention_dense(q, k, vt, attn.scale)
-            out = linear_forward(attn.to_out[0], o, residual=hidden_states.view(B, H * W, C))
-            return out.view(B, H, W, C)
+            return linear_forward(attn.to_out[0], o.view(B, H, W, C), residual=hidden_states, want_stats=True)
         if encoder_hidden_states is None:
             # fused Q|K|V projection: one GEMM reads the normed tokens once; Q and K land token-major
             # side by side, V channel-major (the attention kernel's V^T operand)
@@ -272,8 +272,7 @@ class AttnProcessor2_0:
             w, b = packed_qkv(attn, tokens.dtype, ("k", "v"))
             k, vt = ops.linear_split(encoder_hidden_states, w, b, C)
         o = ops.attention(q, k, vt, attn.heads, scale=attn.scale)
-        out = linear_forward(attn.to_out[0], o, residual=hidden_states.view(B, H * W, C))
-        return out.view(B, H, W, C)
+        return linear_forward(attn.to_out[0], o.view(B, H, W, C), residual=hidden_states, want_stats=True)
 
 
 class Attention(nn.Module):

@@ -188,7 +188,7 @@ class UNet2DModel(nn.Module):
         def take(n):
             return [next(it) for _ in range(n)]
 
-        h = B.conv_forward(self.conv_in, x)
+        h = B.conv_forward(self.conv_in, x, want_stats=True)
         skips = (h,)
         for blk in self.down_blocks:
             h, outs = blk(h, take(len(blk.resnets)))

@@ -177,27 +177,73 @@ def _cat_args(x1, x2):
     return C1, x2, x2.shape[-1]
 
 
-def gn_stats(x1, G, x2=None, out=None):
-    """GroupNorm partial sums [B, S, G, 2] (sum, sum of squares per pixel split) of the virtual
-    concat x1|x2; consumed by gn_apply / af_act, which finish mean / rstd themselves."""
-    C1, x2, C2 = _cat_args(x1, x2)
-    B = x1.shape[0]
-    HW = x1.numel() // (B * C1)
+class GNStats:
+    """Per-channel GroupNorm partial sums of a tensor or of a virtual concat x1|x2:
+    st1 [B, S1, C1, 2], st2 [B, S2, C2, 2] fp32 (sum, sum of squares per pixel split).  Producers:
+    gn_stats (stand-alone pass) and conv2d(..., want_stats=True) (GEMM epilogue, attached to the
+    output tensor as `.gn_partial`).  Consumers finish mean / rstd themselves."""
+    __slots__ = ("st1", "st2")
+
+    def __init__(self, st1, st2=None):
+        self.st1, self.st2 = st1, st2
+
+    @property
+    def S1(self):
+        return self.st1.shape[1]
+
+    @property
+    def S2(self):
+        return 0 if self.st2 is None else self.st2.shape[1]
+
+
+def _tensor_stats(x, out=None):
+    """Per-channel partial sums of ONE NHWC tensor: the ones its producing conv attached, else a pass."""
+    st = getattr(x, "gn_partial", None)
+    if st is not None and out is None:
+        return st
+    _dev(x, "x")
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
     S = lib.afldm_gn_stats_splits(HW)
     if out is None:
-        out = torch.empty((B, S, G, 2), dtype=torch.float32, device=x1.device)
+        out = torch.empty((B, S, C, 2), dtype=torch.float32, device=x.device)
     tok = _begin()
-    check(lib.afldm_gn_stats(ptr(x1), C1, ptr(x2), C2, ptr(out), B, HW, G, _code(x1), stream_ptr()), "gn_stats")
-    _end(tok, "gn_stats", 0, B * HW * (C1 + C2) * x1.element_size())
+    check(lib.afldm_gn_stats(ptr(x), C, ptr(out), B, HW, _code(x), stream_ptr()), "gn_stats")
+    _end(tok, "gn_stats", 0, B * HW * C * x.element_size())
     return out
 
 
-def gn_mean_rstd(part, n, eps):
-    """(mean, rstd) [B, G] from partial sums — host-side helper for tests / debugging only."""
-    s = part.double().sum(1)
+def gn_stats(x1, G=None, x2=None, out=None):
+    """GroupNorm statistics (GNStats) of the virtual concat x1|x2.  `G` is accepted for source
+    compatibility and ignored: the partial sums are per channel, any grouping is formed by the
+    consumer.  `out` (single tensor only) forces a stand-alone pass into that buffer."""
+    C1, x2, C2 = _cat_args(x1, x2)
+    return GNStats(_tensor_stats(x1, out), None if x2 is None else _tensor_stats(x2))
+
+
+def carry_stats(dst, src):
+    """Views / reshapes create new tensor objects: hand the attached statistics over."""
+    st = getattr(src, "gn_partial", None)
+    if st is not None:
+        dst.gn_partial = st
+    return dst
+
+
+def gn_mean_rstd(stats, G, n, eps):
+    """(mean, rstd) [B, G] from GNStats - host-side helper for tests / debugging only."""
+    parts = [stats.st1.double().sum(1)] + ([] if stats.st2 is None else [stats.st2.double().sum(1)])
+    s = torch.cat(parts, 1)                                     # [B, C, 2]
+    B, C, _ = s.shape
+    s = s.view(B, G, C // G, 2).sum(2)
     mean = s[..., 0] / n
     var = (s[..., 1] / n - mean * mean).clamp_min(0)
     return mean.float(), (1.0 / torch.sqrt(var + eps)).float()
+
+
+def _stats_ptrs(stats):
+    if stats is None:
+        return None, 0, None, 0
+    return ptr(stats.st1), stats.S1, ptr(stats.st2), stats.S2
 
 
 def gn_apply(x1, stats, gamma, beta, G, eps, act=0, x2=None, out=None):
@@ -206,8 +252,9 @@ def gn_apply(x1, stats, gamma, beta, G, eps, act=0, x2=None, out=None):
     HW = x1.numel() // (B * C1)
     if out is None:
         out = torch.empty(tuple(x1.shape[:-1]) + (C1 + C2,), dtype=x1.dtype, device=x1.device)
+    p1, S1, p2, S2 = _stats_ptrs(stats)
     tok = _begin()
-    check(lib.afldm_gn_apply(ptr(x1), C1, ptr(x2), C2, ptr(stats), ptr(gamma), ptr(beta), ptr(out), B, HW, G,
+    check(lib.afldm_gn_apply(ptr(x1), C1, ptr(x2), C2, p1, S1, p2, S2, ptr(gamma), ptr(beta), ptr(out), B, HW, G,
                              float(eps), int(act), _code(x1), stream_ptr()), "gn_apply")
     _end(tok, "gn_apply", 0, 2 * B * HW * (C1 + C2) * x1.element_size())
     return out
@@ -233,8 +280,9 @@ def af_act(x1, x2=None, stats=None, gamma=None, beta=None, G=0, eps=0.0, out=Non
         return _af_act_large(x1, stats, gamma, beta, G, eps, out)
     U, D = filter_matrices(N, x1.device)
     packed = packed_filters(N, x1.dtype, x1.device)
+    p1, S1, p2, S2 = _stats_ptrs(stats)
     tok = _begin()
-    check(lib.afldm_af_act(ptr(x1), C1, ptr(x2), C2, ptr(stats), ptr(gamma), ptr(beta), int(G), float(eps), ptr(U),
+    check(lib.afldm_af_act(ptr(x1), C1, ptr(x2), C2, p1, S1, p2, S2, ptr(gamma), ptr(beta), int(G), float(eps), ptr(U),
                            ptr(D), ptr(packed), ptr(out), B, N, _code(x1), stream_ptr()), "af_act")
     # dense separable form: 24 N^3 flop per plane; one read + one write of the tensor
     _end(tok, f"af_act_N{N}", 24.0 * N ** 3 * B * (C1 + C2), 2 * B * N * N * (C1 + C2) * x1.element_size())
@@ -299,9 +347,9 @@ def sep_pass(x, y, M, K, R, outer_count, inner_count, in_outer_stride, in_k_stri
 
 def gn_table(stats, gamma, beta, B, C, G, HW, eps):
     """[B, C, 2] (scale, shift) table from GroupNorm partial sums (for the large-plane passes)."""
-    out = torch.empty((B, C, 2), dtype=torch.float32, device=stats.device)
-    check(lib.afldm_gn_table(ptr(stats), ptr(gamma), ptr(beta), ptr(out), B, C, G, HW, float(eps), stream_ptr()),
-          "gn_table")
+    out = torch.empty((B, C, 2), dtype=torch.float32, device=stats.st1.device)
+    check(lib.afldm_gn_table(ptr(stats.st1), stats.S1, ptr(gamma), ptr(beta), ptr(out), B, C, G, HW, float(eps),
+                             stream_ptr()), "gn_table")
     return out
 
 
@@ -405,9 +453,11 @@ def conv_args(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None
 
 
 def conv2d(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, out=None, out_mode=0,
-           workspace=None):
+           workspace=None, want_stats=False):
     """stride-1 'same' conv (KS in {1,3}) / linear on NHWC input with packed OHWI weights.
-    out_mode 1 returns the channel-major [B, Cout, H*W] tensor (V^T for attention)."""
+    out_mode 1 returns the channel-major [B, Cout, H*W] tensor (V^T for attention).
+    want_stats: also emit the per-channel GroupNorm partial sums of the output (from the GEMM
+    epilogue where possible) and attach them to the returned tensor as `.gn_partial`."""
     Cout = w.shape[0]
     if out is None:
         if out_mode == 0:
@@ -423,8 +473,15 @@ def conv2d(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, o
         if need:
             workspace = torch.empty(need // 4, dtype=torch.float32, device=x1.device)
             a.workspace, a.workspace_bytes = ptr(workspace), need
+    st = None
+    if want_stats and out_mode == 0 and Cout % 4 == 0:
+        S = lib.afldm_conv2d_stats_splits(ctypes.byref(a))
+        st = torch.empty((a.B, S, Cout, 2), dtype=torch.float32, device=x1.device)
+        a.stats_out = ptr(st)
     tok = _begin()
     check(lib.afldm_conv2d(ctypes.byref(a), stream_ptr()), "conv2d")
+    if st is not None:
+        out.gn_partial = st
     if tok is not None:
         M, Ct = a.B * a.H * a.W, a.C1 + a.C2
         es = x1.element_size()

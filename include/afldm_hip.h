@@ -87,28 +87,32 @@ int afldm_silu(const void* x, void* y, size_t n, int dtype, afldm_stream_t strea
  * torch.nn.GroupNorm(G, C, eps) over an NHWC tensor that is the virtual channel-concat of
  * x1 [B,HW,C1] and x2 [B,HW,C2] (x2 may be NULL with C2 = 0): the up-block skip
  * torch.cat([h, skip], 1) is never materialised.
- * Statistics are exchanged as PARTIAL SUMS: part[B][S][G][2] fp32 = (sum, sum of squares) of
- * pixel-split s, S = afldm_gn_stats_splits(HW).  Consumers (afldm_gn_apply, afldm_af_act) add the
- * S partials in a fixed order and finish mean / rstd in fp64: one launch per GroupNorm, no
- * atomics, bit-reproducible. */
+ * Statistics are exchanged as PER-CHANNEL PARTIAL SUMS: stats[B][S][C][2] fp32 = (sum, sum of
+ * squares) of channel c of ONE tensor over pixel-split s.  Producers: afldm_gn_stats (S =
+ * afldm_gn_stats_splits(HW)) and afldm_conv2d, which emits the statistics of its output from the
+ * GEMM epilogue (stats_out, S = afldm_conv2d_stats_splits(args)) so that most GroupNorms cost no
+ * extra pass over the tensor.  Consumers (afldm_gn_apply, afldm_af_act, afldm_gn_table) take the
+ * statistics of x1 and of x2 separately, add the partials of a group's channels in a fixed order
+ * and finish mean / rstd in fp64: no finalize launch, no atomics, bit-reproducible; one tensor's
+ * statistics serve both the next block and, later, a skip concatenation whose groups straddle
+ * the two tensors. */
 int afldm_gn_stats_splits(int HW);
-int afldm_gn_stats(const void* x1, int C1, const void* x2, int C2, float* part, int B, int HW,
-                   int G, int dtype, afldm_stream_t stream);
+int afldm_gn_stats(const void* x, int C, float* stats, int B, int HW, int dtype, afldm_stream_t stream);
 /* y = act((x - mean) * rstd * gamma + beta); act: 0 none (Attention.group_norm),
  * 1 SiLU (conv_norm_out + conv_act, which make_af_unet does NOT wrap: af_api.py:70-83). */
-int afldm_gn_apply(const void* x1, int C1, const void* x2, int C2, const float* part,
-                   const float* gamma, const float* beta, void* y, int B, int HW, int G, float eps,
-                   int act, int dtype, afldm_stream_t stream);
+int afldm_gn_apply(const void* x1, int C1, const void* x2, int C2, const float* stats1, int S1,
+                   const float* stats2, int S2, const float* gamma, const float* beta, void* y, int B,
+                   int HW, int G, float eps, int act, int dtype, afldm_stream_t stream);
 
 /* ---- alias-free operators -----------------------------------------------------------------
  * afldm_af_act: [GroupNorm-apply ->] WarpedNonlinearity(SiLU) (af_blocks.py:19-28):
- *   y = D silu(U xn U^T) D^T per (b, c) plane,  xn = GN-applied x when part != NULL
- *   (part = the partial sums written by afldm_gn_stats for HW = N*N).
+ *   y = D silu(U xn U^T) D^T per (b, c) plane,  xn = GN-applied x when stats1 != NULL
+ *   (stats1 / stats2 = per-channel partial sums of x1 / x2, S1 / S2 their split counts).
  * x = virtual concat of x1/x2 as above, [B,N,N,C]; y [B,N,N,C].  N in {2,4,8,16,32}.
  * U: [2N x N], D: [N x 2N] device fp32 matrices from afldm_filter_matrix(0,N,2) / (1,2N,.). */
-int afldm_af_act(const void* x1, int C1, const void* x2, int C2, const float* part,
-                 const float* gamma, const float* beta, int G, float eps, const float* U,
-                 const float* D, const void* packed, void* y, int B, int N, int dtype,
+int afldm_af_act(const void* x1, int C1, const void* x2, int C2, const float* stats1, int S1,
+                 const float* stats2, int S2, const float* gamma, const float* beta, int G, float eps,
+                 const float* U, const float* D, const void* packed, void* y, int B, int N, int dtype,
                  afldm_stream_t stream);
 /* One-time packing of U / D into the kernel's LDS image for the MFMA plane sizes (N = 16, 32):
  * `packed` = device buffer of afldm_af_pack_bytes(N, dtype) bytes, passed to afldm_af_act. */
@@ -153,8 +157,8 @@ typedef struct {
   int dtype;
 } afldm_sep_args;
 int afldm_sep_pass(const afldm_sep_args* args, afldm_stream_t stream);
-/* table[b][c] = (rstd * gamma[c], beta[c] - mean * rstd * gamma[c]) from afldm_gn_stats partial sums */
-int afldm_gn_table(const float* part, const float* gamma, const float* beta, float* table, int B,
+/* table[b][c] = (rstd * gamma[c], beta[c] - mean * rstd * gamma[c]) from per-channel partial sums */
+int afldm_gn_table(const float* stats, int S, const float* gamma, const float* beta, float* table, int B,
                    int C, int G, int HW, float eps, afldm_stream_t stream);
 /* y[r][:] = softmax(x[r][:] * scale): the single-head d = 512 attention of the VAE mid block is
  * two GEMMs (afldm_conv2d with per-sample "weights") around this kernel. */
@@ -190,6 +194,10 @@ typedef struct {
    * ([B][Cout - split_n][H*W]), to y2 instead of y; y then holds couts [0, split_n) with y_ld. */
   void* y2;
   int split_n;
+  /* optional GroupNorm statistics of the OUTPUT (out_mode 0, no y2): per-channel partial sums
+   * stats_out[B][S][Cout][2] fp32 with S = afldm_conv2d_stats_splits(args), computed on the stored
+   * (rounded) values by the GEMM epilogue / the split-K reduction; NULL = none. */
+  float* stats_out;
 } afldm_conv_args;
 int afldm_conv2d(const afldm_conv_args* args, afldm_stream_t stream);
 /* Tuning hook (benchmarks only): force tile/pipeline variant `variant` (>= 0) and/or a split-K
@@ -197,6 +205,8 @@ int afldm_conv2d(const afldm_conv_args* args, afldm_stream_t stream);
 int afldm_conv2d_tune(int variant, int splitk);
 /* bytes of split-K workspace afldm_conv2d may use for this problem (0 if none). */
 size_t afldm_conv2d_workspace(const afldm_conv_args* args);
+/* split count S of the statistics afldm_conv2d writes to stats_out for this problem (> 0). */
+int afldm_conv2d_stats_splits(const afldm_conv_args* args);
 
 /* ---- attention ---------------------------------------------------------------------------
  * F.scaled_dot_product_attention as called by AttnProcessor2_0 / CrossFrameAttnProcessor

@@ -92,7 +92,7 @@ def test_groupnorm(dtype, C1, C2, G, HW):
     x2 = nhwc(x[:, C1:], dtype) if C2 else None
     st = ops.gn_stats(x1, G, x2=x2)
     xg = x.view(2, G, -1)
-    mean, rs = ops.gn_mean_rstd(st, xg.shape[-1], 1e-5)
+    mean, rs = ops.gn_mean_rstd(st, G, xg.shape[-1], 1e-5)
     assert (mean.cpu() - xg.mean(-1)).abs().max() < 1e-5
     rstd = 1.0 / torch.sqrt(xg.var(-1, unbiased=False) + 1e-5)
     assert ((rs.cpu() - rstd).abs() / rstd).max() < 1e-5
@@ -219,6 +219,49 @@ def test_conv2d_every_gemm_variant(dtype):
     finally:
         _lib.lib.afldm_conv2d_tune(-1, -1)
     assert nvar >= 37
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    (2, 32, 32, 64, 0, 192, 3, True),      # H*W % 128 == 0, no split-K: statistics from the GEMM epilogue
+    (2, 16, 16, 128, 64, 192, 3, True),    # virtual concat input, epilogue
+    (3, 8, 8, 128, 0, 64, 3, False),       # 64x64 tiles: one tile per sample
+    (2, 4, 4, 256, 256, 128, 3, True),     # split-K: statistics from the reduction kernel
+    (2, 2, 2, 256, 0, 128, 3, False),      # tiny plane, split-K
+    (2, 12, 12, 64, 0, 72, 3, False),      # H*W = 144: no fused producer -> stand-alone pass
+    (2, 32, 32, 4, 0, 192, 3, False),      # conv_in (direct kernel) -> stand-alone pass
+    (2, 16, 16, 192, 0, 192, 1, True),     # 1x1 (attention to_out + residual)
+])
+def test_conv2d_emits_groupnorm_statistics(dtype, case):
+    """conv2d(..., want_stats=True): the per-channel partial sums attached to the output must equal
+    those of a stand-alone pass over the stored tensor, whichever kernel produced them, and feed
+    gn_apply to the same result."""
+    ops = _ops()
+    B, H, W, C1, C2, Cout, KS, use_res = case
+    g = torch.Generator().manual_seed(21)
+    x = rnd(dtype, torch.randn(B, C1 + C2, H, W, generator=g))
+    w = rnd(dtype, torch.randn(Cout, C1 + C2, KS, KS, generator=g) / (KS * (C1 + C2) ** 0.5))
+    b = torch.randn(Cout, generator=g)
+    res = rnd(dtype, torch.randn(B, Cout, H, W, generator=g)) if use_res else None
+    y = ops.conv2d(nhwc(x[:, :C1], dtype), ops.pack_weight(w.cuda(), dtype), b.cuda(),
+                   x2=nhwc(x[:, C1:], dtype) if C2 else None, residual=nhwc(res, dtype) if use_res else None,
+                   want_stats=True)
+    assert hasattr(y, "gn_partial") and y.gn_partial.shape[0] == B and y.gn_partial.shape[2:] == (Cout, 2)
+    ref = F.conv2d(x, w, b, padding=KS // 2) + (res if use_res else 0)
+    close(back(y), ref, dtype, f"conv {case}", bf16_rms=6e-3)
+    yv = y.float()                                            # statistics are those of the STORED values
+    s1 = yv.sum((1, 2)).cpu()
+    s2 = (yv * yv).sum((1, 2)).cpu()
+    got = y.gn_partial.double().sum(1).cpu()
+    assert (got[..., 0] - s1).abs().max() <= 1e-4 * (1 + s1.abs().max()), f"sum {case}"
+    assert (got[..., 1] - s2).abs().max() <= 1e-4 * (1 + s2.abs().max()), f"sumsq {case}"
+    G = 8
+    gamma, beta = torch.randn(Cout, generator=g).cuda(), torch.randn(Cout, generator=g).cuda()
+    fused = ops.gn_apply(y, ops.gn_stats(y), gamma, beta, G, 1e-5)
+    plain = torch.empty_like(y)
+    plain.copy_(y)                                            # a copy carries no attached statistics
+    alone = ops.gn_apply(plain, ops.gn_stats(plain), gamma, beta, G, 1e-5)
+    assert (fused.float() - alone.float()).abs().max() <= (1e-5 if dtype == torch.float32 else 2e-2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -103,7 +103,7 @@ def bench_afact(dtype=torch.bfloat16):
         st = ops.gn_stats(x, 32)
         y = torch.empty_like(x)
         t = timeit(lambda: ops.af_act(x, None, st, gamma, beta, 32, 1e-5, out=y))
-        t2 = timeit(lambda: ops.gn_stats(x, 32, out=st))
+        t2 = timeit(lambda: ops.gn_stats(x, 32, out=st.st1))
         nbytes = 2 * x.numel() * x.element_size()
         print(f"af_act N={N:2d} C={C:4d}: {t:8.1f} us  {24.0*N**3*64*C/t/1e6:7.1f} TF(dense-eq)  {nbytes/t/1e3:7.1f} GB/s | "
               f"gn_stats {t2:6.1f} us {nbytes/2/t2/1e3:7.1f} GB/s", flush=True)
