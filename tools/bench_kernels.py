@@ -120,6 +120,26 @@ def bench_attn(dtype=torch.bfloat16):
         print(f"attn T={T:4d} heads={heads:2d}: {t:8.1f} us  {4.0*64*heads*T*T*24/t/1e6:7.1f} TF", flush=True)
 
 
+def bench_lin(dtype=torch.bfloat16):
+    """The short-K 1x1 GEMMs of an attention site at the 32x32 level: fused q|k|v and to_out (+residual, +stats)."""
+    B, T, C = 64, 1024, 192
+    x = torch.randn(B, T, C, device="cuda").to(dtype)
+    w3 = (torch.randn(3 * C, 1, 1, C, device="cuda") / C ** 0.5).to(dtype)
+    b3 = torch.randn(3 * C, device="cuda")
+    w1 = (torch.randn(C, 1, 1, C, device="cuda") / C ** 0.5).to(dtype)
+    b1 = torch.randn(C, device="cuda")
+    x4 = x.view(B, 32, 32, C)
+    res = torch.randn(B, 32, 32, C, device="cuda").to(dtype)
+    t = timeit(lambda: ops.linear_split(x, w3, b3, 2 * C))
+    print(f"qkv  [65536x192]x[192x576]: {t:7.1f} us  {(B*T*C*2 + B*T*3*C*2)/t/1e3:7.1f} GB/s", flush=True)
+    t = timeit(lambda: ops.conv2d(x4, w1, b1))
+    print(f"1x1  [65536x192]x[192x192]: {t:7.1f} us  {(B*T*C*2*2)/t/1e3:7.1f} GB/s", flush=True)
+    t = timeit(lambda: ops.conv2d(x4, w1, b1, residual=res))
+    print(f"1x1 + residual            : {t:7.1f} us  {(B*T*C*2*3)/t/1e3:7.1f} GB/s", flush=True)
+    t = timeit(lambda: ops.conv2d(x4, w1, b1, residual=res, want_stats=True))
+    print(f"1x1 + residual + stats    : {t:7.1f} us  {(B*T*C*2*3)/t/1e3:7.1f} GB/s", flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "conv"
-    {"conv": bench_conv, "afact": bench_afact, "attn": bench_attn}[what]()
+    {"conv": bench_conv, "afact": bench_afact, "attn": bench_attn, "lin": bench_lin}[what]()
