@@ -95,3 +95,78 @@ def shift_ldm(pipeline, num_inference_steps=50, num_shift_steps=16, output_path=
     if ordered and rank == 0 and output_path:
         save_gif_from_tensors(ordered, output_path, denorm=True)
     return ordered, [errors[i] for i in sorted(errors)]
+
+
+def vae_encode_mode(vae, x):
+    """reference scripts/shift_ldm_sr.py:31-34 (the SR harness encodes with the posterior mode)."""
+    return vae.encode(x).latent_dist.mode() * vae.config.scaling_factor
+
+
+@torch.no_grad()
+def shift_ldm_sr(pipeline, num_inference_steps=50, num_shift_steps=16, output_path="results/shift_ldm_sr.gif",
+                 input_path=None, image=None, rank=0, world=1):
+    """Fractional-shift equivariance of x4 super-resolution with I2SB - the flow of reference
+    scripts/shift_ldm_sr.py:43-150: degrade (bicubic x1/4, nearest x4), VAE-encode, denoise with
+    cross-frame attention STORE, then for every offset shift the initial latent, denoise in LOAD mode
+    and compare with the shifted reconstruction.  `image` ([1,3,H,W] in [-1,1]) replaces
+    `input_path` when given; the offsets are sharded across ranks."""
+    from .af_libs.superresolution import build_sr4x
+    device = pipeline.device
+    vae, unet, scheduler = pipeline.vae, pipeline.unet, pipeline.scheduler
+    pipeline.set_progress_bar_config(disable=True)
+    ratio = 2 ** (len(vae.up_block_types) - 1)
+    size = unet.config.sample_size * ratio
+    sr_func = build_sr4x(device, "bicubic", size)
+    latent_shifter = ImageShifter("ideal_crop", ratio)
+    image_shifter = ImageShifter()
+
+    attn_state = AttnState()
+    previous = get_unet_attn_processors(unet)
+    set_unet_attn_processor(unet, {k: CrossFrameAttnProcessor(attn_state) for k in previous})
+
+    def denoise(latents):
+        latents = latents.to(device)
+        scheduler.set_timesteps(num_inference_steps, device=device)
+        ts = scheduler.timesteps
+        for i, t in enumerate(ts):
+            if i == num_inference_steps - 1:
+                break
+            attn_state.set_timestep(t)
+            eps = unet(scheduler.scale_model_input(latents, t), t, return_dict=False)[0]
+            latents = scheduler.step(eps, t, latents, is_ode=True, generator=None).prev_sample
+        return latents
+
+    try:
+        if image is None:
+            image = image_to_tensor(input_path, (size, size))
+        tensor = sr_func(image.to(device).float()).clip(-1, 1)
+        init_latent = vae_encode_mode(vae, tensor.to(vae.dtype)).to(unet.dtype)
+        attn_state.reset()
+        denoised = denoise(init_latent)
+        attn_state.to_load()
+        rec_img = vae_decode(vae, denoised)
+        offsets = torch.linspace(1 / ratio, num_shift_steps / ratio, num_shift_steps)
+        frames, errors = {}, {}
+        for i in range(rank, num_shift_steps, world):
+            tj = float(offsets[i])
+            shifted, mask = latent_shifter.shift(init_latent, 0, tj)
+            den = denoise(shifted)
+            ref_lat, _ = latent_shifter.shift(denoised, 0, tj)
+            errors[i] = float(mask_mse(den, ref_lat, mask))
+            gt, _ = image_shifter.shift(rec_img, 0, tj * ratio)
+            img_in = vae_decode(vae, shifted * mask)
+            img = vae_decode(vae, den * mask)
+            frames[i] = torch.cat((img_in, img, gt, torch.abs(img - gt)), -2).float().cpu()
+    finally:
+        set_unet_attn_processor(unet, dict(previous))
+
+    if world > 1:
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, (frames, errors))
+        frames = {k: v for f, _ in gathered for k, v in f.items()}
+        errors = {k: v for _, e in gathered for k, v in e.items()}
+    ordered = [frames[i] for i in sorted(frames)]
+    if ordered and rank == 0 and output_path:
+        save_gif_from_tensors(ordered, output_path, denorm=True)
+    return ordered, [errors[i] for i in sorted(errors)]
+

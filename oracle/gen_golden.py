@@ -24,6 +24,14 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 
 
 def _import_reference():
+    # the repository ships an `afldm` alias package (afldm.X -> afldm_amd.X); the reference's `afldm`
+    # is a namespace package and would lose to it: drop the repo root from the search path and any
+    # already-imported alias modules before importing the reference
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:] = [q for q in sys.path if os.path.abspath(q or ".") != root]
+    for k in list(sys.modules):
+        if k == "afldm" or k.startswith("afldm."):
+            del sys.modules[k]
     if REF not in sys.path:
         sys.path.insert(0, REF)
     # numba is absent here; shifters -> flow_utils -> flow_utils_np needs only the decorator name
@@ -206,6 +214,25 @@ def part_c():
     np.savez_compressed(os.path.join(OUT, "g8_tiny_vae.npz"), **g)
 
 
+def part_d():
+    """x4 super-resolution degrade operator: outputs of the IMPORTED reference build_sr4x
+    (afldm/af_libs/superresolution.py:288-320) on seeded images (64^2 in full, 256^2 as a crop)."""
+    _import_reference()
+    from afldm.af_libs.superresolution import build_sr4x as ref_build
+    gen = torch.Generator().manual_seed(91)
+    g = {}
+    x64 = torch.rand(2, 3, 64, 64, generator=gen) * 2 - 1
+    g["x64"] = x64.numpy()
+    for flt in ("bicubic", "pool"):
+        g[f"y64_{flt}"] = ref_build("cpu", flt, 64)(x64.clone()).numpy()
+    x256 = torch.rand(1, 3, 256, 256, generator=gen) * 2 - 1
+    g["x256"] = x256.numpy().astype(np.float16)          # stored at half precision (size); inputs are what they are
+    y = ref_build("cpu", "bicubic", 256)(torch.from_numpy(g["x256"].astype(np.float32)))
+    g["y256_bicubic_crop"] = y[:, :, 96:160, 96:160].numpy()
+    g["y256_bicubic_sum"] = np.array([float(y.double().sum()), float((y.double() ** 2).sum())])
+    np.savez_compressed(os.path.join(OUT, "g9_sr4x.npz"), **g)
+
+
 def idf_warp(x):
     from .ideal_filters import warped_nonlinearity
     return warped_nonlinearity(x)
@@ -220,5 +247,7 @@ if __name__ == "__main__":
         part_b()
     if which in ("c", "all"):
         part_c()
+    if which in ("d", "all"):
+        part_d()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

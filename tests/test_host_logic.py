@@ -218,3 +218,13 @@ def test_i2sb_scheduler_tables_and_known_answers():
     assert torch.allclose(s.compute_label(ts, x0, xt), o.compute_label(ts, x0, xt))
     with pytest.raises(RuntimeError, match="MI355X"):
         s.step(x0, 991, x1)
+
+
+def test_sr4x_degrade_matrix_matches_oracle():
+    """The host-built degrade matrix of the product equals the oracle's (same SVD truncation)."""
+    from afldm_amd.af_libs.superresolution import degrade_matrix
+    from oracle.superresolution import degrade_matrix as ref
+    for flt in ("bicubic", "pool"):
+        for n in (64, 256):
+            assert (degrade_matrix(flt, n) - ref(flt, n)).abs().max() < 1e-6
+

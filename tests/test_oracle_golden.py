@@ -133,3 +133,22 @@ def test_scheduler_known_answers():
     assert abs(float(e[0]) - 0.6799572) < 1e-5       # cos[0]
     assert abs(float(e[95]) - 0.9941760) < 1e-5      # cos[95]
     assert abs(float(e[96]) - 0.7332518) < 1e-5      # sin[0]
+
+
+def test_sr4x_degrade_matches_reference_fixture(golden):
+    """oracle.superresolution.build_sr4x vs outputs of the imported reference build_sr4x
+    (afldm/af_libs/superresolution.py:288-320; fixtures: oracle/gen_golden.py part d)."""
+    from oracle.superresolution import build_sr4x
+    g = golden("g9_sr4x.npz")
+    x = torch.from_numpy(g["x64"])
+    for flt in ("bicubic", "pool"):
+        y = build_sr4x(flt, 64)(x)
+        assert (y - torch.from_numpy(g[f"y64_{flt}"])).abs().max() < 1e-6, flt
+    x256 = torch.from_numpy(g["x256"].astype(np.float32))
+    y = build_sr4x("bicubic", 256)(x256)
+    assert (y[:, :, 96:160, 96:160] - torch.from_numpy(g["y256_bicubic_crop"])).abs().max() < 1e-6
+    assert abs(float(y.double().sum()) - g["y256_bicubic_sum"][0]) < 1e-2
+    assert abs(float((y.double() ** 2).sum()) - g["y256_bicubic_sum"][1]) < 1e-2
+    y3 = build_sr4x("bicubic", 64)(x[0])                      # 3-D input keeps its rank
+    assert y3.shape == (3, 64, 64)
+
