@@ -735,18 +735,20 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
 }
 
 // split-K reduction that also emits the per-channel GroupNorm partial sums of the output: one
-// workgroup = (sample, row split, 64 channel quads); thread (quad, row lane 0..3) owns 4 channels and
-// every 4th row of the split; the 4 row lanes are combined in a fixed order through LDS.
-template <typename T>
+// workgroup = (sample, row split, 256 / RL channel quads); thread (quad, row lane) owns 4 channels
+// and every RL-th row of the split; the row lanes are combined in a fixed order through LDS.
+// RL = 16 where a split has 16 rows (4x4 and 8x8 levels), 4 for the 2x2 level.
+template <typename T, int RL>
 __global__ void __launch_bounds__(256) k_splitk_reduce_stats(ConvP p, int rows_per_split) {
-  __shared__ float red[4][64][8];
-  const int HW = p.H * p.W, nq = p.Cout / 4, nqb = (nq + 63) / 64;
+  constexpr int QL = 256 / RL;
+  __shared__ float red[RL][QL][8];
+  const int HW = p.H * p.W, nq = p.Cout / 4, nqb = (nq + QL - 1) / QL;
   int bid = blockIdx.x;
   const int qb = bid % nqb;
   bid /= nqb;
   const int sp = bid % p.stats_S, b = bid / p.stats_S;
-  const int tq = threadIdx.x & 63, tr = threadIdx.x >> 6;
-  const int q = qb * 64 + tq;
+  const int tq = threadIdx.x % QL, tr = threadIdx.x / QL;
+  const int q = qb * QL + tq;
   const bool live = q < nq;
   const int n = 4 * q;
   const int r0 = sp * rows_per_split, r1 = r0 + rows_per_split < HW ? r0 + rows_per_split : HW;
@@ -759,7 +761,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_stats(ConvP p, int rows_p
     if (has_b) bt = *reinterpret_cast<const f32x4*>(p.bias + n);
     float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
     if (temb) load4<T>(temb + (size_t)b * p.temb_stride + n, t0, t1, t2, t3);
-    for (int pix = r0 + tr; pix < r1; pix += 4) {
+    for (int pix = r0 + tr; pix < r1; pix += RL) {
       const size_t m = (size_t)b * HW + pix;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       for (int sl = 0; sl < p.splitk; ++sl) v += *reinterpret_cast<const f32x4*>(p.ws + ((size_t)sl * p.M + m) * p.Cout + n);
@@ -790,8 +792,12 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_stats(ConvP p, int rows_p
   if (tr == 0 && live) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float a1 = ((red[0][tq][2 * e] + red[1][tq][2 * e]) + red[2][tq][2 * e]) + red[3][tq][2 * e];
-      const float a2 = ((red[0][tq][2 * e + 1] + red[1][tq][2 * e + 1]) + red[2][tq][2 * e + 1]) + red[3][tq][2 * e + 1];
+      float a1 = red[0][tq][2 * e], a2 = red[0][tq][2 * e + 1];
+#pragma unroll
+      for (int r = 1; r < RL; ++r) {
+        a1 += red[r][tq][2 * e];
+        a2 += red[r][tq][2 * e + 1];
+      }
       *reinterpret_cast<f32x2*>(p.stats_out + (((size_t)b * p.stats_S + sp) * p.Cout + n + e) * 2) = f32x2{a1, a2};
     }
   }
@@ -1256,9 +1262,15 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
     if (p.splitk > 1) {
       if (smode == ST_REDUCE) {
         p.stats_out = a->stats_out;
-        const int HW = a->H * a->W, nqb = (p.Cout / 4 + 63) / 64;
+        const int HW = a->H * a->W;
         const int rows = (HW + p.stats_S - 1) / p.stats_S;
-        k_splitk_reduce_stats<T><<<a->B * p.stats_S * nqb, 256, 0, st>>>(p, rows);
+        if (rows >= 16) {
+          const int nqb = (p.Cout / 4 + 15) / 16;
+          k_splitk_reduce_stats<T, 16><<<a->B * p.stats_S * nqb, 256, 0, st>>>(p, rows);
+        } else {
+          const int nqb = (p.Cout / 4 + 63) / 64;
+          k_splitk_reduce_stats<T, 4><<<a->B * p.stats_S * nqb, 256, 0, st>>>(p, rows);
+        }
       } else {
         size_t total = (size_t)p.M * ((p.Cout + 3) / 4);
         int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
