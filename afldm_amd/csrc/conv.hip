@@ -602,23 +602,8 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
       if (etid < RPI * CPR) {
         const int ch = etid % CPR;
         const int n = n0 + ch * EO;
-        constexpr int RPT = (PROWS + RPI - 1) / RPI;     // rows per thread per pass
-        const bool fast = p.stage_ok && n + EO <= nhwc_end;
-        // the residual rows of this thread are fetched up front: one HBM latency per pass, not per row
-        Chunk rres[RPT];
-        if (res && fast) {
-#pragma unroll
-          for (int k = 0; k < RPT; ++k) {
-            const int row = etid / CPR + k * RPI;
-            const int mt = row / (TMP * 16), rr = row - mt * (TMP * 16);
-            const int m = m0 + mt * WMS + ps * TMP * 16 + rr;
-            if (row < PROWS && m < p.M) rres[k] = ld16<Chunk>(res + (size_t)m * p.res_ld + n);
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-          const int row = etid / CPR + k * RPI;
-          if (row >= PROWS) continue;
+#pragma unroll 1
+        for (int row = etid / CPR; row < PROWS; row += RPI) {
           const int mt = row / (TMP * 16), rr = row - mt * (TMP * 16);
           const int m = m0 + mt * WMS + ps * TMP * 16 + rr;
           if (m >= p.M || n >= nhwc_end) continue;
@@ -629,7 +614,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
             v[4 * q] = a[0]; v[4 * q + 1] = a[1]; v[4 * q + 2] = a[2]; v[4 * q + 3] = a[3];
           }
           const int b = m / HW;
-          if (fast) {
+          if (p.stage_ok && n + EO <= nhwc_end) {
             if (p.bias) {
 #pragma unroll
               for (int q = 0; q < EO / 4; ++q) {
@@ -643,8 +628,9 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
               for (int e = 0; e < EO; ++e) v[e] += to_f32(tv[e]);
             }
             if (res) {
+              const Chunk rv = ld16<Chunk>(res + (size_t)m * p.res_ld + n);
 #pragma unroll
-              for (int e = 0; e < EO; ++e) v[e] += to_f32(rres[k][e]);
+              for (int e = 0; e < EO; ++e) v[e] += to_f32(rv[e]);
             }
             Chunk o;
 #pragma unroll
