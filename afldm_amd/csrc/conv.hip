@@ -1016,12 +1016,29 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
   int vid, bm, bn;
   const int ksteps_all = a->KS * a->KS * (Ct / kstep);
   const long long tiles64 = ((M + 63) / 64) * ((a->Cout + 63) / 64);
-  if (M <= 4096 && ((ksteps_all <= 64 && tiles64 >= 256) || (ksteps_all <= 16 && tiles64 >= 128))) { vid = 32; bm = 64; bn = 64; }
+  if (M <= 4096 && ((ksteps_all <= 64 && tiles64 >= 256 && !(a->Cout % 192 == 0 && ksteps_all >= 27 && M >= 4096)) ||
+                    (ksteps_all <= 16 && tiles64 >= 128))) { vid = 32; bm = 64; bn = 64; }
   else if (M >= 32768 && a->Cout % 192 == 0) { vid = 29; bm = 128; bn = 192; }
   else if (a->Cout % 192 == 0 && ((M >= 4096 && ksteps_all >= 27) || (M >= 1024 && ksteps_all >= 100))) { vid = 33; bm = 128; bn = 192; }
   else if (M >= 4096 && a->Cout % 128 == 0 && a->KS > 1) { vid = 30; bm = 128; bn = 128; }
   else if (M >= 1024) { vid = 31; bm = 128; bn = 64; }
   else { vid = 32; bm = 64; bn = 64; }
+  // in-situ tuning hook (tools/tune_insitu.py): AFLDM_CONV_OVERRIDE="M:Cout:KS:Ct=variant/splitk;..."
+  int ov_sk = -1;
+  {
+    static const char* ov = getenv("AFLDM_CONV_OVERRIDE");
+    if (ov) {
+      for (const char* q = ov; q && *q;) {
+        long long m_ = 0; int co = 0, ks = 0, ct = 0, v = -1, sk_ = -1;
+        if (sscanf(q, "%lld:%d:%d:%d=%d/%d", &m_, &co, &ks, &ct, &v, &sk_) == 6 && m_ == M && co == a->Cout && ks == a->KS &&
+            ct == Ct && v >= 0 && v < kNumVariants) {
+          vid = v; bm = kVariants[v].bm; bn = kVariants[v].bn; ov_sk = sk_;
+        }
+        q = strchr(q, ';');
+        if (q) ++q;
+      }
+    }
+  }
   if (g_force_variant >= 0 && g_force_variant < kNumVariants) {
     vid = g_force_variant; bm = kVariants[vid].bm; bn = kVariants[vid].bn;
   }
@@ -1037,8 +1054,8 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
     if (sk > 8) sk = 8;
     if (sk < 1) sk = 1;
   } else if (tiles < 256 && ksteps > 16) {   // (short K: a split only adds the reduction pass)   // measured: ~320 workgroups is the sweet spot (conv_variant_sweep2/4.log)
-    const int cap = ksteps >= 192 ? 8 : 4;      // very long K (L4 / L2 concat convs): 8 slices measured +10 %
-    sk = (int)(((cap == 8 ? 768 : 320) + tiles - 1) / tiles);
+    const int cap = ksteps >= 100 ? 8 : 4;      // long K (the 4x4 / 2x2 levels): 8 slices measured best in situ
+    sk = (int)(((ksteps >= 192 ? 768 : (cap == 8 ? 384 : 320)) + tiles - 1) / tiles);
     int maxsk = ksteps / 4;
     if (maxsk < 1) maxsk = 1;
     if (sk > maxsk) sk = maxsk;
@@ -1046,6 +1063,7 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
     if (sk < 1) sk = 1;
   }
   pl.splitk = sk;
+  if (ov_sk >= 1) pl.splitk = ov_sk;
   if (g_force_splitk >= 1) pl.splitk = g_force_splitk;
   return pl;
 }
