@@ -12,7 +12,8 @@ F32, BF16 = 0, 1
 DTYPE_CODE = {torch.float32: F32, torch.bfloat16: BF16}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libafldm_hip.so")
+# AFLDM_LIB: alternative build of the same library (A/B timing of kernel changes on one GPU box)
+LIB_PATH = os.environ.get("AFLDM_LIB") or os.path.join(_HERE, "lib", "libafldm_hip.so")
 
 
 class ConvArgs(Structure):

@@ -77,7 +77,10 @@ struct PlaneCfg {
   static constexpr int CONST_ELEMS = NFRAG * 64 * EPC;
   static constexpr int XS = CH * N * KHP;                  // X tile; re-used as the output staging tile Ys
   static constexpr int VT = N * H2P;                       // per wave: V^T of one plane
-  static constexpr int LDS_BYTES = (CONST_ELEMS + XS + NW * VT) * (int)sizeof(T) + 2 * 16 * (int)sizeof(float);
+  // bf16: the constant fragments are copied to registers once, so their LDS image shares the Vt
+  // region (N = 32, 8-channel items: 54 -> 38 KB, three workgroups per CU instead of two)
+  static constexpr int CV = CREG ? (CONST_ELEMS > NW * VT ? CONST_ELEMS : NW * VT) : CONST_ELEMS + NW * VT;
+  static constexpr int LDS_BYTES = (XS + CV) * (int)sizeof(T) + 2 * 16 * (int)sizeof(float);
   static_assert(N * YRP <= XS, "output staging tile must fit in the X region");
   static_assert(NW * 16 * 2 * 8 <= NW * VT * (int)sizeof(T), "GroupNorm reduction scratch aliases Vt");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -157,10 +160,10 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
   constexpr int NT = CF::NW * 64, TN = CF::TN, TH = CF::TH, NKF1 = CF::NKF1, NKF3 = CF::NKF3, CPW = CF::CPW;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* Cs = reinterpret_cast<T*>(smem);
-  T* Xs = Cs + CF::CONST_ELEMS;
-  T* Vt = Xs + CF::XS;
-  float* gsc = reinterpret_cast<float*>(Vt + CF::NW * CF::VT);
+  T* Xs = reinterpret_cast<T*>(smem);
+  T* Cs = Xs + CF::XS;                                   // constants (aliased by Vt when they live in registers)
+  T* Vt = CF::CREG ? Cs : Cs + CF::CONST_ELEMS;
+  float* gsc = reinterpret_cast<float*>(Cs + CF::CV);
   float* gsh = gsc + 16;   // (16 slots, CH used)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -183,6 +186,7 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
 #pragma unroll
     for (int f = 0; f < CF::NFRAG; ++f) creg[f] = ld16<Chunk>(Cs + (f * 64 + lane) * EPC);
   }
+  if constexpr (CF::CREG) __syncthreads();   // every wave has its copy before Vt (same LDS bytes) is written
   auto cfrag = [&](int f) -> Chunk {
     if constexpr (CF::CREG) return creg[f];
     else return ld16<Chunk>(Cs + (f * 64 + lane) * EPC);
@@ -692,7 +696,7 @@ __global__ void __launch_bounds__(256) k_axis_contract_reg(const TI* __restrict_
 template <typename T, int N, int CH>
 static int af_plane_wgs_per_cu() {
   const int by_lds = (160 * 1024) / PlaneCfg<T, N, CH>::LDS_BYTES;
-  const int by_regs = N == 32 ? 2 : 4;
+  const int by_regs = N == 32 ? (CH == 8 && sizeof(T) == 2 ? 3 : 2) : 4;
   return by_lds < 1 ? 1 : (by_lds < by_regs ? by_lds : by_regs);
 }
 template <typename T, int N, int CH>
@@ -726,7 +730,10 @@ static int launch_af_mfma(const AfP<T>& p, hipStream_t st) {
   const long long slots16 = (long long)cus * af_plane_wgs_per_cu<T, N, 16>(), slots8 = (long long)cus * af_plane_wgs_per_cu<T, N, 8>();
   const long long items16 = (long long)p.B * (Ct / 16), items8 = 2 * items16;
   const double t16 = (double)((items16 + slots16 - 1) / slots16), t8 = 0.65 * (double)((items8 + slots8 - 1) / slots8);
-  if (t8 < t16 && p.C1 % 8 == 0) return launch_af_plane<T, N, 8>(p, cus, st);
+  // (8-channel items read 16-byte pieces of every pixel: only worth it while the tensor stays
+  //  cache-resident between the two item passes over a line - measured 1.15x slower per round at 75 MB)
+  const size_t bytes = (size_t)p.B * N * N * Ct * sizeof(T);
+  if (t8 < t16 && p.C1 % 8 == 0 && bytes <= (40u << 20)) return launch_af_plane<T, N, 8>(p, cus, st);
   return launch_af_plane<T, N, 16>(p, cus, st);
 }
 template <typename T, int N>
