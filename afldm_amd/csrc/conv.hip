@@ -491,6 +491,10 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) MM::mma(acc[tn][tm], a[tn], b[tm]);
+      // two compute waves per SIMD (8 consumers): the partner wave covers this wave's LDS latency,
+      // so the fragments of the next K chunk are NOT prefetched (saves 40 registers: no spills at
+      // the 170-register budget of 12 waves per CU)
+      if constexpr (NPROD > 0 && NWC >= 8) __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -1132,7 +1136,7 @@ static bool launch_variant(int id, const ConvP& p, hipStream_t st) {
     case 23: launch_igemm2<T, 128, 128, 2, 2, 2, 2, 4>(p, st); return true;
     case 24: launch_igemm2<T, 128, 128, 2, 2, 3, 2, 4>(p, st); return true;
     case 25: launch_igemm2<T, 128, 192, 2, 2, 2, 2, 2>(p, st); return true;
-    case 26: launch_igemm2<T, 256, 192, 4, 2, 2, 2, 4>(p, st); return true;
+    case 26: launch_igemm2<T, 256, 192, 4, 2, 2, 2, 4, true, 3>(p, st); return true;
     case 27: launch_igemm2<T, 256, 128, 4, 2, 2, 2, 4>(p, st); return true;
     case 28: launch_igemm2<T, 128, 64, 2, 2, 3, 2, 2>(p, st); return true;
     case 29: launch_igemm2<T, 128, 192, 2, 2, 2, 2, 0, true, 2>(p, st); return true;

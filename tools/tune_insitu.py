@@ -16,6 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # name: (M, Cout, KS, Ct), candidates "variant/splitk" (first = current policy)
 SHAPES = {
     "S1 L32 3x3 192->192": ((65536, 192, 3, 192), ["29/1", "12/1", "26/1", "33/1"]),
+    "S1b L32 3x3 576->192": ((65536, 192, 3, 576), ["29/1", "26/1", "33/1"]),
+    "S1c L32 3x3 384->192": ((65536, 192, 3, 384), ["29/1", "26/1", "33/1"]),
+    "S1d L32 3x3 384->384": ((65536, 384, 3, 384), ["29/1", "26/1", "33/1"]),
     "S2 L16 3x3 384->384": ((16384, 384, 3, 384), ["33/1", "29/1", "30/1", "22/1"]),
     "S2b L16 3x3 768->384": ((16384, 384, 3, 768), ["33/1", "29/1", "30/1"]),
     "S3 L8 3x3 384->384": ((4096, 384, 3, 384), ["32/1", "33/4", "33/2", "31/2", "11/1"]),
