@@ -396,7 +396,8 @@ struct KronCfg {
   static constexpr int KU_ELEMS = Q * PK, KD_ELEMS = PR * Q;
   static constexpr int CONST_ELEMS = KU_ELEMS + KD_ELEMS;
   static constexpr int XK = 16 * PK;                        // per-wave transposed X tile
-  static constexpr int LDS_BYTES = (CONST_ELEMS + 4 * XK) * (int)sizeof(T);
+  static constexpr int YS = PR * 16;                        // per-wave output staging tile [px][16 c]
+  static constexpr int LDS_BYTES = (CONST_ELEMS + 4 * (XK + YS)) * (int)sizeof(T);
 };
 
 template <typename T, int N>
@@ -409,7 +410,7 @@ __global__ void k_af_pack_kron(const float* __restrict__ U, const float* __restr
       const int q = i / PK, pp = i - q * PK;
       if (pp < P) {
         const int hp = q / H2, wp = q - hp * H2, h = pp / N, w = pp - h * N;
-        v = U[hp * N + h] * U[wp * N + w];
+        v = U[hp * N + h] * U[wp * N + w] * 1.4426950408889634f;   // SiLU works on z log2(e) (see silu_log2_x4)
       }
     } else {
       const int j = i - CF::KU_ELEMS;
@@ -421,7 +422,7 @@ __global__ void k_af_pack_kron(const float* __restrict__ U, const float* __restr
       }
       if (pr < P) {
         const int h = pr / N, w = pr - h * N, hp = k / H2, wp = k - hp * H2;
-        v = D[h * H2 + hp] * D[w * H2 + wp];
+        v = D[h * H2 + hp] * D[w * H2 + wp] * 0.6931471805599453f;
       }
     }
     out[i] = from_f32<T>(v);
@@ -440,7 +441,8 @@ __global__ void __launch_bounds__(256) k_af_act_kron(AfP<T> p) {
   T* KU = reinterpret_cast<T*>(smem);
   T* KD = KU + CF::KU_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  T* Xk = KD + CF::KD_ELEMS + wave * CF::XK;   // this wave's [16 c][PK] tile
+  T* Xk = KD + CF::KD_ELEMS + wave * (CF::XK + CF::YS);   // this wave's [16 c][PK] tile
+  T* Ys = Xk + CF::XK;                                      // ... and its [px][16 c] output staging tile
   const int li = lane & 15, lg = lane >> 4;
   const int Ct = p.C1 + p.C2, ctiles = Ct / 16, nitems = p.B * ctiles;
   const int cpg = p.gs.st1 ? Ct / p.G : 1;
@@ -487,7 +489,8 @@ __global__ void __launch_bounds__(256) k_af_act_kron(AfP<T> p) {
       usc[cc] = __shfl(sc, (lane % CQ) * EPC + cc, 64);
       ush[cc] = __shfl(sh, (lane % CQ) * EPC + cc, 64);
     }
-    __syncthreads();   // previous group's GEMM1 reads of Xk are complete
+    // (Xk / Ys are private to the wave and same-wave LDS operations are ordered: no workgroup barrier,
+    //  the four waves drift apart and overlap their load / MFMA / store phases)
     if (live) {
       for (int u = lane; u < UNITS; u += 64) {
         const int cq = u % CQ, pq = u / CQ;
@@ -504,7 +507,6 @@ __global__ void __launch_bounds__(256) k_af_act_kron(AfP<T> p) {
         }
       }
     }
-    __syncthreads();
 
     // ---- GEMM1 + SiLU
     Chunk xf[NKF1];
@@ -516,8 +518,7 @@ __global__ void __launch_bounds__(256) k_af_act_kron(AfP<T> p) {
       z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kf = 0; kf < NKF1; ++kf) MM::mma(z[t], ld16<Chunk>(KU + (16 * t + li) * PK + kf * KPF + lg * EPC), xf[kf]);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) z[t][r] = silu_f(z[t][r]);
+      z[t] = silu_log2_x4(z[t]);
     }
     // ---- GEMM2 (chained) + store: lane (c = li, g) holds pixels 16 t + 4 g + r
     Chunk pb[NKF2];
@@ -533,12 +534,14 @@ __global__ void __launch_bounds__(256) k_af_act_kron(AfP<T> p) {
       f32x4 y = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int f = 0; f < NKF2; ++f) MM::mma(y, ld16<Chunk>(KD + (16 * t + li) * Q + f * KPF + lg * EPC), pb[f]);
-      if (live) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int px = 16 * t + 4 * lg + r;
-          if (px < P) p.y[((size_t)b * P + px) * Ct + c0 + li] = from_f32<T>(y[r]);
-        }
+      for (int r = 0; r < 4; ++r) Ys[(16 * t + 4 * lg + r) * 16 + li] = from_f32<T>(y[r]);
+    }
+    if (live) {   // 16-byte stores: two (bf16) / four (fp32) lanes per pixel
+      constexpr int CPP = 16 / EPC;
+      for (int i = lane; i < P * CPP; i += 64) {
+        const int px = i / CPP, q = i - px * CPP;
+        st16<Chunk>(p.y + ((size_t)b * P + px) * Ct + c0 + q * EPC, ld16<Chunk>(Ys + px * 16 + q * EPC));
       }
     }
   }
