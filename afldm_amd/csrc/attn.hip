@@ -79,30 +79,10 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnP<T> p) {
   const int q0 = (qb * NW + wave) * 32;
   const int C = p.heads * p.d;
 
-  // ---- LDS padding is written ONCE: K pieces beyond head_dim and V^T rows beyond head_dim stay
-  // zero in both buffers, V^T row `d` is all ones (-> row d of O^T accumulates the softmax
-  // denominator on the MFMA pipe, no VALU adds), K channel slot `d` is a constant 1 (Q carries
-  // -m_run there); the chunk loop only rewrites the live pieces.
-  for (int idx = tid; idx < SMEM_BYTES / 16; idx += NT) st16<Chunk>(smem + idx * 16, MM::zero());
-  __syncthreads();
   const int kf_pad = p.d / KPF, lg_pad = (p.d % KPF) / EPC;
-  for (int idx = tid; idx < 2 * NPV * 4 + 2 * KC; idx += NT) {
-    if (idx < 2 * NPV * 4) {
-      Chunk ones;
-#pragma unroll
-      for (int e = 0; e < EPC; ++e) ones[e] = from_f32<T>(1.0f);
-      const int bsel = idx / (NPV * 4), rem = idx % (NPV * 4);
-      st16<Chunk>(sV + bsel * VT_BYTES + ((rem >> 2) * ND * 16 + p.d) * 64 + ((rem & 3) << 4), ones);
-    } else {
-      Chunk one0 = MM::zero();
-      one0[0] = from_f32<T>(1.0f);
-      const int r2 = idx - 2 * NPV * 4;
-      const int bsel = r2 / KC, row = r2 % KC;
-      st16<Chunk>(sK + bsel * KT_BYTES + (kf_pad * KC + row) * 64 + ((lg_pad ^ aswz(row)) << 4), one0);
-    }
-  }
 
-  // ---- Q fragments (pre-scaled), two 16-query tiles
+  // ---- Q fragments, two 16-query tiles (raw loads first: every global load of the prologue is
+  // issued before anything waits on one)
   Chunk qf[2][NKF];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
@@ -112,10 +92,7 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnP<T> p) {
 #pragma unroll
     for (int kf = 0; kf < NKF; ++kf) {
       const int e0 = kf * KPF + lg * EPC;
-      Chunk c = (qok && e0 + EPC <= p.d) ? ld16<Chunk>(qptr + e0) : MM::zero();
-#pragma unroll
-      for (int e = 0; e < EPC; ++e) c[e] = from_f32<T>(to_f32(c[e]) * p.scale_log2e);
-      qf[u][kf] = c;
+      qf[u][kf] = (qok && e0 + EPC <= p.d) ? ld16<Chunk>(qptr + e0) : MM::zero();   // scaled below, after the K / V loads are out
     }
   }
 
@@ -349,9 +326,37 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnP<T> p) {
   Chunk rkA[KPT], rvA[VPT], rkB[KPT], rvB[VPT];
   const int nchunks = (p.Tk + KC - 1) / KC;
   load_chunk(0, 1 < nchunks, rkA, rvA);     // pointers now at chunk 1 (if there is one)
+  load_chunk(KC, 2 < nchunks, rkB, rvB);    // chunk 1 (or chunk 0 again when there is only one)
+  // ---- LDS padding is written ONCE: K pieces beyond head_dim and V^T rows beyond head_dim stay
+  // zero in both buffers, V^T row `d` is all ones (-> row d of O^T accumulates the softmax
+  // denominator on the MFMA pipe, no VALU adds), K channel slot `d` is a constant 1 (Q carries
+  // -m_run there); the chunk loop only rewrites the live pieces.
+  for (int idx = tid; idx < SMEM_BYTES / 16; idx += NT) st16<Chunk>(smem + idx * 16, MM::zero());
+  __syncthreads();
+  for (int idx = tid; idx < 2 * NPV * 4 + 2 * KC; idx += NT) {
+    if (idx < 2 * NPV * 4) {
+      Chunk ones;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) ones[e] = from_f32<T>(1.0f);
+      const int bsel = idx / (NPV * 4), rem = idx % (NPV * 4);
+      st16<Chunk>(sV + bsel * VT_BYTES + ((rem >> 2) * ND * 16 + p.d) * 64 + ((rem & 3) << 4), ones);
+    } else {
+      Chunk one0 = MM::zero();
+      one0[0] = from_f32<T>(1.0f);
+      const int r2 = idx - 2 * NPV * 4;
+      const int bsel = r2 / KC, row = r2 % KC;
+      st16<Chunk>(sK + bsel * KT_BYTES + (kf_pad * KC + row) * 64 + ((lg_pad ^ aswz(row)) << 4), one0);
+    }
+  }
+
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int kf = 0; kf < NKF; ++kf)
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) qf[u][kf][e] = from_f32<T>(to_f32(qf[u][kf][e]) * p.scale_log2e);
   __syncthreads();       // zero fill / constant rows complete before the live pieces land
   store_chunk(0, rkA, rvA);
-  load_chunk(KC, 2 < nchunks, rkB, rvB);    // chunk 1 (or chunk 0 again when there is only one)
   __syncthreads();
   for (int c = 0; c < nchunks; c += 2) {
     // even step: B holds chunk c+1, A receives chunk c+2
