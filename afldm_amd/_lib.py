@@ -23,7 +23,7 @@ class ConvArgs(Structure):
         ("C1", c_int), ("C2", c_int), ("B", c_int), ("H", c_int), ("W", c_int), ("Cout", c_int),
         ("KS", c_int), ("temb_stride", c_int), ("res_ld", c_int), ("y_ld", c_int),
         ("out_mode", c_int), ("dtype", c_int), ("y2", c_void_p), ("split_n", c_int),
-        ("stats_out", c_void_p),
+        ("stats_out", c_void_p), ("temb_mod", c_int),
     ]
 
 

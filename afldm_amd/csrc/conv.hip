@@ -35,6 +35,7 @@ struct ConvP {
   int split_n;
   int C1, C2, B, H, W, Cout, KS;
   int temb_stride, res_ld, y_ld, out_mode;
+  int temb_mod;  // temb column = cout % temb_mod (a 3x3 conv on a 2x2 plane run as one dense layer: cout = pixel * C + c)
   int M;        // B*H*W
   int ksteps;   // total K steps = KS*KS * (C1+C2)/(KCH*EPR)
   int splitk;   // grid.z
@@ -74,7 +75,7 @@ __device__ __forceinline__ void epilogue_store(const ConvP& p, int m, int n, f32
     }
     if (temb) {
       float a0, a1, a2, a3;
-      load4<T>(temb + (size_t)b * p.temb_stride + n, a0, a1, a2, a3);
+      load4<T>(temb + (size_t)b * p.temb_stride + n % p.temb_mod, a0, a1, a2, a3);
       v[0] += a0; v[1] += a1; v[2] += a2; v[3] += a3;
     }
     if (res) {
@@ -95,7 +96,7 @@ __device__ __forceinline__ void epilogue_store(const ConvP& p, int m, int n, f32
       if (n + r >= p.Cout) break;
       float s = v[r];
       if (p.bias) s += p.bias[n + r];
-      if (temb) s += to_f32(temb[(size_t)b * p.temb_stride + n + r]);
+      if (temb) s += to_f32(temb[(size_t)b * p.temb_stride + (n + r) % p.temb_mod]);
       if (res) s += to_f32(res[(size_t)m * p.res_ld + n + r]);
       if (p.out_mode == 0) y[(size_t)m * p.y_ld + n + r] = from_f32<T>(s);
       else y[((size_t)b * p.Cout + n + r) * HW + pix] = from_f32<T>(s);
@@ -627,7 +628,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
               }
             }
             if (temb) {
-              const Chunk tv = ld16<Chunk>(temb + (size_t)b * p.temb_stride + n);
+              const Chunk tv = ld16<Chunk>(temb + (size_t)b * p.temb_stride + n % p.temb_mod);
 #pragma unroll
               for (int e = 0; e < EO; ++e) v[e] += to_f32(tv[e]);
             }
@@ -652,7 +653,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
             for (int e = 0; e < EO && n + e < nhwc_end; ++e) {
               float sv = v[e];
               if (p.bias) sv += p.bias[n + e];
-              if (temb) sv += to_f32(temb[(size_t)b * p.temb_stride + n + e]);
+              if (temb) sv += to_f32(temb[(size_t)b * p.temb_stride + (n + e) % p.temb_mod]);
               if (res) sv += to_f32(res[(size_t)m * p.res_ld + n + e]);
               ((T*)p.y)[(size_t)m * p.y_ld + n + e] = from_f32<T>(sv);
             }
@@ -677,12 +678,12 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
           if (m >= p.M) continue;
           const int b = m / HW, pix = m - b * HW;
           const float bsv = p.bias ? p.bias[n] : 0.f;
-          const float tsv = temb ? to_f32(temb[(size_t)b * p.temb_stride + n]) : 0.f;
+          const float tsv = temb ? to_f32(temb[(size_t)b * p.temb_stride + n % p.temb_mod]) : 0.f;
           Chunk o;
 #pragma unroll
           for (int e = 0; e < EO; ++e) {
             float sv = sC[(row0 + e) * SROW + nl] + bsv;
-            if (temb && m + e < p.M) sv += p.stage_ok ? tsv : to_f32(temb[(size_t)((m + e) / HW) * p.temb_stride + n]);
+            if (temb && m + e < p.M) sv += p.stage_ok ? tsv : to_f32(temb[(size_t)((m + e) / HW) * p.temb_stride + n % p.temb_mod]);
             if (res && m + e < p.M) sv += to_f32(res[(size_t)(m + e) * p.res_ld + n]);
             o[e] = from_f32<T>(sv);
           }
@@ -750,7 +751,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_stats(ConvP p, int rows_p
     const bool has_b = p.bias != nullptr;
     if (has_b) bt = *reinterpret_cast<const f32x4*>(p.bias + n);
     float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-    if (temb) load4<T>(temb + (size_t)b * p.temb_stride + n, t0, t1, t2, t3);
+    if (temb) load4<T>(temb + (size_t)b * p.temb_stride + n % p.temb_mod, t0, t1, t2, t3);
     for (int pix = r0 + tr; pix < r1; pix += RL) {
       const size_t m = (size_t)b * HW + pix;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -837,7 +838,7 @@ __global__ void __launch_bounds__(256) k_conv_small_cin(ConvP p) {
         for (int c = 0; c < Ct; ++c) acc = fmaf(to_f32(xs[c]), to_f32(wsrc[c]), acc);
       }
     }
-    if (p.temb) acc += to_f32(((const T*)p.temb)[(size_t)b * p.temb_stride + n]);
+    if (p.temb) acc += to_f32(((const T*)p.temb)[(size_t)b * p.temb_stride + n % p.temb_mod]);
     if (p.residual) acc += to_f32(((const T*)p.residual)[(size_t)m * p.res_ld + n]);
     if (p.out_mode == 0) y[(size_t)m * p.y_ld + n] = from_f32<T>(acc);
     else y[((size_t)b * p.Cout + n) * HW + pix] = from_f32<T>(acc);
@@ -929,7 +930,7 @@ __global__ void __launch_bounds__(256) k_conv_small_cout(ConvP p) {
     if (lane == 0) {
       for (int n = 0; n < p.Cout; ++n) {
         float s = acc[n] + (p.bias ? p.bias[n] : 0.f);
-        if (p.temb) s += to_f32(((const T*)p.temb)[(size_t)b * p.temb_stride + n]);
+        if (p.temb) s += to_f32(((const T*)p.temb)[(size_t)b * p.temb_stride + n % p.temb_mod]);
         if (p.residual) s += to_f32(((const T*)p.residual)[(size_t)m * p.res_ld + n]);
         if (p.out_mode == 0) y[(size_t)m * p.y_ld + n] = from_f32<T>(s);
         else y[((size_t)b * p.Cout + n) * HW + pix] = from_f32<T>(s);
@@ -1209,6 +1210,7 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
   p.y2 = a->y2; p.split_n = a->split_n;
   p.C1 = a->C1; p.C2 = a->C2; p.B = a->B; p.H = a->H; p.W = a->W; p.Cout = a->Cout; p.KS = a->KS;
   p.temb_stride = a->temb_stride; p.res_ld = a->res_ld; p.y_ld = a->y_ld; p.out_mode = a->out_mode;
+  p.temb_mod = a->temb_mod > 0 ? a->temb_mod : a->Cout;
   p.M = a->B * a->H * a->W;
   p.splitk = 1; p.tiles_n = 1; p.ksteps = 0;
   static const int s_dbg = getenv("AFLDM_CONV_DBG") ? atoi(getenv("AFLDM_CONV_DBG")) : 0;
@@ -1308,6 +1310,8 @@ static int conv_validate(const afldm_conv_args* a) {
                 "afldm_conv2d: y_ld=%d too small for Cout=%d", a->y_ld, a->Cout);
   AFLDM_REQUIRE(!a->residual || a->res_ld >= a->Cout, AFLDM_ESHAPE, "afldm_conv2d: res_ld=%d < Cout=%d", a->res_ld, a->Cout);
   AFLDM_REQUIRE((long long)a->B * a->H * a->W < (1ll << 30), AFLDM_ESHAPE, "afldm_conv2d: M too large");
+  AFLDM_REQUIRE(a->temb_mod == 0 || (a->temb_mod > 0 && a->temb_mod % 8 == 0 && a->Cout % a->temb_mod == 0), AFLDM_ESHAPE,
+                "afldm_conv2d: temb_mod=%d must divide Cout=%d and be a multiple of 8", a->temb_mod, a->Cout);
   AFLDM_REQUIRE(!a->stats_out || (a->out_mode == 0 && !a->y2 && a->y_ld == a->Cout && a->Cout % 4 == 0), AFLDM_ESHAPE,
                 "afldm_conv2d: stats_out needs a dense NHWC output (out_mode 0, no y2, y_ld == Cout, Cout %% 4 == 0)");
   AFLDM_REQUIRE(aligned16(a->x1) && aligned16(a->w) && aligned16(a->y) && aligned16(a->x2) && aligned16(a->residual) &&

@@ -424,7 +424,7 @@ def af_resample(x, M, out=None, workspace=None):
 
 # ----------------------------------------------------------------------------- conv / linear
 def conv_args(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, out=None, out_mode=0,
-              workspace=None, y_ld=None, out2=None, split_n=0):
+              workspace=None, y_ld=None, out2=None, split_n=0, temb_mod=0):
     """Build the afldm_conv_args struct (keeps references to the tensors alive in `.keep`)."""
     C1, x2, C2 = _cat_args(x1, x2)
     _dev(w, "w")
@@ -446,6 +446,7 @@ def conv_args(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None
     a.out_mode = int(out_mode)
     a.dtype = _code(x1)
     a.y2, a.split_n = ptr(out2), int(split_n)
+    a.temb_mod = int(temb_mod)
     if out2 is not None and y_ld is None:
         a.y_ld = int(split_n)
     a.keep = (x1, x2, w, bias, temb, residual, out, workspace)
@@ -453,7 +454,7 @@ def conv_args(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None
 
 
 def conv2d(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, out=None, out_mode=0,
-           workspace=None, want_stats=False):
+           workspace=None, want_stats=False, temb_mod=0):
     """stride-1 'same' conv (KS in {1,3}) / linear on NHWC input with packed OHWI weights.
     out_mode 1 returns the channel-major [B, Cout, H*W] tensor (V^T for attention).
     want_stats: also emit the per-channel GroupNorm partial sums of the output (from the GEMM
@@ -465,7 +466,7 @@ def conv2d(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, o
         else:
             B = x1.shape[0]
             out = torch.empty((B, Cout, x1.numel() // (B * x1.shape[-1])), dtype=x1.dtype, device=x1.device)
-    a = conv_args(x1, w, bias, x2, temb, temb_stride, residual, out, out_mode, workspace)
+    a = conv_args(x1, w, bias, x2, temb, temb_stride, residual, out, out_mode, workspace, temb_mod=temb_mod)
     if out_mode == 1 and x1.ndim == 3:      # [B, T, C] tokens: treat T as the pixel axis
         a.B, a.H, a.W = x1.shape[0], x1.shape[1], 1
     if workspace is None:

@@ -198,6 +198,10 @@ typedef struct {
    * stats_out[B][S][Cout][2] fp32 with S = afldm_conv2d_stats_splits(args), computed on the stored
    * (rounded) values by the GEMM epilogue / the split-K reduction; NULL = none. */
   float* stats_out;
+  /* 0, or the period of the time-embedding column: temb[b*temb_stride + n % temb_mod] (a 3x3
+   * convolution on a 2x2 plane executed as ONE dense layer over the flattened plane: cout index =
+   * pixel * C + c, every pixel takes the same per-channel time embedding; must divide Cout). */
+  int temb_mod;
 } afldm_conv_args;
 int afldm_conv2d(const afldm_conv_args* args, afldm_stream_t stream);
 /* Tuning hook (benchmarks only): force tile/pipeline variant `variant` (>= 0) and/or a split-K

@@ -265,6 +265,37 @@ def test_conv2d_emits_groupnorm_statistics(dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C1,C2,Cout", [(64, 0, 64), (96, 32, 48)])
+def test_conv3x3_on_2x2_plane_runs_as_one_dense_layer(dtype, C1, C2, Cout):
+    """blocks.conv_forward on a 2x2 plane (the 2x2 level of the UNet): the dense re-formulation
+    (no zero-padding taps) must equal F.conv2d, including virtual concat, the per-channel time
+    embedding (temb_mod), the residual and the attached GroupNorm statistics."""
+    import torch.nn as nn
+    from afldm_amd.models import blocks
+    ops = _ops()
+    g = torch.Generator().manual_seed(33)
+    B = 5
+    conv = nn.Conv2d(C1 + C2, Cout, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(rnd(dtype, torch.randn(conv.weight.shape, generator=g) / (3 * (C1 + C2) ** 0.5)))
+        conv.bias.copy_(torch.randn(Cout, generator=g))
+    x = rnd(dtype, torch.randn(B, C1 + C2, 2, 2, generator=g))
+    temb = rnd(dtype, torch.randn(B, Cout, generator=g))
+    res = rnd(dtype, torch.randn(B, Cout, 2, 2, generator=g))
+    ref = F.conv2d(x, conv.weight, conv.bias, padding=1) + temb[:, :, None, None] + res
+    conv = conv.cuda()
+    xin = nhwc(x[:, :C1], dtype) if C2 == 0 else (nhwc(x[:, :C1], dtype), nhwc(x[:, C1:], dtype))
+    y = blocks.conv_forward(conv, xin, temb=temb.to(device="cuda", dtype=dtype), temb_stride=Cout,
+                            residual=nhwc(res, dtype), want_stats=True)
+    assert y.shape == (B, 2, 2, Cout) and ("dense2x2", dtype, C1, C2) in conv.__dict__["_afldm_cache"]
+    close(back(y), ref, dtype, "dense 2x2 conv", bf16_rms=6e-3)
+    got = y.gn_partial.double().sum(1).cpu()
+    yv = y.float()
+    assert (got[..., 0] - yv.sum((1, 2)).cpu()).abs().max() < 1e-3
+    assert (got[..., 1] - (yv * yv).sum((1, 2)).cpu()).abs().max() < 1e-2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv2d_channel_major_output(dtype):
     ops = _ops()
     g = torch.Generator().manual_seed(5)

@@ -27,6 +27,8 @@ SHAPES = {
     "S5 L4 3x3 768->768": ((1024, 768, 3, 768), ["33/8", "33/4", "31/4", "31/8", "24/4"]),
     "S6 L2 3x3 768->768": ((256, 768, 3, 768), ["32/4", "32/8", "11/4", "31/8"]),
     "S7 L32 to_out 192->192": ((65536, 192, 1, 192), ["29/1", "31/1", "12/1"]),
+    "S9 L2 dense 3072->3072": ((64, 3072, 1, 3072), ["32/4", "32/8", "32/2", "32/12", "31/8", "33/8"]),
+    "S9b L2 dense 6144->3072": ((64, 3072, 1, 6144), ["32/4", "32/8", "32/12", "31/8", "33/8"]),
     "S8 L8 3x3 1152->384": ((4096, 384, 3, 1152), ["33/4", "33/2", "32/1", "29/4"]),
 }
 
