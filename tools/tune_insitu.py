@@ -29,6 +29,11 @@ SHAPES = {
     "S7 L32 to_out 192->192": ((65536, 192, 1, 192), ["29/1", "31/1", "12/1"]),
     "S9 L2 dense 3072->3072": ((64, 3072, 1, 3072), ["32/4", "32/8", "32/2", "32/12", "31/8", "33/8"]),
     "S9b L2 dense 6144->3072": ((64, 3072, 1, 6144), ["32/4", "32/8", "32/12", "31/8", "33/8"]),
+    "T1 L4 qkv 768->2304": ((1024, 2304, 1, 768), ["32/1", "31/1", "30/1", "33/1", "32/2", "29/1"]),
+    "T2 L4 out 768->768": ((1024, 768, 1, 768), ["32/1", "31/1", "32/2", "11/1"]),
+    "T3 L8 qkv 384->1152": ((4096, 1152, 1, 384), ["32/1", "31/1", "30/1", "29/1", "33/1"]),
+    "T4 L8 out 384->384": ((4096, 384, 1, 384), ["32/1", "31/1", "30/1"]),
+    "T5 L16 out 384->384": ((16384, 384, 1, 384), ["31/1", "30/1", "29/1", "32/1"]),
     "S8 L8 3x3 1152->384": ((4096, 384, 3, 1152), ["33/4", "33/2", "32/1", "29/4"]),
 }
 
