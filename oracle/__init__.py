@@ -20,10 +20,16 @@ reference algorithm on the hot path of SingleZombie/AFLDM:
   * ImageShifter ('ideal', 'ideal_crop', bilinear) and the masked metrics
                        (reference afldm/shift_utils/shifters.py:31-206,
                         afldm/shift_utils/metrics.py:5-20)
+  * the AF-VAE (AutoencoderKL after make_af_vae_from_config), the I2SB scheduler
+    and the x4 super-resolution degrade operator build_sr4x
+                       (reference afldm/models/af_vae.py:8-55, af_api.py:34-67,
+                        afldm/schedulers/i2sb_scheduler.py:131-197,382-459,
+                        afldm/af_libs/superresolution.py:160-320)
 
 Pinning status
 --------------
-* The alias-free pieces, shifters and metrics are pinned bit-for-bit (fp32)
+* The alias-free pieces, shifters, metrics and the super-resolution degrade
+  operator (g9_sr4x) are pinned bit-for-bit / to 1e-6 (fp32)
   against the *imported* reference modules by ``oracle/gen_golden.py`` (run in
   the build container, where /root/reference exists); its outputs are committed
   under ``tests/golden/`` and re-checked by ``tests/test_oracle_golden.py``.
