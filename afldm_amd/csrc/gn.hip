@@ -186,7 +186,7 @@ extern "C" int afldm_gn_apply(const void* x1, int C1, const void* x2, int C2, co
   AFLDM_REQUIRE(C1 % 4 == 0 && C2 % 4 == 0, AFLDM_ESHAPE, "afldm_gn_apply: C1=%d / C2=%d must be multiples of 4", C1, C2);
   hipStream_t st = (hipStream_t)stream;
   const int C = C1 + C2;
-  int rows = 8192 / C;            // ~8K elements per workgroup
+  int rows = (HW >= 4096 ? 32768 : 8192) / C;   // ~8K elements per workgroup (32K on the big VAE planes: amortises the statistics prologue)
   if (rows < 1) rows = 1;
   if (rows > HW) rows = HW;
   const int grid = B * ((HW + rows - 1) / rows);
