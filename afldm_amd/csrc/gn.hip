@@ -1,6 +1,8 @@
 // gn.hip — GroupNorm statistics and apply(+SiLU) over NHWC tensors that may be the virtual
 // channel-concat of two tensors.  HBM-bound: algorithmic bytes = 1 read (stats; the second
 // centred pass re-reads from L2) and 1 read + 1 write (apply) of the logical tensor.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace afldm {
@@ -109,24 +111,51 @@ __global__ void __launch_bounds__(256) k_gn_apply(const T* __restrict__ x1, int 
   const int r1 = r0 + rows_per_block < HW ? r0 + rows_per_block : HW;
   typedef typename Mma<T>::Chunk Chunk;
   constexpr int EPC = Mma<T>::EPC;
-  if (C1 % EPC == 0 && C2 % EPC == 0) {
-    // 16 bytes per lane (8-byte accesses run at 0.54-0.70x the 16-byte rate, MI355X_MICROARCH.md)
-    const int nc = C / EPC;
-    const int total = (r1 - r0) * nc;
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
-      const int pix = r0 + i / nc, c = EPC * (i % nc);
+  if (C1 % EPC == 0 && C2 % EPC == 0 && C / EPC <= (int)blockDim.x) {
+    // Streaming form: a thread keeps ONE 16-byte channel column (its scale / shift live in registers)
+    // and walks down the rows with four independent loads in flight - no index division, no LDS
+    // reads in the loop (8-byte accesses run at 0.54-0.70x the 16-byte rate, MI355X_MICROARCH.md).
+    const int nc = C / EPC, rl = (int)blockDim.x / nc;
+    if ((int)threadIdx.x < rl * nc) {
+      const int col = (int)threadIdx.x % nc, lane_r = (int)threadIdx.x / nc, c = EPC * col;
       const bool second = c >= C1;
-      const T* src = second ? x2 : x1;
-      const int Cs = second ? C2 : C1, cs = second ? c - C1 : c;
-      const Chunk v = ld16<Chunk>(src + ((size_t)b * HW + pix) * Cs + cs);
-      Chunk o;
+      const T* src = (second ? x2 : x1) + (size_t)b * HW * (second ? C2 : C1) + (second ? c - C1 : c);
+      const size_t Cs = second ? C2 : C1;
+      T* dst = y + (size_t)b * HW * C + c;
+      float ks[EPC], hs[EPC];
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
-        float f = to_f32(v[e]) * sc[c + e] + sh[c + e];
-        if (act == 1) f = silu_f(f);
-        o[e] = from_f32<T>(f);
+        ks[e] = sc[c + e];
+        hs[e] = sh[c + e];
       }
-      st16<Chunk>(y + ((size_t)b * HW + pix) * C + c, o);
+      int row = r0 + lane_r;
+      for (; row + 3 * rl < r1; row += 4 * rl) {
+        Chunk v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ld16<Chunk>(src + (size_t)(row + u * rl) * Cs);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          Chunk o;
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            float f = to_f32(v[u][e]) * ks[e] + hs[e];
+            if (act == 1) f = silu_f(f);
+            o[e] = from_f32<T>(f);
+          }
+          st16<Chunk>(dst + (size_t)(row + u * rl) * C, o);
+        }
+      }
+      for (; row < r1; row += rl) {
+        const Chunk v = ld16<Chunk>(src + (size_t)row * Cs);
+        Chunk o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          float f = to_f32(v[e]) * ks[e] + hs[e];
+          if (act == 1) f = silu_f(f);
+          o[e] = from_f32<T>(f);
+        }
+        st16<Chunk>(dst + (size_t)row * C, o);
+      }
     }
     return;
   }
@@ -186,7 +215,8 @@ extern "C" int afldm_gn_apply(const void* x1, int C1, const void* x2, int C2, co
   AFLDM_REQUIRE(C1 % 4 == 0 && C2 % 4 == 0, AFLDM_ESHAPE, "afldm_gn_apply: C1=%d / C2=%d must be multiples of 4", C1, C2);
   hipStream_t st = (hipStream_t)stream;
   const int C = C1 + C2;
-  int rows = (HW >= 4096 ? 32768 : 8192) / C;   // ~8K elements per workgroup (32K on the big VAE planes: amortises the statistics prologue)
+  static const int s_el = getenv("AFLDM_GN_ELEMS") ? atoi(getenv("AFLDM_GN_ELEMS")) : 0;
+  int rows = (s_el > 0 ? s_el : (HW >= 4096 ? 32768 : 16384)) / C;   // ~8K elements per workgroup (32K on the big VAE planes: amortises the statistics prologue)
   if (rows < 1) rows = 1;
   if (rows > HW) rows = HW;
   const int grid = B * ((HW + rows - 1) / rows);
