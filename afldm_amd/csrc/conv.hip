@@ -607,6 +607,27 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
       if (etid < RPI * CPR) {
         const int ch = etid % CPR;
         const int n = n0 + ch * EO;
+        const bool fast = p.stage_ok && n + EO <= nhwc_end;
+        // the thread's column is fixed: bias (and the time embedding, when the tile lies inside one
+        // sample) are fetched ONCE, not per row - a global-load latency per row was most of the
+        // epilogue of the short-K 1x1 GEMMs
+        const bool one_sample = (HW % BM) == 0;
+        float bvec[EO], tvec[EO];
+#pragma unroll
+        for (int e = 0; e < EO; ++e) bvec[e] = tvec[e] = 0.f;
+        if (fast && p.bias) {
+#pragma unroll
+          for (int q = 0; q < EO / 4; ++q) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n + 4 * q);
+            bvec[4 * q] = bv[0]; bvec[4 * q + 1] = bv[1]; bvec[4 * q + 2] = bv[2]; bvec[4 * q + 3] = bv[3];
+          }
+        }
+        const int b_tile = m0 / HW;
+        if (fast && temb && one_sample) {
+          const Chunk tv = ld16<Chunk>(temb + (size_t)b_tile * p.temb_stride + n % p.temb_mod);
+#pragma unroll
+          for (int e = 0; e < EO; ++e) tvec[e] = to_f32(tv[e]);
+        }
 #pragma unroll 1
         for (int row = etid / CPR; row < PROWS; row += RPI) {
           const int mt = row / (TMP * 16), rr = row - mt * (TMP * 16);
@@ -618,19 +639,20 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
             const f32x4 a = *reinterpret_cast<const f32x4*>(sC + row * SROW + ch * EO + 4 * q);
             v[4 * q] = a[0]; v[4 * q + 1] = a[1]; v[4 * q + 2] = a[2]; v[4 * q + 3] = a[3];
           }
-          const int b = m / HW;
-          if (p.stage_ok && n + EO <= nhwc_end) {
+          if (fast) {
             if (p.bias) {
 #pragma unroll
-              for (int q = 0; q < EO / 4; ++q) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n + 4 * q);
-                v[4 * q] += bv[0]; v[4 * q + 1] += bv[1]; v[4 * q + 2] += bv[2]; v[4 * q + 3] += bv[3];
-              }
+              for (int e = 0; e < EO; ++e) v[e] += bvec[e];
             }
             if (temb) {
-              const Chunk tv = ld16<Chunk>(temb + (size_t)b * p.temb_stride + n % p.temb_mod);
+              if (one_sample) {
 #pragma unroll
-              for (int e = 0; e < EO; ++e) v[e] += to_f32(tv[e]);
+                for (int e = 0; e < EO; ++e) v[e] += tvec[e];
+              } else {
+                const Chunk tv = ld16<Chunk>(temb + (size_t)(m / HW) * p.temb_stride + n % p.temb_mod);
+#pragma unroll
+                for (int e = 0; e < EO; ++e) v[e] += to_f32(tv[e]);
+              }
             }
             if (res) {
               const Chunk rv = ld16<Chunk>(res + (size_t)m * p.res_ld + n);
@@ -650,6 +672,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
               }
             }
           } else {   // ragged cout tail / odd leading dimensions
+            const int b = m / HW;
             for (int e = 0; e < EO && n + e < nhwc_end; ++e) {
               float sv = v[e];
               if (p.bias) sv += p.bias[n + e];
