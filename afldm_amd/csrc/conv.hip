@@ -569,6 +569,13 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
     float ss1[EO], ss2[EO];
 #pragma unroll
     for (int e = 0; e < EO; ++e) ss1[e] = ss2[e] = 0.f;
+    // A tile that lies wholly in the channel-major output (the V^T third of a fused q|k|v GEMM,
+    // out_mode 1) is staged TRANSPOSED ([cout][pixel]): the copy-out then reads 16-byte runs of
+    // consecutive pixels instead of gathering 8 strided floats per store.
+    constexpr int TROW = PROWS + 4;                      // transposed row stride (floats)
+    constexpr bool T_FITS = BN * TROW * 4 <= LDS_TOTAL;
+    const int cm_beg0 = p.out_mode == 1 ? 0 : (p.y2 ? p.split_n : p.Cout);
+    const bool cm_tile = T_FITS && p.splitk == 1 && p.stage_ok && n0 >= cm_beg0 && !p.residual && (HW % EO) == 0;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       __syncthreads();   // pipeline buffers idle (first pass) / previous pass copied out
@@ -577,10 +584,50 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
 #pragma unroll
         for (int t = 0; t < TMP; ++t) {
           const int row = (wm * TMP + t) * 16 + li;      // staged row  <->  tile row wm*WMS + (ps*TMP + t)*16 + li
-          *reinterpret_cast<f32x4*>(sC + row * SROW + wn * WNS + tn * 16 + 4 * lg) = acc[tn][ps * TMP + t];
+          if (cm_tile) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sC[(wn * WNS + tn * 16 + 4 * lg + r) * TROW + row] = acc[tn][ps * TMP + t][r];
+          } else {
+            *reinterpret_cast<f32x4*>(sC + row * SROW + wn * WNS + tn * 16 + 4 * lg) = acc[tn][ps * TMP + t];
+          }
           __builtin_amdgcn_sched_barrier(0);   // one tile at a time: keeps the accumulator -> VGPR copies from piling up
         }
       __syncthreads();
+      if (cm_tile) {
+        T* yc = p.out_mode == 1 ? (T*)p.y : (T*)p.y2;
+        const int cch = p.Cout - cm_beg0;
+        constexpr int RG = PROWS / EO;                   // 16-byte pixel runs per cout per pass
+#pragma unroll 1
+        for (int i = etid; i < BN * RG; i += NTC) {
+          const int nl = i / RG, g = i - nl * RG;
+          const int n = n0 + nl;
+          if (n >= p.Cout) continue;
+          const int row0 = g * EO;
+          const int mt = row0 / (TMP * 16), rr = row0 - mt * (TMP * 16);
+          const int m = m0 + mt * WMS + ps * TMP * 16 + rr;
+          if (m >= p.M) continue;
+          const int b = m / HW, pix = m - b * HW;
+          float add = p.bias ? p.bias[n] : 0.f;
+          const float tsv = temb ? to_f32(temb[(size_t)b * p.temb_stride + n % p.temb_mod]) : 0.f;
+          Chunk o;
+#pragma unroll
+          for (int q = 0; q < EO / 4; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(sC + nl * TROW + row0 + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float sv = a[e] + add;
+              if (temb) sv += tsv;
+              o[4 * q + e] = from_f32<T>(sv);
+            }
+          }
+          if (m + EO <= p.M) {
+            st16<Chunk>(yc + ((size_t)b * cch + (n - cm_beg0)) * HW + pix, o);
+          } else {
+            for (int e = 0; e < EO && m + e < p.M; ++e) yc[((size_t)b * cch + (n - cm_beg0)) * HW + pix + e] = o[e];
+          }
+        }
+        continue;
+      }
       if (p.splitk > 1) {
         // split-K slab: fp32 rows, 16 bytes per lane
         constexpr int QPR = BN / 4;

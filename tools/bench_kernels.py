@@ -132,6 +132,10 @@ def bench_lin(dtype=torch.bfloat16):
     res = torch.randn(B, 32, 32, C, device="cuda").to(dtype)
     t = timeit(lambda: ops.linear_split(x, w3, b3, 2 * C))
     print(f"qkv  [65536x192]x[192x576]: {t:7.1f} us  {(B*T*C*2 + B*T*3*C*2)/t/1e3:7.1f} GB/s", flush=True)
+    t = timeit(lambda: ops.conv2d(x4, w3, b3))
+    print(f"1x1  [65536x192]x[192x576] all NHWC: {t:7.1f} us  {(B*T*C*2 + B*T*3*C*2)/t/1e3:7.1f} GB/s", flush=True)
+    t = timeit(lambda: ops.conv2d(x4, w3, b3, out_mode=1))
+    print(f"1x1  [65536x192]x[192x576] all channel-major: {t:7.1f} us", flush=True)
     t = timeit(lambda: ops.conv2d(x4, w1, b1))
     print(f"1x1  [65536x192]x[192x192]: {t:7.1f} us  {(B*T*C*2*2)/t/1e3:7.1f} GB/s", flush=True)
     t = timeit(lambda: ops.conv2d(x4, w1, b1, residual=res))
