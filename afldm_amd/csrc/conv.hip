@@ -1063,6 +1063,9 @@ static const Variant kVariants[] = {
     {128, 128, 4, 2},  // 34  + 4 producer waves
     {128, 128, 4, 3},  // 35
     {256, 64, 4, 2},   // 36
+    {64, 192, 4, 2},   // 37  short-K GEMMs: twice the tiles of 128x192 (epilogues of one round overlap the next)
+    {64, 128, 4, 2},   // 38
+    {64, 192, 4, 3},   // 39
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -1218,6 +1221,9 @@ static bool launch_variant(int id, const ConvP& p, hipStream_t st) {
     case 34: launch_igemm2<T, 128, 128, 2, 2, 2, 2, 4, true>(p, st); return true;
     case 35: launch_igemm2<T, 128, 128, 2, 2, 3, 2, 0, true>(p, st); return true;
     case 36: launch_igemm2<T, 256, 64, 4, 1, 2, 2, 0, true>(p, st); return true;
+    case 37: launch_igemm2<T, 64, 192, 2, 2, 2, 2, 0, true, 2>(p, st); return true;
+    case 38: launch_igemm2<T, 64, 128, 2, 2, 2, 2, 0, true, 2>(p, st); return true;
+    case 39: launch_igemm2<T, 64, 192, 2, 2, 3, 2, 0, true, 2>(p, st); return true;
   }
   return false;
 }

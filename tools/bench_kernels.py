@@ -52,7 +52,7 @@ CONV_SHAPES = [
 
 def bench_conv(dtype=torch.bfloat16):
     # CONV_VARIANTS=4,12,21  CONV_SHAPES=L32,L16  restrict the sweep
-    variants = [int(v) for v in os.environ.get("CONV_VARIANTS", ",".join(map(str, range(37)))).split(",")]
+    variants = [int(v) for v in os.environ.get("CONV_VARIANTS", ",".join(map(str, range(40)))).split(",")]
     only = [t for t in os.environ.get("CONV_SHAPES", "").split(",") if t]
     out = {}
     for name, B, H, W, C1, C2, Cout, KS in CONV_SHAPES:
