@@ -296,6 +296,36 @@ def test_conv3x3_on_2x2_plane_runs_as_one_dense_layer(dtype, C1, C2, Cout):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,HW,K,N,use_res", [(4, 1024, 192, 192, True), (4, 1024, 192, 576, False), (16, 256, 384, 384, True)])
+def test_short_k_linear_layers_at_attention_sizes(dtype, B, HW, K, N, use_res):
+    """The attention blocks' 1x1 layers at their real row counts (M >= 4096, K = 192 / 384): NHWC output
+    with bias + residual + GroupNorm statistics from the epilogue, and the fused q|k|v form (token-major
+    q|k, channel-major v through the transposed staging tile)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(44)
+    side = int(HW ** 0.5)
+    x = rnd(dtype, torch.randn(B, K, side, side, generator=g))
+    w = rnd(dtype, torch.randn(N, K, 1, 1, generator=g) / K ** 0.5)
+    b = torch.randn(N, generator=g)
+    res = rnd(dtype, torch.randn(B, N, side, side, generator=g)) if use_res else None
+    ref = F.conv2d(x, w, b) + (res if use_res else 0)
+    xh, wp = nhwc(x, dtype), ops.pack_weight(w.cuda(), dtype)
+    y = ops.conv2d(xh, wp, b.cuda(), residual=nhwc(res, dtype) if use_res else None, want_stats=True)
+    close(back(y), ref, dtype, "streaming 1x1", bf16_rms=6e-3)
+    yv = y.float()
+    got = y.gn_partial.double().sum(1).cpu()
+    assert (got[..., 0] - yv.sum((1, 2)).cpu()).abs().max() <= 1e-4 * (1 + yv.sum((1, 2)).abs().max().item())
+    assert (got[..., 1] - (yv * yv).sum((1, 2)).cpu()).abs().max() <= 1e-4 * (1 + (yv * yv).sum((1, 2)).max().item())
+    if N % 192 == 0 and N >= 384 and not use_res:      # fused projection: last third channel-major
+        split = 2 * N // 3
+        tok = xh.view(B, HW, K)
+        qk, vt = ops.linear_split(tok, wp, b.cuda(), split)
+        refs = (F.conv2d(x, w, b)).flatten(2)              # [B, N, HW]
+        close(qk.float().cpu(), refs[:, :split].transpose(1, 2), dtype, "q|k token-major", bf16_rms=6e-3)
+        close(vt.float().cpu(), refs[:, split:], dtype, "v channel-major", bf16_rms=6e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv2d_channel_major_output(dtype):
     ops = _ops()
     g = torch.Generator().manual_seed(5)
