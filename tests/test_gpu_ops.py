@@ -422,3 +422,39 @@ def test_fused_qkv_split_gemm_and_strided_attention(dtype):
     q, k, v = (rnd(dtype, ref[..., i * C:(i + 1) * C]).view(B, T, heads, d).transpose(1, 2) for i in range(3))
     oref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, T, C)
     close(o.float().cpu(), oref, dtype, "attention on fused qkv", f32_tol=5e-5, bf16_rms=1.5e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,C", [(32, 192), (16, 384), (8, 384), (4, 768), (2, 768)])
+def test_alias_free_ops_full_size_properties(dtype, N, C):
+    """Full-size (batch 64) properties of the alias-free kernels, independent of any reference run:
+    * every operator is a circulant product, so it commutes with integer circular shifts:
+      af_act(roll(x)) == roll(af_act(x))  (catches any pixel / plane ordering slip at every N);
+    * the resampling operators are linear: op(a x + b z) == a op(x) + b op(z);
+    * the fused GroupNorm path equals gn_apply followed by the plain activation."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    B = 64
+    x = (torch.randn(B, N, N, C, generator=g) * 1.3 + 0.1).to(device="cuda", dtype=dtype)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+
+    def rr(a, b):
+        a, b = a.float(), b.float()
+        return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-12))
+
+    y = ops.af_act(x)
+    ys = ops.af_act(torch.roll(x, shifts=(1, N - 1), dims=(1, 2)).contiguous())
+    assert rr(ys, torch.roll(y, shifts=(1, N - 1), dims=(1, 2))) <= tol
+    if N <= 16:
+        z = torch.randn(B, N, N, C, generator=g).to(device="cuda", dtype=dtype)
+        mix = (0.75 * x.float() - 1.5 * z.float()).to(dtype)
+        for op in ((ops.af_up2, ops.af_lpf_down2) if N >= 4 else (ops.af_up2,)):
+            lin = 0.75 * op(x).float() - 1.5 * op(z).float()
+            assert rr(op(mix), lin) <= (1e-5 if dtype == torch.float32 else 2e-2), op.__name__
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).cuda()
+    beta = (0.1 * torch.randn(C, generator=g)).cuda()
+    st = ops.gn_stats(x)
+    fused = ops.af_act(x, None, st, gamma, beta, 32, 1e-5)
+    two = ops.af_act(ops.gn_apply(x, st, gamma, beta, 32, 1e-5, act=0))
+    assert rr(fused, two) <= (1e-5 if dtype == torch.float32 else 1.5e-2)
+
