@@ -458,3 +458,46 @@ def test_alias_free_ops_full_size_properties(dtype, N, C):
     two = ops.af_act(ops.gn_apply(x, st, gamma, beta, 32, 1e-5, act=0))
     assert rr(fused, two) <= (1e-5 if dtype == torch.float32 else 1.5e-2)
 
+
+@pytest.mark.parametrize("shape", [(64, 32, 32, 192, 192, 3), (64, 16, 16, 384, 384, 3), (64, 4, 4, 768, 768, 3),
+                                   (64, 32, 32, 192, 576, 1)])
+def test_conv_full_size_linearity(shape):
+    """Batch-64 layer shapes of the FFHQ UNet (bf16): the convolution minus its bias is linear in the
+    input - conv(a x + b z) - conv(0) == a (conv(x) - conv(0)) + b (conv(z) - conv(0)) - for the
+    LDS-DMA tile variants, the producer/consumer variant, split-K and the staged epilogue alike."""
+    ops = _ops()
+    B, H, W, Cin, Cout, KS = shape
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, H, W, Cin, generator=g).to(device="cuda", dtype=dt)
+    z = torch.randn(B, H, W, Cin, generator=g).to(device="cuda", dtype=dt)
+    w = (torch.randn(Cout, KS, KS, Cin, generator=g) / (KS * Cin ** 0.5)).to(device="cuda", dtype=dt)
+    b = torch.randn(Cout, generator=g).cuda()
+    c0 = ops.conv2d(torch.zeros_like(x), w, b).float()
+    mix = (0.5 * x.float() + 2.0 * z.float()).to(dt)
+    lhs = ops.conv2d(mix, w, b).float() - c0
+    rhs = 0.5 * (ops.conv2d(x, w, b).float() - c0) + 2.0 * (ops.conv2d(z, w, b).float() - c0)
+    rel = float((lhs - rhs).pow(2).mean().sqrt() / rhs.pow(2).mean().sqrt())
+    assert rel <= 1.5e-2, rel        # three bf16 roundings of O(1) values on each side
+
+
+@pytest.mark.parametrize("T,heads", [(1024, 8), (256, 16)])
+def test_attention_full_size_properties(T, heads):
+    """Batch-64 attention (bf16): the output is invariant under a permutation of the key/value
+    positions (the 64-key chunking and the lazy reference max see a different order), and a
+    constant V comes back unchanged (rows of the softmax sum to one through the row of ones)."""
+    ops = _ops()
+    dt, B, d = torch.bfloat16, 64, 24
+    C = heads * d
+    g = torch.Generator().manual_seed(10)
+    q = torch.randn(B, T, C, generator=g).to(device="cuda", dtype=dt)
+    k = torch.randn(B, T, C, generator=g).to(device="cuda", dtype=dt)
+    v = torch.randn(B, T, C, generator=g).to(device="cuda", dtype=dt)
+    o = ops.attention(q, k, v.transpose(1, 2).contiguous(), heads).float()
+    perm = torch.randperm(T, generator=g).cuda()
+    op = ops.attention(q, k[:, perm].contiguous(), v[:, perm].transpose(1, 2).contiguous(), heads).float()
+    assert float((o - op).pow(2).mean().sqrt() / o.pow(2).mean().sqrt()) <= 1e-2
+    const = torch.full((B, C, T), 0.625, device="cuda", dtype=dt)
+    oc = ops.attention(q, k, const, heads).float()
+    assert (oc - 0.625).abs().max() <= 4e-3
+
