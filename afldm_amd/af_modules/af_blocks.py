@@ -68,4 +68,4 @@ class AliasFreeDownsample2D(Downsample2D):
         # padding == 1 (UNet): the conv's own padding.  Both are the stride-1 'same' convolution.
         assert self.padding in (0, 1) and tuple(self.conv.kernel_size) == (3, 3)
         hidden_states = conv_forward(self.conv, hidden_states)
-        return ops.af_lpf_down2(hidden_states)
+        return ops.af_lpf_down2(hidden_states, want_stats=True)

@@ -693,6 +693,178 @@ __global__ void __launch_bounds__(256) k_axis_contract_reg(const TI* __restrict_
   }
 }
 
+
+// ----------------------------------------------------------------------------- fused resample (N = 16 -> 32, 32 -> 16)
+// y = M x M^T per (sample, channel) plane in ONE kernel for the two large alias-free resampling sites
+// of the UNet (AliasFreeUpsample2D at 16 -> 32, AliasFreeDownsample2D at 32 -> 16): the two-pass VALU
+// form (k_axis_contract_reg) round-trips an fp32 intermediate through HBM (81 / 163 MB of traffic for
+// 31 / 63 MB of tensor).  Same structure as k_af_act_plane: the item's 16 channels are transposed into
+// per-channel planes in LDS, each wave carries whole planes through  T^T = X^T M^T  (A = X^T rows from
+// LDS, B = M) and  Y^T = M T^T  (chained: the accumulator is the next B operand), and the tile leaves
+// through LDS as 16-byte stores.  Optionally emits the per-channel GroupNorm partial sums (S = 1).
+template <typename T, int N, int R>
+struct RsCfg {
+  typedef Mma<T> MM;
+  static constexpr int EPC = MM::EPC, KPF = MM::KPF;
+  static constexpr int KH = ((N + KPF - 1) / KPF) * KPF, NKF1 = KH / KPF;
+  static constexpr int TNI = N / 16, TR = R / 16;
+  static constexpr int NW = 4, CPW = 4;
+  static constexpr bool PERM = sizeof(T) == 2;
+  static constexpr int KHP = KH + EPC;
+  static constexpr int YRP = R * 16 + 8;
+  static constexpr int XS = 16 * N * KHP, YS = R * YRP;
+  static constexpr int REG = XS > YS ? XS : YS;
+  static constexpr int LDS_BYTES = REG * (int)sizeof(T);
+  static_assert(N % 16 == 0 && R % 16 == 0, "16-row MFMA tiles");
+};
+
+template <typename T, int N, int R>
+__global__ void __launch_bounds__(256) k_resample_plane(const T* __restrict__ x, const float* __restrict__ M,
+                                                        T* __restrict__ y, float* __restrict__ stats_out, int B, int C) {
+  typedef RsCfg<T, N, R> CF;
+  typedef Mma<T> MM;
+  typedef typename MM::Chunk Chunk;
+  constexpr int EPC = CF::EPC, KPF = CF::KPF, KH = CF::KH, KHP = CF::KHP, YRP = CF::YRP;
+  constexpr int NKF1 = CF::NKF1, TNI = CF::TNI, TR = CF::TR, CPW = CF::CPW, NT = 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* Xs = reinterpret_cast<T*>(smem);
+  T* Ys = Xs;   // the X planes are dead once every wave has read its fragments
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int ctiles = C / 16, nitems = B * ctiles;
+
+  // constant fragments of M [R][N] (fp32 in global), once per workgroup
+  Chunk mB[TR][NKF1], mA[TR][NKF1];
+#pragma unroll
+  for (int t = 0; t < TR; ++t)
+#pragma unroll
+    for (int f = 0; f < NKF1; ++f)
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const int kb = af_kidx<T>(f, lg, e, false), ka = af_kidx<T>(f, lg, e, true);
+        mB[t][f][e] = from_f32<T>(kb < N ? M[(16 * t + li) * N + kb] : 0.f);
+        mA[t][f][e] = from_f32<T>(ka < N ? M[(16 * t + li) * N + ka] : 0.f);
+      }
+
+  constexpr int CQ = 16 / EPC, HQ = N / EPC, UNITS = N * CQ * HQ, UPT = (UNITS + NT - 1) / NT;
+  for (int item = xcd_remap(blockIdx.x, gridDim.x); item < nitems; item += gridDim.x) {
+    const int b = item / ctiles, c0 = (item - b * ctiles) * 16;
+    __syncthreads();   // previous item's copy out of the (aliased) region is done
+    if constexpr (KH > N) {
+      for (int i = tid; i < N * 16 * (KH - N); i += NT) {
+        const int row = i / (KH - N), k = N + (i - row * (KH - N));
+        Xs[row * KHP + k] = from_f32<T>(0.f);
+      }
+    }
+    // ---- tile -> Xs[c][w][h] (h K-contiguous): unit = EPC pixels (along h) x EPC channels
+#pragma unroll
+    for (int k = 0; k < UPT; ++k) {
+      const int u = tid + k * NT;
+      if (u < UNITS) {
+        const int cq = u % CQ, w = (u / CQ) % N, hq = u / (CQ * N);
+        Chunk pre[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+          pre[e] = ld16<Chunk>(x + ((size_t)(b * N + hq * EPC + e) * N + w) * C + c0 + cq * EPC);
+#pragma unroll
+        for (int cc = 0; cc < EPC; ++cc) {
+          Chunk o;
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) o[e] = pre[e][cc];
+          st16<Chunk>(Xs + ((size_t)((cq * EPC + cc) * N + w)) * KHP + hq * EPC, o);
+        }
+      }
+    }
+    __syncthreads();
+    f32x4 yacc[CPW][TR][TR];
+#pragma unroll
+    for (int pl = 0; pl < CPW; ++pl) {
+      const int c = wave * CPW + pl;
+      Chunk xa[TNI][NKF1];
+#pragma unroll
+      for (int tw = 0; tw < TNI; ++tw)
+#pragma unroll
+        for (int kf = 0; kf < NKF1; ++kf)
+          xa[tw][kf] = ld16<Chunk>(Xs + ((size_t)(c * N + 16 * tw + li)) * KHP + kf * KPF + lg * EPC);
+#pragma unroll
+      for (int th = 0; th < TR; ++th) {
+        f32x4 t1[TNI];        // rows w, columns h' (tile th)
+#pragma unroll
+        for (int tw = 0; tw < TNI; ++tw) {
+          t1[tw] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kf = 0; kf < NKF1; ++kf) MM::mma(t1[tw], xa[tw][kf], mB[th][kf]);
+        }
+        Chunk b2[NKF1];
+        if constexpr (CF::PERM) {
+#pragma unroll
+          for (int f = 0; f < NKF1; ++f)
+            b2[f] = pack_chain<T>(t1[2 * f], 2 * f + 1 < TNI ? t1[2 * f + 1 < TNI ? 2 * f + 1 : 0] : f32x4{0.f, 0.f, 0.f, 0.f});
+        } else {
+#pragma unroll
+          for (int f = 0; f < NKF1; ++f) b2[f] = t1[f];
+        }
+#pragma unroll
+        for (int tr = 0; tr < TR; ++tr) {   // rows w' (tile tr), columns h'
+          yacc[pl][tr][th] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int f = 0; f < NKF1; ++f) MM::mma(yacc[pl][tr][th], mA[tr][f], b2[f]);
+        }
+      }
+    }
+    __syncthreads();   // every wave has its X fragments: the region becomes the output tile
+#pragma unroll
+    for (int pl = 0; pl < CPW; ++pl) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int tr = 0; tr < TR; ++tr)
+#pragma unroll
+        for (int th = 0; th < TR; ++th)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const T o = from_f32<T>(yacc[pl][tr][th][r]);
+            Ys[(16 * th + li) * YRP + (16 * tr + 4 * lg + r) * 16 + wave * CPW + pl] = o;
+            const float vr = to_f32(o);
+            s1 += vr;
+            s2 = fmaf(vr, vr, s2);
+          }
+      if (stats_out) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          s1 += __shfl_xor(s1, o, 64);
+          s2 += __shfl_xor(s2, o, 64);
+        }
+        if (lane == 0) *reinterpret_cast<f32x2*>(stats_out + ((size_t)b * C + c0 + wave * CPW + pl) * 2) = f32x2{s1, s2};
+      }
+    }
+    __syncthreads();
+    {
+      constexpr int CPP = 16 / EPC;
+      for (int i = tid; i < R * R * CPP; i += NT) {
+        const int pix = i / CPP, q = i - pix * CPP;
+        const int h = pix / R, w = pix - h * R;
+        st16<Chunk>(y + ((size_t)b * R * R + pix) * C + c0 + q * EPC, ld16<Chunk>(Ys + h * YRP + w * 16 + q * EPC));
+      }
+    }
+  }
+}
+
+template <typename T, int N, int R>
+static int launch_resample_plane(const void* x, const float* M, void* y, float* stats, int B, int C, hipStream_t st) {
+  typedef RsCfg<T, N, R> CF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_resample_plane<T, N, R>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
+    attr_set = true;
+  }
+  const int nitems = B * (C / 16);
+  const int per_cu = (160 * 1024) / CF::LDS_BYTES > 3 ? 3 : (160 * 1024) / CF::LDS_BYTES;
+  int grid = 256 * per_cu;
+  if (grid > nitems) grid = nitems;
+  k_resample_plane<T, N, R><<<grid, 256, CF::LDS_BYTES, st>>>((const T*)x, M, (T*)y, stats, B, C);
+  return check_launch("afldm_af_resample_plane");
+}
+
 // ----------------------------------------------------------------------------- launchers
 // resident (persistent) workgroups of the plane kernel per CU: LDS-bound, and at most 2 (N = 32) /
 // 4 (N = 16) four-wave workgroups by the register budget
@@ -898,5 +1070,22 @@ extern "C" int afldm_af_resample(const void* x, const float* M, void* y, float* 
   if (dtype == AFLDM_F32) return resample_dispatch<float>(x, M, y, workspace, B, N, C, R, st);
   if (dtype == AFLDM_BF16) return resample_dispatch<bf16>(x, M, y, workspace, B, N, C, R, st);
   set_error("afldm_af_resample: unknown dtype %d", dtype);
+  return AFLDM_EDTYPE;
+}
+
+extern "C" int afldm_af_resample_plane(const void* x, const float* M, void* y, float* stats_out, int B, int N, int C,
+                                       int R, int dtype, afldm_stream_t stream) {
+  AFLDM_REQUIRE(x && M && y, AFLDM_ENULL, "afldm_af_resample_plane: NULL pointer");
+  AFLDM_REQUIRE(B > 0 && C > 0 && C % 16 == 0 && ((N == 16 && R == 32) || (N == 32 && R == 16)), AFLDM_ESHAPE,
+                "afldm_af_resample_plane: covers N=16->32 and N=32->16 with C %% 16 == 0 (got N=%d R=%d C=%d)", N, R, C);
+  AFLDM_REQUIRE(aligned16(x) && aligned16(y), AFLDM_EALIGN, "afldm_af_resample_plane: pointers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == AFLDM_BF16)
+    return N == 16 ? launch_resample_plane<bf16, 16, 32>(x, M, y, stats_out, B, C, st)
+                   : launch_resample_plane<bf16, 32, 16>(x, M, y, stats_out, B, C, st);
+  if (dtype == AFLDM_F32)
+    return N == 16 ? launch_resample_plane<float, 16, 32>(x, M, y, stats_out, B, C, st)
+                   : launch_resample_plane<float, 32, 16>(x, M, y, stats_out, B, C, st);
+  set_error("afldm_af_resample_plane: unknown dtype %d", dtype);
   return AFLDM_EDTYPE;
 }

@@ -3,6 +3,7 @@ of device memory and streams; every op below is one or two HIP kernel launches f
 libafldm_hip.so on torch's current stream.  All activations are NHWC ([B, H, W, C]) or
 token-major ([B, T, C]) contiguous CUDA tensors in fp32 or bf16.  CPU tensors raise."""
 import ctypes
+import os
 
 import torch
 
@@ -289,6 +290,22 @@ def af_act(x1, x2=None, stats=None, gamma=None, beta=None, G=0, eps=0.0, out=Non
     return out
 
 
+def _resample_plane(x, M, R, out, want_stats):
+    """One-kernel MFMA resample (afldm_af_resample_plane) for the UNet's 16 -> 32 / 32 -> 16 sites."""
+    B, N, _, C = x.shape
+    st = torch.empty((B, 1, C, 2), dtype=torch.float32, device=x.device) if want_stats else None
+    tok = _begin()
+    check(lib.afldm_af_resample_plane(ptr(x), ptr(M), ptr(out), ptr(st), B, N, C, R, _code(x), stream_ptr()),
+          "af_resample_plane")
+    _end(tok, "af_resample_plane", 4.0 * (N * N * R + N * R * R) * B * C / 2, B * (N * N + R * R) * C * x.element_size())
+    if st is not None:
+        out.gn_partial = st
+    return out
+
+
+_PLANE_RESAMPLE = os.environ.get("AFLDM_NO_RESAMPLE_PLANE", "0") != "1"
+
+
 def af_up2(x, out=None, workspace=None):
     _dev(x, "x")
     B, N, N2, C = x.shape
@@ -298,6 +315,8 @@ def af_up2(x, out=None, workspace=None):
         out = torch.empty((B, 2 * N, 2 * N, C), dtype=x.dtype, device=x.device)
     if N >= 32 and C % 16 == 0 and (x.dtype == torch.bfloat16 or N <= 64):
         return _resample_large(x, U, 2 * N, out)
+    if N == 16 and C % 16 == 0 and _PLANE_RESAMPLE:
+        return _resample_plane(x, U, 32, out, False)
     if workspace is None:
         workspace = torch.empty(B * 2 * N * N * C, dtype=torch.float32, device=x.device)
     assert workspace.numel() >= B * 2 * N * N * C
@@ -307,7 +326,7 @@ def af_up2(x, out=None, workspace=None):
     return out
 
 
-def af_lpf_down2(x, out=None, workspace=None):
+def af_lpf_down2(x, out=None, workspace=None, want_stats=False):
     _dev(x, "x")
     B, N, N2, C = x.shape
     assert N == N2
@@ -316,6 +335,8 @@ def af_lpf_down2(x, out=None, workspace=None):
         out = torch.empty((B, N // 2, N // 2, C), dtype=x.dtype, device=x.device)
     if N >= 64 and C % 16 == 0 and (x.dtype == torch.bfloat16 or N <= 128):
         return _resample_large(x, D, N // 2, out)
+    if N == 32 and C % 16 == 0 and _PLANE_RESAMPLE:
+        return _resample_plane(x, D, 16, out, want_stats)
     if workspace is None:
         workspace = torch.empty(B * (N // 2) * N * C, dtype=torch.float32, device=x.device)
     assert workspace.numel() >= B * (N // 2) * N * C

@@ -114,6 +114,12 @@ int afldm_af_act(const void* x1, int C1, const void* x2, int C2, const float* st
                  const float* stats2, int S2, const float* gamma, const float* beta, int G, float eps,
                  const float* U, const float* D, const void* packed, void* y, int B, int N, int dtype,
                  afldm_stream_t stream);
+/* y = M x M^T per plane in ONE kernel (MFMA, no fp32 intermediate through HBM) for the two large
+ * resampling sites of the UNet: AliasFreeUpsample2D at 16 -> 32 (M = U, af_blocks.py:92-93) and
+ * AliasFreeDownsample2D at 32 -> 16 (M = D, af_blocks.py:149-150).  stats_out (optional):
+ * per-channel GroupNorm partial sums of y, [B][1][C][2] (S = 1). */
+int afldm_af_resample_plane(const void* x, const float* M, void* y, float* stats_out, int B, int N,
+                            int C, int R, int dtype, afldm_stream_t stream);
 /* One-time packing of U / D into the kernel's LDS image for the MFMA plane sizes (N = 16, 32):
  * `packed` = device buffer of afldm_af_pack_bytes(N, dtype) bytes, passed to afldm_af_act. */
 size_t afldm_af_pack_bytes(int N, int dtype);

@@ -152,6 +152,38 @@ def test_af_resample(dtype, N, C):
         close(back(ops.af_lpf_down2(nhwc(x, dtype))), ref, dtype, f"af_lpf_down2 N={N}", bf16_rms=4e-3)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,C,B", [(16, 96, 3), (32, 192, 2), (32, 48, 5), (16, 384, 2)])
+def test_af_resample_plane(dtype, N, C, B):
+    """The one-kernel MFMA resample (afldm_af_resample_plane: 16 -> 32 with U, 32 -> 16 with D) against
+    the oracle's rfft definition and the two-pass path, and its emitted GroupNorm partial sums against
+    the stand-alone statistics pass over its own output."""
+    from oracle import ideal_filters as idf
+    ops = _ops()
+    g = torch.Generator().manual_seed(N + C)
+    x = rnd(dtype, torch.randn(B, C, N, N, generator=g))
+    xh = nhwc(x, dtype)
+    if N == 16:
+        y = ops.af_up2(xh)
+        ref = idf.upsample_rfft(x, 2)
+        M = ops.up_matrix(N, 2, xh.device)
+        assert getattr(y, "gn_partial", None) is None
+    else:
+        y = ops.af_lpf_down2(xh, want_stats=True)
+        ref = idf.lpf_rfft(x)[:, :, ::2, ::2]
+        M = ops.down_matrix(N, xh.device)
+        st = y.gn_partial
+        assert st.shape == (B, 1, C, 2)
+        want = ops.gn_stats(y, out=torch.empty((B, ops.lib.afldm_gn_stats_splits(y.shape[1] * y.shape[2]), C, 2),
+                                               dtype=torch.float32, device="cuda")).st1.sum(1)
+        torch.testing.assert_close(st[:, 0], want, rtol=2e-5, atol=2e-3)
+    close(back(y), ref, dtype, f"resample_plane N={N}", bf16_rms=4e-3)
+    two = ops.af_resample(xh, M)
+    tol = 1e-5 if dtype == torch.float32 else 6e-3
+    d = (y.float() - two.float()).pow(2).mean().sqrt() / two.float().pow(2).mean().sqrt()
+    assert float(d) <= tol, float(d)
+
+
 CONV_CASES = [
     # B, H, W, C1, C2, Cout, KS, temb, residual
     (2, 16, 16, 64, 0, 64, 3, False, False),
