@@ -4,9 +4,11 @@ subpixel_shift :161-172, mask builders :12-49) executed as dense separable circu
 on MI355X (afldm_af_resample) instead of rfft2 -> mask -> irfft2.
 
 Public tensors are NCHW like the reference; square planes only (the reference builds its mask
-from the width alone, ideal_lpf.py:80).  cutoff is restricted to what the hot path uses
-(LPF: 1/2; recon: 1/up) — other values raise instead of silently differing.
+from the width alone, ideal_lpf.py:80).  The UNet's own filters (cutoff 1/2, up 2 / 8) take their
+matrices from the C library (afldm_filter_matrix); any other cutoff / up / factor builds the
+circulant of the reference's 1-D mask on the host in fp64 (`_circulant`).
 """
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -42,6 +44,27 @@ def create_fixed_lpf_rect(N, size):
     return r[:, None] * r[None, :]
 
 
+_MATRIX_CACHE = {}
+
+
+def _circulant(r):
+    """Real circulant C = F^-1 diag(r) F of a 1-D frequency mask (fp64 host arithmetic).  The masks are
+    even (r[k] == r[N - k]), so rfft2 -> mask -> irfft2 with the separable mask r r^T is exactly
+    C x C^T on every plane."""
+    r = np.asarray(r, dtype=np.float64)
+    N = r.shape[0]
+    k = np.arange(N)
+    first_col = (r[None, :] * np.cos(2 * np.pi * np.outer(k, k) / N)).sum(1) / N      # Re(ifft(r))
+    return first_col[(k[:, None] - k[None, :]) % N]
+
+
+def _device_matrix(key, build, device):
+    key = key + (str(device),)
+    if key not in _MATRIX_CACHE:
+        _MATRIX_CACHE[key] = torch.from_numpy(np.ascontiguousarray(build())).to(torch.float32).to(device)
+    return _MATRIX_CACHE[key]
+
+
 def _plane_op(x, M):
     """y = M x M^T on every (b, c) plane of an NCHW CUDA tensor."""
     if not x.is_cuda:
@@ -56,41 +79,63 @@ class LPF_RFFT(nn.Module):
     def __init__(self, cutoff=0.5, transform_mode="rfft", fixed_size=None):
         super().__init__()
         assert transform_mode in ("fft", "rfft"), f"transform_mode={transform_mode} is not supported"
-        if cutoff != 0.5 or fixed_size is not None:
-            raise NotImplementedError("afldm_amd.LPF_RFFT implements cutoff=1/2 (the only value on the AF-LDM path)")
         self.cutoff = cutoff
-        self.fixed_size = fixed_size
+        self.fixed_size = fixed_size          # stored and, like the reference's forward (:69-93), never used
         self.transform_mode = transform_mode
         self.rect_dict = {}
 
     def forward(self, x):
-        return _plane_op(x, ops.lpf_matrix(x.shape[-1], x.device))
+        if self.transform_mode == "fft":
+            # the reference's 'fft' inverse is a one-argument lambda called with s= (ideal_lpf.py:67-68,91)
+            raise TypeError("LPF_RFFT(transform_mode='fft'): itransform() got an unexpected keyword argument 's' "
+                            "(same failure as the reference)")
+        N = x.shape[-1]
+        if self.cutoff == 0.5:
+            return _plane_op(x, ops.lpf_matrix(N, x.device))
+        M = _device_matrix(("lpf", N, float(self.cutoff)), lambda: _circulant(_rect_1d(N, self.cutoff, 0.0).numpy()),
+                           x.device)
+        return _plane_op(x, M)
 
 
 class LPF_RECON_RFFT(nn.Module):
-    """Recon filter on an ALREADY zero-stuffed tensor is not separately exposed on the HIP path:
-    use UpsampleRFFT (zero-stuffing + recon + gain fused into one matrix)."""
+    """Reconstruction filter on an already zero-stuffed plane (ideal_lpf.py:96-134); the inverse
+    transform is the same in both transform modes up to rounding.  Even planes only (the reference's
+    irfft2 without `s` returns an even-width plane)."""
 
     def __init__(self, cutoff=0.5, transform_mode="rfft"):
         super().__init__()
+        assert transform_mode in ("fft", "rfft"), f"mode={transform_mode} is not supported"
         self.cutoff = cutoff
         self.transform_mode = transform_mode
         self.rect_dict = {}
 
+    def matrix(self, N, device):
+        return _device_matrix(("recon", N, float(self.cutoff)),
+                              lambda: _circulant(_rect_1d(N, self.cutoff, 0.5).numpy()), device)
+
     def forward(self, x):
-        raise NotImplementedError("use UpsampleRFFT: the zero-stuffed intermediate never exists on the HIP path")
+        N = x.shape[-1]
+        if N % 2:
+            raise NotImplementedError("LPF_RECON_RFFT on an odd plane changes its width in the reference (irfft2)")
+        return _plane_op(x, self.matrix(N, x.device))
 
 
 class UpsampleRFFT(nn.Module):
     def __init__(self, up=2, transform_mode="rfft", factor=1):
         super().__init__()
-        if factor != 1:
-            raise NotImplementedError("factor != 1 is not used on the AF-LDM path")
         self.up = up
+        self.factor = factor
         self.recon_filter = LPF_RECON_RFFT(cutoff=1 / up * factor, transform_mode=transform_mode)
 
     def forward(self, x):
-        return _plane_op(x, ops.up_matrix(x.shape[-1], self.up, x.device))
+        N, up = x.shape[-1], self.up
+        if self.factor == 1:
+            return _plane_op(x, ops.up_matrix(N, up, x.device))
+        # zero-stuffing keeps every up-th column of the recon circulant; gain up per axis (ideal_lpf.py:148-158)
+        cutoff = self.recon_filter.cutoff
+        M = _device_matrix(("up", N, up, float(cutoff)),
+                           lambda: up * _circulant(_rect_1d(N * up, cutoff, 0.5).numpy())[:, ::up], x.device)
+        return _plane_op(x, M)
 
 
 def subpixel_shift(images, up=2, shift_x=1, shift_y=1, up_method="ideal"):

@@ -1073,6 +1073,27 @@ extern "C" int afldm_af_resample(const void* x, const float* M, void* y, float* 
   return AFLDM_EDTYPE;
 }
 
+extern "C" int afldm_af_resample_hw(const void* x, const float* Mh, const float* Mw, void* y, float* workspace, int B,
+                                    int N, int C, int R, int dtype, afldm_stream_t stream) {
+  AFLDM_REQUIRE(x && Mh && Mw && y && workspace, AFLDM_ENULL, "afldm_af_resample_hw: NULL pointer");
+  AFLDM_REQUIRE(B > 0 && N > 0 && C > 0 && R > 0, AFLDM_ESHAPE, "afldm_af_resample_hw: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n1 = (size_t)B * R * N * C, n2 = (size_t)B * R * R * C;
+  const int g1 = (int)((n1 + 255) / 256 < 8192 ? (n1 + 255) / 256 : 8192);
+  const int g2 = (int)((n2 + 255) / 256 < 8192 ? (n2 + 255) / 256 : 8192);
+  if (dtype == AFLDM_F32) {
+    k_axis_contract<float, float><<<g1, 256, 0, st>>>((const float*)x, workspace, Mh, B, N, N, C, R, 0);
+    k_axis_contract<float, float><<<g2, 256, 0, st>>>(workspace, (float*)y, Mw, B, R, N, C, R, 1);
+  } else if (dtype == AFLDM_BF16) {
+    k_axis_contract<bf16, float><<<g1, 256, 0, st>>>((const bf16*)x, workspace, Mh, B, N, N, C, R, 0);
+    k_axis_contract<float, bf16><<<g2, 256, 0, st>>>(workspace, (bf16*)y, Mw, B, R, N, C, R, 1);
+  } else {
+    set_error("afldm_af_resample_hw: unknown dtype %d", dtype);
+    return AFLDM_EDTYPE;
+  }
+  return check_launch("afldm_af_resample_hw");
+}
+
 extern "C" int afldm_af_resample_plane(const void* x, const float* M, void* y, float* stats_out, int B, int N, int C,
                                        int R, int dtype, afldm_stream_t stream) {
   AFLDM_REQUIRE(x && M && y, AFLDM_ENULL, "afldm_af_resample_plane: NULL pointer");

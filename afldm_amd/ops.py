@@ -443,6 +443,45 @@ def af_resample(x, M, out=None, workspace=None):
     return out
 
 
+def af_resample_hw(x, Mh, Mw, out=None, workspace=None):
+    """y = Mh x Mw^T per plane (different matrices along H and W): [B,N,N,C] -> [B,R,R,C]."""
+    _dev(x, "x")
+    B, N, N2, C = x.shape
+    assert N == N2 and Mh.shape == Mw.shape and Mh.shape[1] == N
+    R = Mh.shape[0]
+    if out is None:
+        out = torch.empty((B, R, R, C), dtype=x.dtype, device=x.device)
+    if workspace is None:
+        workspace = torch.empty(B * R * N * C, dtype=torch.float32, device=x.device)
+    check(lib.afldm_af_resample_hw(ptr(x), ptr(Mh), ptr(Mw), ptr(out), ptr(workspace), B, N, C, R, _code(x),
+                                   stream_ptr()), "af_resample_hw")
+    return out
+
+
+# ----------------------------------------------------------------------------- upfirdn2d (NCHW planes)
+def upfirdn2d(x, f, upx=1, upy=1, downx=1, downy=1, padx0=0, padx1=0, pady0=0, pady1=0, flip_filter=False, gain=1.0,
+              out=None):
+    """afldm_upfirdn2d on an NCHW CUDA tensor (fp32 / bf16) with a 2-D device fp32 filter [fh, fw]."""
+    _dev(x, "x")
+    _dev(f, "f")
+    assert x.ndim == 4 and f.ndim == 2 and f.dtype == torch.float32
+    B, C, H, W = x.shape
+    fh, fw = f.shape
+    outW = lib.afldm_upfirdn2d_out_size(W, upx, downx, padx0, padx1, fw)
+    outH = lib.afldm_upfirdn2d_out_size(H, upy, downy, pady0, pady1, fh)
+    assert outW > 0 and outH > 0, "upfirdn2d: the padded / cropped up-sampled plane is smaller than the filter"
+    if out is None:
+        out = torch.empty((B, C, outH, outW), dtype=x.dtype, device=x.device)
+    if B * C == 0:
+        return out
+    tok = _begin()
+    check(lib.afldm_upfirdn2d(ptr(x), ptr(f), ptr(out), B * C, H, W, fh, fw, upx, upy, downx, downy, padx0, padx1,
+                              pady0, pady1, int(bool(flip_filter)), float(gain), _code(x), stream_ptr()), "upfirdn2d")
+    _end(tok, "upfirdn2d", 2.0 * out.numel() * ((fh + upy - 1) // upy) * ((fw + upx - 1) // upx),
+         (x.numel() + out.numel()) * x.element_size())
+    return out
+
+
 # ----------------------------------------------------------------------------- conv / linear
 def conv_args(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, out=None, out_mode=0,
               workspace=None, y_ld=None, out2=None, split_n=0, temb_mod=0):

@@ -140,6 +140,11 @@ int afldm_af_lpf_down2(const void* x, const float* D, void* y, float* workspace,
 int afldm_af_resample(const void* x, const float* M, void* y, float* workspace, int B, int N, int C,
                       int R, int dtype, afldm_stream_t stream);
 
+/* y = Mh x Mw^T per plane with different matrices along H and W ([R][N] each): the phase-ramp shift
+ * of shifters.py:103-132 (fourier_shift_batch) in dense circulant form.  workspace: B*R*N*C floats. */
+int afldm_af_resample_hw(const void* x, const float* Mh, const float* Mw, void* y, float* workspace,
+                         int B, int N, int C, int R, int dtype, afldm_stream_t stream);
+
 /* ---- large-plane separable passes (alias-free VAE, planes 64^2 .. 256^2) ----------------------
  * y[line][r] = act(sum_k M[r][k] xn[line][k])            or, with M2 (chained in registers):
  * y[line][r2] = sum_r M2[r2][r] silu(sum_k M[r][k] xn[line][k])
@@ -247,6 +252,20 @@ int afldm_ddim_step_flat(const float* x, const float* eps, float* x_prev, float 
 /* tvals[step] -> t_out[0] (device->device), so the timestep also follows step_idx. */
 int afldm_select_timestep(const float* tvals, const int* step_idx, float* t_out,
                           afldm_stream_t stream);
+
+/* ---- upfirdn2d ---------------------------------------------------------------------------
+ * Zero-stuffing up-sample (upx, upy) -> pad (negative = crop) -> 2-D FIR -> decimate (downx, downy) on
+ * NCHW planes: torch_utils/ops/upfirdn2d.py:140-194 (`_upfirdn2d_ref`; the reference's fast path is the
+ * vendored upfirdn2d.cu plugin).  x [planes][H][W], f [fh][fw] DEVICE fp32 taps, y [planes][outH][outW],
+ * outW = (W*upx + padx0 + padx1 - fw) / downx + 1 (same for H).  flip_filter = 0 is a true convolution
+ * (the filter is flipped), 1 a correlation; every tap is scaled by `gain` (the reference scales a 2-D
+ * filter by gain and each pass of a separable one by sqrt(gain): callers pass the per-call factor).
+ * Serves equivariance.py:68-103 (Lanczos fractional translation), shifters.py:158-161, :292-365. */
+int afldm_upfirdn2d(const void* x, const float* f, void* y, int planes, int H, int W, int fh, int fw,
+                    int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1,
+                    int flip_filter, float gain, int dtype, afldm_stream_t stream);
+/* Output extent along one axis for the arguments above, -1 when the plane is smaller than the filter. */
+int afldm_upfirdn2d_out_size(int in, int up, int down, int pad0, int pad1, int ftaps);
 
 #ifdef __cplusplus
 }

@@ -233,6 +233,91 @@ def part_d():
     np.savez_compressed(os.path.join(OUT, "g9_sr4x.npz"), **g)
 
 
+def part_e():
+    """upfirdn2d family: outputs of the IMPORTED reference (its PyTorch `_upfirdn2d_ref` path, which is
+    what `upfirdn2d()` dispatches to on CPU), the translation operators of af_libs/equivariance.py, and
+    the lanczos / fourier ImageShifter modes and blur / ideal ImageUpsampler / ImageDownsampler of
+    shift_utils/shifters.py, on seeded inputs."""
+    ref_lpf, _, ref_shift = _import_reference()
+    from afldm.af_libs.torch_utils.ops import upfirdn2d as ru
+    from afldm.af_libs import equivariance as req
+    gen = torch.Generator().manual_seed(2024)
+    g = {}
+    x = torch.randn(2, 3, 12, 10, generator=gen)
+    g["x"] = x.numpy()
+    f2 = torch.rand(4, 3, generator=gen)
+    f1 = torch.rand(5, generator=gen)
+    g["f2"], g["f1"] = f2.numpy(), f1.numpy()
+    cases = [  # name, filter, up, down, padding, flip, gain
+        ("c0", "f2", 1, 1, 0, False, 1),
+        ("c1", "f2", 2, 1, [2, 1, 3, 0], False, 4),
+        ("c2", "f2", [1, 3], [2, 1], [1, 2, 2, 2], True, 0.5),
+        ("c3", "f1", 2, 2, [3, 3, 2, 2], False, 2),
+        ("c4", "f1", 1, 3, [-1, 2, 0, -2], True, 1),
+        ("c5", "f2", 3, 2, [-2, 4, 5, -3], False, 1.5),
+        ("c6", None, 2, 1, 0, False, 1),
+    ]
+    for name, fn, up, down, pad, flip, gain in cases:
+        f = None if fn is None else (f2 if fn == "f2" else f1)
+        g[name] = ru.upfirdn2d(x, f, up=up, down=down, padding=pad, flip_filter=flip, gain=gain, impl="ref").numpy()
+    fs = ru.setup_filter([1, 3, 3, 1])
+    g["setup_1331"] = fs.numpy()
+    g["setup_sep"] = ru.setup_filter([1, 2, 3, 4, 4, 3, 2, 1], gain=2).numpy()
+    g["filter2d"] = ru.filter2d(x, fs, padding=1, impl="ref").numpy()
+    g["upsample2d"] = ru.upsample2d(x, fs, up=2, impl="ref").numpy()
+    g["downsample2d"] = ru.downsample2d(x, fs, down=2, impl="ref").numpy()
+    # translations (unit = image extent)
+    img = torch.rand(2, 3, 32, 32, generator=gen) * 2 - 1
+    g["img"] = img.numpy()
+    for k, (tx, ty) in enumerate([(0.125 / 32 * 3, 0.5 / 32), (1.375 / 32, -2.25 / 32), (-0.5 / 32, 3.0 / 32),
+                                  (40.0 / 32, 0.0), (-29.5 / 32, 30.25 / 32)]):
+        z, m = req.apply_fractional_translation(img, tx, ty)
+        g[f"frac{k}_t"], g[f"frac{k}_z"], g[f"frac{k}_m"] = np.array([tx, ty]), z.numpy(), m.numpy()
+        z, m = req.apply_integer_translation(img, tx, ty)
+        g[f"int{k}_z"], g[f"int{k}_m"] = z.numpy(), m.numpy()
+    for flt in ("lanczos", "fourier", "fourier_crop"):
+        sh = ref_shift.ImageShifter(flt)
+        for k, (ti, tj) in enumerate([(0.125, 0.5), (1.0, -2.375), (-3.5, 0.25)]):
+            w, m = sh.shift(img, ti, tj)
+            g[f"shift_{flt}{k}_w"], g[f"shift_{flt}{k}_m"] = w.numpy(), m.numpy()
+    g["shift_t"] = np.array([(0.125, 0.5), (1.0, -2.375), (-3.5, 0.25)])
+    # image up / down samplers.  ImageDownsampler('ideal') builds LPF_RFFT(cutoff=scale) (shifters.py:348),
+    # whose mask indexes out of range when N % 4 == 0: recorded on a 30x30 plane where it is the identity.
+    img30 = torch.rand(2, 3, 30, 30, generator=gen) * 2 - 1
+    g["img30"] = img30.numpy()
+    for mode in ("blur", "ideal", "nearest", "bilinear"):
+        up = ref_shift.ImageUpsampler(2, mode, device="cpu")
+        g[f"up_{mode}"] = up.upsample(img).numpy()
+        if mode in ("blur", "ideal"):
+            g[f"lowpass_{mode}"] = up.low_pass(img).numpy()
+        dn = ref_shift.ImageDownsampler(2, mode, device="cpu")
+        if mode == "blur":
+            # shifters.py:357 passes `scale` in upfirdn2d's `up` slot, so the plane comes back at the
+            # input size and the final reshape (:364) raises: pin that behaviour instead of an output
+            try:
+                dn.downsample(img)
+                g["down_blur_raises"] = np.array(0)
+            except RuntimeError:
+                g["down_blur_raises"] = np.array(1)
+            continue
+        g[f"down_{mode}"] = dn.downsample(img30 if mode == "ideal" else img).numpy()
+    # general-cutoff ideal filters
+    xz = torch.randn(2, 3, 24, 24, generator=gen)
+    g["xz"] = xz.numpy()
+    g["lpf_q"] = ref_lpf.LPF_RFFT(cutoff=0.25)(xz.clone()).numpy()
+    try:   # ideal_lpf.py:67-68,91: the 'fft' itransform lambda takes no `s`, so LPF_RFFT('fft') raises
+        ref_lpf.LPF_RFFT(cutoff=0.5, transform_mode="fft")(xz.clone())
+        g["lpf_fft_raises"] = np.array(0)
+    except TypeError:
+        g["lpf_fft_raises"] = np.array(1)
+    g["recon_fft"] = ref_lpf.LPF_RECON_RFFT(cutoff=0.5, transform_mode="fft")(xz.clone()).numpy()
+    g["recon_h"] = ref_lpf.LPF_RECON_RFFT(cutoff=0.5)(xz.clone()).numpy()
+    g["recon_q"] = ref_lpf.LPF_RECON_RFFT(cutoff=0.25)(xz.clone()).numpy()
+    g["up4"] = ref_lpf.UpsampleRFFT(4)(xz[:, :, :12, :12].clone()).numpy()
+    g["up2_f2"] = ref_lpf.UpsampleRFFT(2, factor=0.5)(xz[:, :, :12, :12].clone()).numpy()
+    np.savez_compressed(os.path.join(OUT, "g10_upfirdn.npz"), **g)
+
+
 def idf_warp(x):
     from .ideal_filters import warped_nonlinearity
     return warped_nonlinearity(x)
@@ -249,5 +334,7 @@ if __name__ == "__main__":
         part_c()
     if which in ("d", "all"):
         part_d()
+    if which in ("e", "all"):
+        part_e()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

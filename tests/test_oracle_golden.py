@@ -152,3 +152,82 @@ def test_sr4x_degrade_matches_reference_fixture(golden):
     y3 = build_sr4x("bicubic", 64)(x[0])                      # 3-D input keeps its rank
     assert y3.shape == (3, 64, 64)
 
+
+
+UPFIRDN_CASES = [  # name, filter, up, down, padding, flip, gain  (oracle/gen_golden.py part e)
+    ("c0", "f2", 1, 1, 0, False, 1),
+    ("c1", "f2", 2, 1, [2, 1, 3, 0], False, 4),
+    ("c2", "f2", [1, 3], [2, 1], [1, 2, 2, 2], True, 0.5),
+    ("c3", "f1", 2, 2, [3, 3, 2, 2], False, 2),
+    ("c4", "f1", 1, 3, [-1, 2, 0, -2], True, 1),
+    ("c5", "f2", 3, 2, [-2, 4, 5, -3], False, 1.5),
+    ("c6", None, 2, 1, 0, False, 1),
+]
+FRAC_SHIFTS = 5
+SHIFT_T = [(0.125, 0.5), (1.0, -2.375), (-3.5, 0.25)]
+
+
+def test_upfirdn2d_oracle_vs_reference(golden):
+    """oracle/upfirdn.py against outputs of the imported reference's upfirdn2d (ref path)."""
+    from oracle import upfirdn as ou
+    g = golden("g10_upfirdn.npz")
+    x = t(g["x"])
+    for name, fn, up, down, pad, flip, gain in UPFIRDN_CASES:
+        f = None if fn is None else t(g[fn])
+        mine = ou.upfirdn2d(x, f, up=up, down=down, padding=pad, flip_filter=flip, gain=gain)
+        assert mine.shape == g[name].shape, name
+        torch.testing.assert_close(mine, t(g[name]), rtol=0, atol=0, msg=name)
+    fs = ou.setup_filter([1, 3, 3, 1])
+    assert np.array_equal(fs.numpy(), g["setup_1331"])
+    assert np.array_equal(ou.setup_filter([1, 2, 3, 4, 4, 3, 2, 1], gain=2).numpy(), g["setup_sep"])
+    assert np.array_equal(ou.filter2d(x, fs, padding=1).numpy(), g["filter2d"])
+    assert np.array_equal(ou.upsample2d(x, fs, up=2).numpy(), g["upsample2d"])
+    assert np.array_equal(ou.downsample2d(x, fs, down=2).numpy(), g["downsample2d"])
+
+
+def test_translations_oracle_vs_reference(golden):
+    from oracle import upfirdn as ou
+    g = golden("g10_upfirdn.npz")
+    img = t(g["img"])
+    for k in range(FRAC_SHIFTS):
+        tx, ty = (float(v) for v in g[f"frac{k}_t"])
+        z, m = ou.apply_fractional_translation(img, tx, ty)
+        assert np.array_equal(z.numpy(), g[f"frac{k}_z"]) and np.array_equal(m.numpy(), g[f"frac{k}_m"]), k
+        z, m = ou.apply_integer_translation(img, tx, ty)
+        assert np.array_equal(z.numpy(), g[f"int{k}_z"]) and np.array_equal(m.numpy(), g[f"int{k}_m"]), k
+    for k, (ti, tj) in enumerate(SHIFT_T):
+        w = ou.fourier_shift_batch(img, ti, tj)
+        assert np.array_equal(w.numpy(), g[f"shift_fourier{k}_w"]), k
+        assert np.array_equal(g[f"shift_fourier{k}_m"], np.ones_like(g[f"shift_fourier{k}_w"]))
+        mc = shift.gen_valid_mask(w.shape, ti, tj)
+        assert np.array_equal(mc.numpy(), g[f"shift_fourier_crop{k}_m"])
+        assert np.array_equal((w * mc).numpy(), g[f"shift_fourier_crop{k}_w"])
+        z, m = ou.apply_fractional_translation(img, tj / 32, ti / 32)     # shifters.py:158-161
+        assert np.array_equal(z.numpy(), g[f"shift_lanczos{k}_w"])
+        assert np.array_equal(m[:, 0:1].numpy(), g[f"shift_lanczos{k}_m"])
+
+
+def test_image_samplers_and_general_cutoff_oracle_vs_reference(golden):
+    from oracle import upfirdn as ou
+    g = golden("g10_upfirdn.npz")
+    img, img30 = t(g["img"]), t(g["img30"])
+    for mode in ("blur", "ideal", "nearest", "bilinear"):
+        assert np.array_equal(ou.image_upsample(img, 2, mode).numpy(), g[f"up_{mode}"]), mode
+        if mode in ("blur", "ideal"):
+            assert np.array_equal(ou.image_low_pass(img, 2, mode).numpy(), g[f"lowpass_{mode}"]), mode
+    assert int(g["down_blur_raises"]) == 1
+    with pytest.raises(RuntimeError):
+        ou.image_downsample(img, 2, "blur")
+    with pytest.raises(IndexError):       # LPF_RFFT(cutoff=2) mask on a plane with N % 4 == 0
+        ou.image_downsample(img, 2, "ideal")
+    for mode in ("ideal", "nearest", "bilinear"):
+        src = img30 if mode == "ideal" else img
+        assert np.array_equal(ou.image_downsample(src, 2, mode).numpy(), g[f"down_{mode}"]), mode
+    xz = t(g["xz"])
+    assert int(g["lpf_fft_raises"]) == 1
+    assert np.array_equal(idf.lpf_rfft(xz.clone(), 0.25).numpy(), g["lpf_q"])
+    assert np.array_equal(idf.lpf_recon_rfft(xz.clone(), 0.5).numpy(), g["recon_h"])
+    assert np.array_equal(idf.lpf_recon_rfft(xz.clone(), 0.25).numpy(), g["recon_q"])
+    np.testing.assert_allclose(idf.lpf_recon_rfft(xz.clone(), 0.5).numpy(), g["recon_fft"], rtol=0, atol=2e-6)
+    assert np.array_equal(idf.upsample_rfft(xz[:, :, :12, :12].clone(), 4).numpy(), g["up4"])
+    assert np.array_equal(idf.upsample_rfft(xz[:, :, :12, :12].clone(), 2, factor=0.5).numpy(), g["up2_f2"])

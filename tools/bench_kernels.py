@@ -144,6 +144,34 @@ def bench_lin(dtype=torch.bfloat16):
     print(f"1x1 + residual + stats    : {t:7.1f} us  {(B*T*C*2*3)/t/1e3:7.1f} GB/s", flush=True)
 
 
+def bench_fir():
+    """upfirdn2d (csrc/fir.hip) on the image shifter's sizes: HBM-bound, algorithmic bytes = in + out."""
+    from afldm_amd.af_libs import equivariance as eq
+    from afldm_amd.af_libs.torch_utils.ops import upfirdn2d as up
+    from afldm_amd.shift_utils.shifters import ImageShifter
+    for dtype in (torch.float32, torch.bfloat16):
+        es = 4 if dtype == torch.float32 else 2
+        img = torch.randn(64, 3, 256, 256, device="cuda").to(dtype)
+        n = img.numel()
+        f6 = torch.rand(1, 6, device="cuda")
+        t = timeit(lambda: ops.upfirdn2d(img, f6, padx0=3, padx1=2))
+        print(f"{dtype}: 6-tap row pass  64x3x256^2: {t:7.1f} us  {2*n*es/t/1e3:7.1f} GB/s", flush=True)
+        f6c = f6.reshape(6, 1).contiguous()
+        t = timeit(lambda: ops.upfirdn2d(img, f6c, pady0=3, pady1=2))
+        print(f"{dtype}: 6-tap col pass  64x3x256^2: {t:7.1f} us  {2*n*es/t/1e3:7.1f} GB/s", flush=True)
+        t = timeit(lambda: eq.apply_fractional_translation(img, 2.375 / 256, 0.5 / 256))
+        print(f"{dtype}: lanczos shift (2 passes + mask): {t:7.1f} us  {4*n*es/t/1e3:7.1f} GB/s", flush=True)
+        sh = ImageShifter()
+        t = timeit(lambda: sh.shift(img, 0.0, 2.375))
+        print(f"{dtype}: bilinear shift (2 passes + mask): {t:7.1f} us  {4*n*es/t/1e3:7.1f} GB/s", flush=True)
+        fb = up.setup_filter([1, 3, 3, 1], device="cuda")
+        x128 = img[:, :, :128, :128].contiguous()
+        t = timeit(lambda: up.upsample2d(x128, fb, up=2))
+        print(f"{dtype}: blur upsample2d 128^2 -> 256^2 (4x4): {t:7.1f} us  {(x128.numel()+n)*es/t/1e3:7.1f} GB/s", flush=True)
+        t = timeit(lambda: up.downsample2d(img, fb, down=2))
+        print(f"{dtype}: blur downsample2d 256^2 -> 128^2 (4x4): {t:7.1f} us  {(x128.numel()+n)*es/t/1e3:7.1f} GB/s", flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "conv"
-    {"conv": bench_conv, "afact": bench_afact, "attn": bench_attn, "lin": bench_lin}[what]()
+    {"conv": bench_conv, "afact": bench_afact, "attn": bench_attn, "lin": bench_lin, "fir": bench_fir}[what]()
