@@ -961,6 +961,133 @@ __global__ void __launch_bounds__(256) k_conv_cin4(ConvP p) {
   }
 }
 
+// conv_in on MFMA (bf16, Cin = 4, 3x3): a [pixels x 36] x [36 x Cout] GEMM that is purely write-bound
+// (25 MB of output at batch 64 against 0.5 MB of input).  K = 36 is padded to two 16x16x32 steps; the
+// im2col rows are gathered straight into the B fragments (lane group g of fragment 0 holds taps 2g and
+// 2g + 1 of its pixel, fragment 1 only tap 8), the weight rows [Cout][36] are the A fragments read from
+// global (13.8 KB, cache resident).  A wave owns 32 pixels x all couts; the tile leaves through a
+// wave-private LDS patch as whole 16-byte rows, and the per-channel GroupNorm partial sums of the stored
+// (rounded) values are reduced across the 16 pixel lanes with DPP shuffles, then across the 4 waves.
+constexpr int CIN4_BM = 128;
+__global__ void __launch_bounds__(256) k_conv_cin4_mfma(ConvP p) {
+  typedef Mma<bf16> MM;
+  typedef MM::Chunk Chunk;
+  extern __shared__ __attribute__((aligned(16))) char smem_c4[];
+  const int SROW = p.Cout + 8;
+  bf16* stg = reinterpret_cast<bf16*>(smem_c4);
+  float* ssum = reinterpret_cast<float*>(smem_c4 + (size_t)CIN4_BM * SROW * sizeof(bf16));   // [4][Cout][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int HW = p.H * p.W;
+  const int mb = blockIdx.x * CIN4_BM, mw = mb + wave * 32;
+  const bf16* x = (const bf16*)p.x1;
+  const bf16* w = (const bf16*)p.w;
+  // ---- B fragments: im2col rows of the wave's 2 x 16 pixels
+  Chunk bq[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int m = mw + 16 * mt + li;
+    const bool live = m < p.M;
+    const int mm = live ? m : 0;
+    const int b = mm / HW, pix = mm - b * HW, oh = pix / p.W, ow = pix - oh * p.W;
+    bf16x4 tp[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int tap = q < 2 ? 2 * lg + q : 8;
+      const int kh = tap / 3, kw = tap - 3 * kh;
+      const int ih = oh + kh - 1, iw = ow + kw - 1;
+      const bool ok = live && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && (q < 2 || lg == 0);
+      bf16x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (bf16)0.0f;
+      if (ok) v = *reinterpret_cast<const bf16x4*>(x + ((size_t)(b * p.H + ih) * p.W + iw) * 4);
+      tp[q] = v;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      bq[mt][0][e] = tp[0][e];
+      bq[mt][0][4 + e] = tp[1][e];
+      bq[mt][1][e] = tp[2][e];
+      bq[mt][1][4 + e] = (bf16)0.0f;
+    }
+  }
+  const int NT = p.Cout / 16;
+  bf16* wst = stg + (size_t)wave * 32 * SROW;
+  for (int t = 0; t < NT; ++t) {
+    // ---- A fragments: weight row 16 t + li, k = 8 lg .. 8 lg + 7 and (lg == 0) k = 32 .. 35
+    const bf16* wr = w + (size_t)(16 * t + li) * 36;
+    Chunk a0, a1 = MM::zero();
+    {
+      const bf16x4 lo = *reinterpret_cast<const bf16x4*>(wr + 8 * lg);
+      const bf16x4 hi = *reinterpret_cast<const bf16x4*>(wr + 8 * lg + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a0[e] = lo[e]; a0[4 + e] = hi[e]; }
+      if (lg == 0) {
+        const bf16x4 tl = *reinterpret_cast<const bf16x4*>(wr + 32);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a1[e] = tl[e];
+      }
+    }
+    const int n0 = 16 * t + 4 * lg;
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = p.bias ? p.bias[n0 + r] : 0.f;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      MM::mma(acc, a0, bq[mt][0]);
+      MM::mma(acc, a1, bq[mt][1]);
+      bf16x4 o;
+      const bool live = mw + 16 * mt + li < p.M;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o[r] = (bf16)(acc[r] + bv[r]);
+        const float vr = live ? (float)o[r] : 0.f;
+        s1[r] += vr;
+        s2[r] = fmaf(vr, vr, s2[r]);
+      }
+      *reinterpret_cast<bf16x4*>(wst + (size_t)(16 * mt + li) * SROW + n0) = o;
+    }
+    if (p.stats_out) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          s1[r] += __shfl_xor(s1[r], o, 64);
+          s2[r] += __shfl_xor(s2[r], o, 64);
+        }
+      }
+      if (li == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x2*>(ssum + ((size_t)wave * p.Cout + n0 + r) * 2) = f32x2{s1[r], s2[r]};
+      }
+    }
+  }
+  __syncthreads();
+  // ---- copy out: whole rows, 16 bytes per lane (the patch is wave-private, the barrier is for ssum)
+  {
+    const int cpr = p.Cout / 8;                  // 16-byte chunks per row
+    bf16* y = (bf16*)p.y;
+    for (int i = lane; i < 32 * cpr; i += 64) {
+      const int row = i / cpr, c = i - row * cpr;
+      const int m = mw + row;
+      if (m < p.M) st16<Chunk>(y + (size_t)m * p.y_ld + c * 8, ld16<Chunk>(wst + (size_t)row * SROW + c * 8));
+    }
+  }
+  if (p.stats_out) {
+    const int b = mb / HW, sidx = (mb - b * HW) / CIN4_BM;
+    for (int c = tid; c < p.Cout; c += 256) {
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) {
+        a += ssum[((size_t)wv * p.Cout + c) * 2];
+        q += ssum[((size_t)wv * p.Cout + c) * 2 + 1];
+      }
+      *reinterpret_cast<f32x2*>(p.stats_out + (((size_t)b * p.stats_S + sidx) * p.Cout + c) * 2) = f32x2{a, q};
+    }
+  }
+}
+
 // conv_out (Cout = 4): one wave per pixel, lanes stride the channels, butterfly reduce.
 template <typename T, int NOUT>
 __global__ void __launch_bounds__(256) k_conv_small_cout(ConvP p) {
@@ -1253,6 +1380,15 @@ static Exec resolve_exec(const afldm_conv_args* a) {
   return e;
 }
 
+// conv_in on MFMA (k_conv_cin4_mfma): bf16, Cin = 4, 3x3, whole 128-pixel blocks inside one sample
+template <typename T>
+static bool cin4_mfma_ok(const afldm_conv_args* a) {
+  static const bool off = getenv("AFLDM_NO_CIN4_MFMA") && atoi(getenv("AFLDM_NO_CIN4_MFMA")) != 0;
+  return sizeof(T) == 2 && !off && a->C1 == 4 && a->C2 == 0 && a->KS == 3 && a->Cout % 16 == 0 && a->Cout <= 512 &&
+         !a->temb && !a->residual && a->out_mode == 0 && !a->y2 && a->y_ld % 8 == 0 && (a->H * a->W) % CIN4_BM == 0 &&
+         aligned16(a->y) && (reinterpret_cast<uintptr_t>(a->x1) & 7) == 0 && (reinterpret_cast<uintptr_t>(a->w) & 7) == 0;
+}
+
 // Where the GroupNorm partial sums of the output come from, and their split count S.
 enum { ST_EPILOGUE = 1, ST_REDUCE = 2, ST_STANDALONE = 3 };
 static int reduce_stats_splits(int HW) { return HW >= 64 ? (HW / 16 > 32 ? 32 : HW / 16) : 1; }
@@ -1270,6 +1406,10 @@ static int stats_mode(const afldm_conv_args* a, const Exec& e, int* S) {
   if (e.pl.kind == 0 && e.splitk == 1 && kVariants[e.vid].ver >= 2 && HW % kVariants[e.vid].bm == 0 && vec16 &&
       !getenv("AFLDM_CONV_NOSTAGE")) {
     *S = HW / kVariants[e.vid].bm;
+    return ST_EPILOGUE;
+  }
+  if (cin4_mfma_ok<T>(a)) {
+    *S = HW / CIN4_BM;
     return ST_EPILOGUE;
   }
   *S = gn_splits(HW);
@@ -1318,7 +1458,17 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
   p.stats_S = 1;
   if (a->stats_out) smode = stats_mode<T>(a, ex, &p.stats_S);
   int rc = AFLDM_OK;
-  if (pl.kind == 1 && a->C1 == 4 && a->C2 == 0 && a->KS == 3 && a->Cout % 16 == 0 && a->Cout * 36 * 4 <= 64 * 1024 &&
+  if (pl.kind == 1 && cin4_mfma_ok<T>(a)) {
+    if (smode == ST_EPILOGUE) p.stats_out = a->stats_out;
+    const int lds = CIN4_BM * (a->Cout + 8) * 2 + 4 * a->Cout * 2 * (int)sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)k_conv_cin4_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    k_conv_cin4_mfma<<<(p.M + CIN4_BM - 1) / CIN4_BM, 256, lds, st>>>(p);
+    rc = check_launch("afldm_conv2d(cin4_mfma)");
+  } else if (pl.kind == 1 && a->C1 == 4 && a->C2 == 0 && a->KS == 3 && a->Cout % 16 == 0 && a->Cout * 36 * 4 <= 64 * 1024 &&
       !a->temb && !a->residual && a->out_mode == 0 && a->y_ld % 4 == 0) {
     const int lds = a->Cout * 36 * (int)sizeof(float);
     k_conv_cin4<T, 4, 3><<<(p.M + 63) / 64, 256, lds, st>>>(p);

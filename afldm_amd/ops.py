@@ -211,6 +211,8 @@ def _tensor_stats(x, out=None):
     tok = _begin()
     check(lib.afldm_gn_stats(ptr(x), C, ptr(out), B, HW, _code(x), stream_ptr()), "gn_stats")
     _end(tok, "gn_stats", 0, B * HW * C * x.element_size())
+    if st is None:
+        x.gn_partial = out      # a skip connection is normalised twice (down block, then up block): one pass
     return out
 
 

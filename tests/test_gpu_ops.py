@@ -261,7 +261,9 @@ def test_conv2d_every_gemm_variant(dtype):
     (2, 4, 4, 256, 256, 128, 3, True),     # split-K: statistics from the reduction kernel
     (2, 2, 2, 256, 0, 128, 3, False),      # tiny plane, split-K
     (2, 12, 12, 64, 0, 72, 3, False),      # H*W = 144: no fused producer -> stand-alone pass
-    (2, 32, 32, 4, 0, 192, 3, False),      # conv_in (direct kernel) -> stand-alone pass
+    (2, 32, 32, 4, 0, 192, 3, False),      # conv_in: MFMA kernel with fused statistics (bf16), direct kernel (fp32)
+    (3, 16, 16, 4, 0, 64, 3, False),       # conv_in shape with 2 statistic splits per sample
+    (2, 12, 12, 4, 0, 64, 3, False),       # conv_in shape whose plane is no multiple of 128 pixels: direct kernel
     (2, 16, 16, 192, 0, 192, 1, True),     # 1x1 (attention to_out + residual)
 ])
 def test_conv2d_emits_groupnorm_statistics(dtype, case):
