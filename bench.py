@@ -147,6 +147,10 @@ def main():
             done += n
 
     run_steps(args.warmup if args.warmup > 0 else 1)       # includes graph capture
+    if world > 1:
+        # RCCL builds its communicator rings / channels lazily on the first collective of a kind:
+        # that one-off set-up belongs to the warm-up, not to the timed steps
+        torch.distributed.all_gather_into_tensor(final, eng.lat)
     torch.cuda.synchronize()
     parallel.barrier()
     torch.cuda.synchronize()
