@@ -1380,6 +1380,10 @@ static Exec resolve_exec(const afldm_conv_args* a) {
   return e;
 }
 
+// weights-in-registers kernel for the short-K attention projections (lin.hip)
+int lin_wreg_bm(const afldm_conv_args* a);
+int lin_wreg_launch(const afldm_conv_args* a, hipStream_t st);
+
 // conv_in on MFMA (k_conv_cin4_mfma): bf16, Cin = 4, 3x3, whole 128-pixel blocks inside one sample
 template <typename T>
 static bool cin4_mfma_ok(const afldm_conv_args* a) {
@@ -1458,6 +1462,7 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
   p.stats_S = 1;
   if (a->stats_out) smode = stats_mode<T>(a, ex, &p.stats_S);
   int rc = AFLDM_OK;
+  if (lin_wreg_bm(a)) return lin_wreg_launch(a, st);
   if (pl.kind == 1 && cin4_mfma_ok<T>(a)) {
     if (smode == ST_EPILOGUE) p.stats_out = a->stats_out;
     const int lds = CIN4_BM * (a->Cout + 8) * 2 + 4 * a->Cout * 2 * (int)sizeof(float);
@@ -1567,6 +1572,7 @@ extern "C" int afldm_conv2d_stats_splits(const afldm_conv_args* a) {
 
 extern "C" size_t afldm_conv2d_workspace(const afldm_conv_args* a) {
   if (!a || (a->dtype != AFLDM_F32 && a->dtype != AFLDM_BF16)) return 0;
+  if (lin_wreg_bm(a)) return 0;
   Plan pl = make_plan(a, a->dtype == AFLDM_F32 ? 16 : 32);
   if (pl.kind != 0 || pl.splitk <= 1) return 0;
   return (size_t)pl.splitk * a->B * a->H * a->W * a->Cout * sizeof(float);

@@ -184,6 +184,52 @@ def test_af_resample_plane(dtype, N, C, B):
     assert float(d) <= tol, float(d)
 
 
+@pytest.mark.parametrize("C,B,HW", [(192, 4, 1024), (192, 8, 1024), (384, 16, 256), (384, 64, 64)])
+def test_weights_in_registers_projections(C, B, HW):
+    """The short-K attention projections (lin.hip: weights in registers, persistent workgroups) at
+    eligible sizes (bf16, K = 192 / 384, M >= 4096): fused q|k|v with channel-major V^T, and to_out with
+    residual + GroupNorm partial sums.  Reference 1: fp32 torch.  Reference 2 (bit-exact): the general
+    implicit-GEMM kernel, reached by appending 16 rows so that M is no multiple of the token tile."""
+    ops = _ops()
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(C + B)
+    T = HW
+    x = torch.randn(B, T, C, generator=g).to(dt).cuda()
+    w = (torch.randn(3 * C, 1, 1, C, generator=g) / C ** 0.5).to(dt).cuda()
+    bias = torch.randn(3 * C, generator=g).cuda()
+    qk, vt = ops.linear_split(x, w, bias, 2 * C)
+    ref = x.float() @ w.view(3 * C, C).float().t() + bias
+    assert (qk.float() - ref[..., :2 * C]).abs().max() <= 3e-2 * ref.abs().max()
+    assert (vt.float() - ref[..., 2 * C:].transpose(1, 2)).abs().max() <= 3e-2 * ref.abs().max()
+    # general kernel on the same rows (one long "sample" of B*T + 16 tokens is not tile-aligned)
+    xl = torch.cat([x.view(1, B * T, C), torch.zeros(1, 16, C, dtype=dt, device="cuda")], 1).contiguous()
+    qk2, vt2 = ops.linear_split(xl, w, bias, 2 * C)
+    assert torch.equal(qk.view(B * T, 2 * C), qk2[0, :B * T])
+    assert torch.equal(vt.transpose(1, 2).reshape(B * T, C), vt2[0].t()[:B * T])
+    # to_out: residual + statistics
+    side = int(round(HW ** 0.5))
+    o = torch.randn(B, side, side, C, generator=g).to(dt).cuda()
+    res = torch.randn(B, side, side, C, generator=g).to(dt).cuda()
+    wo = (torch.randn(C, 1, 1, C, generator=g) / C ** 0.5).to(dt).cuda()
+    bo = torch.randn(C, generator=g).cuda()
+    y = ops.conv2d(o, wo, bo, residual=res, want_stats=True)
+    yref = o.float() @ wo.view(C, C).float().t() + bo + res.float()
+    assert (y.float() - yref).abs().max() <= 3e-2 * yref.abs().max()
+    ol = torch.cat([o.view(1, B * HW, 1, C), torch.zeros(1, 16, 1, C, dtype=dt, device="cuda")], 1).contiguous()
+    rl = torch.cat([res.view(1, B * HW, 1, C), torch.zeros(1, 16, 1, C, dtype=dt, device="cuda")], 1).contiguous()
+    y2 = ops.conv2d(ol, wo, bo, residual=rl)
+    assert torch.equal(y.view(B * HW, C), y2[0, :B * HW, 0])
+    st = y.gn_partial
+    assert st.shape[0] == B and st.shape[2:] == (C, 2)
+    yv = y.float()
+    assert (st.double().sum(1)[..., 0].cpu() - yv.sum((1, 2)).double().cpu()).abs().max() <= 1e-3 * (1 + yv.sum((1, 2)).abs().max().item())
+    assert (st.double().sum(1)[..., 1].cpu() - (yv * yv).sum((1, 2)).double().cpu()).abs().max() <= 1e-3 * (1 + (yv * yv).sum((1, 2)).max().item())
+    # repeated launches are deterministic (no cross-workgroup races in the ring / staging)
+    for _ in range(3):
+        qk3, vt3 = ops.linear_split(x, w, bias, 2 * C)
+        assert torch.equal(qk3, qk) and torch.equal(vt3, vt)
+
+
 CONV_CASES = [
     # B, H, W, C1, C2, Cout, KS, temb, residual
     (2, 16, 16, 64, 0, 64, 3, False, False),
