@@ -52,19 +52,25 @@ def shift_equivariance(sd, cfg, init_latent, offsets, num_inference_steps=50, ra
     return base, out
 
 
-def time_denoise_steps(sd, cfg, batch=1, steps=2, threads=None, seed=1234):
-    """cpu_baseline leg of bench.py: seconds per UNet+scheduler step on the host cores."""
+def time_denoise_steps(sd, cfg, batch=1, steps=2, threads=None, seed=1234, budget_s=None):
+    """cpu_baseline leg of bench.py: (seconds per UNet+scheduler step, steps timed) on the host cores.
+    With budget_s the loop stops once that much wall time has been spent (at least 2, at most `steps`)."""
     if threads:
         torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(seed)
     lat = torch.randn(batch, cfg["in_channels"], cfg["sample_size"], cfg["sample_size"], generator=g)
     sched = DDIM()
     sched.set_timesteps(50)
+    steps = min(steps, 49)
     ts = sched.timesteps[:steps + 1]
     eps = unet_forward(sd, cfg, lat, ts[0])        # warm-up (FFT plans, oneDNN primitives)
     t0 = time.perf_counter()
+    done = 0
     for t in ts[1:]:
         eps = unet_forward(sd, cfg, lat, t)
         lat = sched.step(eps, t, lat)
+        done += 1
+        if budget_s is not None and done >= 2 and time.perf_counter() - t0 >= budget_s:
+            break
     dt = time.perf_counter() - t0
-    return dt / steps
+    return dt / done, done
