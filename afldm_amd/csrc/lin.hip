@@ -47,8 +47,8 @@ struct LinCfg {
   static_assert((SROW * 2) % 16 == 0 && (TROW * 2) % 16 == 0, "16-byte staged rows");
 };
 
-template <int K, int NPW, int BM, int NST, int NWC, int MINW>
-__global__ void __launch_bounds__((NWC + 1) * 64, MINW) k_lin_wreg(LinP p) {
+template <int K, int NPW, int BM, int NST, int NWC, int NPROD, int MINW>
+__global__ void __launch_bounds__((NWC + NPROD) * 64, MINW) k_lin_wreg(LinP p) {
   typedef LinCfg<K, NPW, BM, NST, NWC> CF;
   typedef Mma<bf16> MM;
   typedef MM::Chunk Chunk;
@@ -62,14 +62,17 @@ __global__ void __launch_bounds__((NWC + 1) * 64, MINW) k_lin_wreg(LinP p) {
   const int chunk = l % p.nchunks, t0 = l / p.nchunks, tstride = G / p.nchunks;
   const int nmine = t0 < p.ntiles ? (p.ntiles - t0 + tstride - 1) / tstride : 0;
 
-  if (wave == CF::NWC) {
+  if (wave >= CF::NWC) {
+    const int pw = wave - CF::NWC;                 // producer index: instruction j belongs to producer j % NPROD
+    static_assert(CF::DMA_PER_TILE % NPROD == 0, "DMA instructions must divide among the producer waves");
     // ---------------- producer: x tile t -> ring slot.  Instruction j covers plane j / RG, rows 8 (j % RG) .. +7;
     // lane l: row + (l >> 3), LDS position l & 7 holds source chunk (l & 7) ^ ((row >> 1) & 7).
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)((long long)p.M * K * 2), 0x00020000);
     auto issue = [&](int slot, int t) {
       const int soff = t * BM * K * 2;
 #pragma unroll
-      for (int j = 0; j < CF::DMA_PER_TILE; ++j) {
+      for (int jj = 0; jj < CF::DMA_PER_TILE / NPROD; ++jj) {
+        const int j = pw + NPROD * jj;
         const int plane = j / CF::RG, rg = j % CF::RG;
         const int row = 8 * rg + (lane >> 3);
         const int src = (lane & 7) ^ ((row >> 1) & 7);
@@ -85,7 +88,7 @@ __global__ void __launch_bounds__((NWC + 1) * 64, MINW) k_lin_wreg(LinP p) {
     int slot = NST - 1;
     for (int i = 0; i < ((p.dbg & 32) ? 1 : nmine); ++i) {
       // tile i has landed once at most the NST - 2 younger tiles are outstanding (fewer at the tail)
-      if (i + NST - 1 <= nmine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * CF::DMA_PER_TILE) : "memory");
+      if (i + NST - 1 <= nmine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * CF::DMA_PER_TILE / NPROD) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                    // tile i visible; the slot of tile i - 1 is free again
       if (i + NST - 1 < nmine) issue(slot, t0 + (i + NST - 1) * tstride);
@@ -191,12 +194,12 @@ __global__ void __launch_bounds__((NWC + 1) * 64, MINW) k_lin_wreg(LinP p) {
   }
 }
 
-template <int K, int NPW, int BM, int NST, int NWC, int MINW>
+template <int K, int NPW, int BM, int NST, int NWC, int NPROD, int MINW>
 static int launch_lin(LinP p, hipStream_t st) {
   typedef LinCfg<K, NPW, BM, NST, NWC> CF;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_lin_wreg<K, NPW, BM, NST, NWC, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS);
+    (void)hipFuncSetAttribute((const void*)k_lin_wreg<K, NPW, BM, NST, NWC, NPROD, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS);
     attr_set = true;
   }
   p.ntiles = p.M / BM;
@@ -204,7 +207,7 @@ static int launch_lin(LinP p, hipStream_t st) {
   const long long items = (long long)p.ntiles * p.nchunks;
   long long g = items < 512 ? items : 512;
   g = (g / p.nchunks) * p.nchunks;
-  k_lin_wreg<K, NPW, BM, NST, NWC, MINW><<<(int)g, (NWC + 1) * 64, CF::LDS, st>>>(p);
+  k_lin_wreg<K, NPW, BM, NST, NWC, NPROD, MINW><<<(int)g, (NWC + NPROD) * 64, CF::LDS, st>>>(p);
   return check_launch("afldm_conv2d(lin_wreg)");
 }
 
@@ -237,8 +240,9 @@ int lin_wreg_launch(const afldm_conv_args* a, hipStream_t st) {
   static const int s_dbg = getenv("AFLDM_LIN_DBG") ? atoi(getenv("AFLDM_LIN_DBG")) : 0;   // timing decomposition (garbage results)
   p.dbg = s_dbg;
   static const int s_wide = getenv("AFLDM_LIN_WIDE") ? atoi(getenv("AFLDM_LIN_WIDE")) : 0;
-  if (s_wide) return a->C1 == 192 ? launch_lin<192, 48, 32, 4, 4, 3>(p, st) : launch_lin<384, 32, 32, 2, 4, 3>(p, st);
-  return a->C1 == 192 ? launch_lin<192, 16, 32, 4, 12, 7>(p, st) : launch_lin<384, 16, 32, 2, 8, 5>(p, st);
+  if (s_wide == 1) return a->C1 == 192 ? launch_lin<192, 48, 32, 4, 4, 1, 3>(p, st) : launch_lin<384, 32, 32, 2, 4, 1, 3>(p, st);
+  if (s_wide == 2) return a->C1 == 192 ? launch_lin<192, 16, 32, 4, 12, 1, 7>(p, st) : launch_lin<384, 16, 32, 2, 8, 1, 5>(p, st);
+  return a->C1 == 192 ? launch_lin<192, 16, 32, 4, 12, 2, 7>(p, st) : launch_lin<384, 16, 32, 2, 8, 2, 5>(p, st);
 }
 
 }  // namespace afldm
