@@ -189,6 +189,39 @@ static int gn_check(const char* fn, const void* x1, int C1, const void* x2, int 
   return AFLDM_OK;
 }
 
+// Fold S_in row splits of per-channel partial sums into S_out (S_in % S_out == 0, fixed order).  The GEMM
+// epilogue emits one split per 128-pixel tile: 512 per sample on the 256^2 planes of the AF-VAE, and every
+// consumer walks cpg x S partials per group in its prologue (k_gn_apply re-read 524 KB of partials per 65 KB
+// of payload there).
+__global__ void __launch_bounds__(256) k_gn_fold(const float* __restrict__ in, float* __restrict__ out, int C, int S_in,
+                                                 int S_out, size_t total) {
+  const int r = S_in / S_out;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const size_t bs = i / C;              // b * S_out + so
+    const size_t b = bs / S_out, so = bs - b * S_out;
+    const float* q = in + ((b * S_in + so * r) * C + c) * 2;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < r; ++k) {
+      const f32x2 v = *reinterpret_cast<const f32x2*>(q + (size_t)k * C * 2);
+      s1 += v[0];
+      s2 += v[1];
+    }
+    *reinterpret_cast<f32x2*>(out + i * 2) = f32x2{s1, s2};
+  }
+}
+
+extern "C" int afldm_gn_fold(const float* stats_in, int S_in, float* stats_out, int S_out, int B, int C,
+                             afldm_stream_t stream) {
+  AFLDM_REQUIRE(stats_in && stats_out, AFLDM_ENULL, "afldm_gn_fold: NULL pointer");
+  AFLDM_REQUIRE(B > 0 && C > 0 && S_in > 0 && S_out > 0 && S_in % S_out == 0, AFLDM_ESHAPE,
+                "afldm_gn_fold: S_in=%d must be a multiple of S_out=%d", S_in, S_out);
+  const size_t total = (size_t)B * S_out * C;
+  const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  k_gn_fold<<<grid, 256, 0, (hipStream_t)stream>>>(stats_in, stats_out, C, S_in, S_out, total);
+  return check_launch("afldm_gn_fold");
+}
+
 extern "C" int afldm_gn_stats_splits(int HW) { return gn_splits(HW); }
 
 extern "C" int afldm_gn_stats(const void* x, int C, float* part, int B, int HW, int dtype, afldm_stream_t stream) {

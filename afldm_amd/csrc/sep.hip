@@ -194,14 +194,23 @@ __global__ void __launch_bounds__(256) k_sep(SepP p) {
 __global__ void __launch_bounds__(256) k_gn_table(GnStats gs, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, float* __restrict__ table, int B, int C,
                                                   int G, double n, float eps) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * C) return;
-  const int b = i / C, c = i - b * C, cpg = C / G;
+  // one wave per (sample, group): the cpg x S partials are summed across the lanes (a thread per channel
+  // walked them serially: 100 us per call at S = 512)
+  const int lane = threadIdx.x & 63;
+  const int wg = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wg >= B * G) return;
+  const int b = wg / G, g = wg - b * G, cpg = C / G;
+  double s1, s2;
+  gn_group_sums_wave(gs, b, g, cpg, lane, s1, s2);
   float mean, rstd;
-  gn_finalize(gs, b, c / cpg, cpg, n, eps, mean, rstd);
-  const float k = rstd * gamma[c];
-  table[2 * i + 0] = k;
-  table[2 * i + 1] = beta[c] - mean * k;
+  gn_mean_rstd(s1, s2, n, eps, mean, rstd);
+  for (int j = lane; j < cpg; j += 64) {
+    const int c = g * cpg + j;
+    const float k = rstd * gamma[c];
+    const size_t i = (size_t)b * C + c;
+    table[2 * i + 0] = k;
+    table[2 * i + 1] = beta[c] - mean * k;
+  }
 }
 
 // row softmax: y[r][:] = softmax(x[r][:] * scale), one workgroup per row (cols <= 16384)
@@ -292,9 +301,8 @@ extern "C" int afldm_gn_table(const float* stats, int S, const float* gamma, con
                               int G, int HW, float eps, afldm_stream_t stream) {
   AFLDM_REQUIRE(stats && gamma && beta && table, AFLDM_ENULL, "afldm_gn_table: NULL pointer");
   AFLDM_REQUIRE(B > 0 && C > 0 && G > 0 && C % G == 0 && HW > 0 && S > 0, AFLDM_ESHAPE, "afldm_gn_table: bad shape");
-  const int n = B * C;
   const GnStats gs{stats, nullptr, C, 0, S, 0};
-  k_gn_table<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(gs, gamma, beta, table, B, C, G, (double)HW * (C / G), eps);
+  k_gn_table<<<(B * G + 3) / 4, 256, 0, (hipStream_t)stream>>>(gs, gamma, beta, table, B, C, G, (double)HW * (C / G), eps);
   return check_launch("afldm_gn_table");
 }
 

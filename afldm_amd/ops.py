@@ -178,6 +178,9 @@ def _cat_args(x1, x2):
     return C1, x2, x2.shape[-1]
 
 
+_MAX_SPLITS = 32       # row splits of GroupNorm partial sums a consumer should have to walk
+
+
 class GNStats:
     """Per-channel GroupNorm partial sums of a tensor or of a virtual concat x1|x2:
     st1 [B, S1, C1, 2], st2 [B, S2, C2, 2] fp32 (sum, sum of squares per pixel split).  Producers:
@@ -544,6 +547,11 @@ def conv2d(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, o
     tok = _begin()
     check(lib.afldm_conv2d(ctypes.byref(a), stream_ptr()), "conv2d")
     if st is not None:
+        if st.shape[1] > _MAX_SPLITS and st.shape[1] % _MAX_SPLITS == 0:
+            # one split per 128-pixel tile is 512 per sample on a 256^2 plane: fold before the consumers walk them
+            folded = torch.empty((a.B, _MAX_SPLITS, Cout, 2), dtype=torch.float32, device=x1.device)
+            check(lib.afldm_gn_fold(ptr(st), st.shape[1], ptr(folded), _MAX_SPLITS, a.B, Cout, stream_ptr()), "gn_fold")
+            st = folded
         out.gn_partial = st
     if tok is not None:
         M, Ct = a.B * a.H * a.W, a.C1 + a.C2

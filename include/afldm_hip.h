@@ -104,6 +104,11 @@ int afldm_gn_apply(const void* x1, int C1, const void* x2, int C2, const float* 
                    const float* stats2, int S2, const float* gamma, const float* beta, void* y, int B,
                    int HW, int G, float eps, int act, int dtype, afldm_stream_t stream);
 
+/* Fold S_in row splits of per-channel partial sums [B][S_in][C][2] into [B][S_out][C][2] (S_in % S_out == 0):
+ * the GEMM epilogue emits one split per 128-pixel tile, 512 per sample on the AF-VAE's 256^2 planes. */
+int afldm_gn_fold(const float* stats_in, int S_in, float* stats_out, int S_out, int B, int C,
+                  afldm_stream_t stream);
+
 /* ---- alias-free operators -----------------------------------------------------------------
  * afldm_af_act: [GroupNorm-apply ->] WarpedNonlinearity(SiLU) (af_blocks.py:19-28):
  *   y = D silu(U xn U^T) D^T per (b, c) plane,  xn = GN-applied x when stats1 != NULL
