@@ -33,7 +33,10 @@ def vae_decode(vae, x):
 
 @torch.no_grad()
 def shift_ldm(pipeline, num_inference_steps=50, num_shift_steps=16, output_path="results/shift_ldm.gif",
-              input_path=None, generator=None, rank=0, world=1):
+              input_path=None, generator=None, rank=0, world=1, batch_offsets=True):
+    """batch_offsets: the LOAD passes of this rank's offsets run as ONE batch (samples are independent; the
+    cross-frame K/V of the stored pass is shared by the whole batch) instead of the reference's one B = 1
+    sampler run per offset (shift_ldm_ffhq.py:124-151) - 50 UNet evaluations instead of 50 per offset."""
     device = pipeline.device
     vae, unet, scheduler = pipeline.vae, pipeline.unet, pipeline.scheduler
     pipeline.set_progress_bar_config(disable=True)
@@ -73,10 +76,15 @@ def shift_ldm(pipeline, num_inference_steps=50, num_shift_steps=16, output_path=
         offsets = torch.linspace(1 / ratio, num_shift_steps / ratio, num_shift_steps)
         mine = list(range(rank, num_shift_steps, world))
         frames, errors = {}, {}
+        shifted = {i: latent_shifter.shift(init_latent, 0, float(offsets[i])) for i in mine}
+        if batch_offsets and len(mine) > 1:
+            den_all = denoise(torch.cat([shifted[i][0] for i in mine], 0))
+            dens = {i: den_all[k:k + 1] for k, i in enumerate(mine)}
+        else:
+            dens = {i: denoise(shifted[i][0]) for i in mine}
         for i in mine:
             tj = float(offsets[i])
-            shifted, mask = latent_shifter.shift(init_latent, 0, tj)
-            den = denoise(shifted)
+            den, mask = dens[i], shifted[i][1]
             ref_lat, _ = latent_shifter.shift(denoised, 0, tj)
             errors[i] = float(mask_mse(den, ref_lat, mask))
             if vae is not None:
@@ -104,7 +112,7 @@ def vae_encode_mode(vae, x):
 
 @torch.no_grad()
 def shift_ldm_sr(pipeline, num_inference_steps=50, num_shift_steps=16, output_path="results/shift_ldm_sr.gif",
-                 input_path=None, image=None, rank=0, world=1):
+                 input_path=None, image=None, rank=0, world=1, batch_offsets=True):
     """Fractional-shift equivariance of x4 super-resolution with I2SB - the flow of reference
     scripts/shift_ldm_sr.py:43-150: degrade (bicubic x1/4, nearest x4), VAE-encode, denoise with
     cross-frame attention STORE, then for every offset shift the initial latent, denoise in LOAD mode
@@ -147,10 +155,16 @@ def shift_ldm_sr(pipeline, num_inference_steps=50, num_shift_steps=16, output_pa
         rec_img = vae_decode(vae, denoised)
         offsets = torch.linspace(1 / ratio, num_shift_steps / ratio, num_shift_steps)
         frames, errors = {}, {}
-        for i in range(rank, num_shift_steps, world):
+        mine = list(range(rank, num_shift_steps, world))
+        shifts = {i: latent_shifter.shift(init_latent, 0, float(offsets[i])) for i in mine}
+        if batch_offsets and len(mine) > 1:      # one batched LOAD pass for this rank's offsets (see shift_ldm)
+            den_all = denoise(torch.cat([shifts[i][0] for i in mine], 0))
+            dens = {i: den_all[k:k + 1] for k, i in enumerate(mine)}
+        else:
+            dens = {i: denoise(shifts[i][0]) for i in mine}
+        for i in mine:
             tj = float(offsets[i])
-            shifted, mask = latent_shifter.shift(init_latent, 0, tj)
-            den = denoise(shifted)
+            (shifted, mask), den = shifts[i], dens[i]
             ref_lat, _ = latent_shifter.shift(denoised, 0, tj)
             errors[i] = float(mask_mse(den, ref_lat, mask))
             gt, _ = image_shifter.shift(rec_img, 0, tj * ratio)

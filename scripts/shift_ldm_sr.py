@@ -24,6 +24,8 @@ def parse_args():
     p.add_argument("--random-init", action="store_true")
     p.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     p.add_argument("--seed", type=int, default=1234)
+    p.add_argument("--sequential", action="store_true",
+                   help="one B = 1 sampler run per offset like the reference loop (default: all offsets of a rank in one batch)")
     return p.parse_args()
 
 
@@ -66,7 +68,7 @@ def main():
     make_af_unet(pipe.unet)
     make_af_vae_from_config(pipe.vae)
     frames, errs = shift_ldm_sr(pipe, args.num_inference_steps, args.shift_steps, args.output_path, args.input_path,
-                                image=image, rank=rank, world=world)
+                                image=image, rank=rank, world=world, batch_offsets=not args.sequential)
     if rank == 0:
         print(f"wrote {args.output_path}: {len(frames)} frames; latent equivariance mask-MSE per offset:",
               " ".join(f"{e:.3e}" for e in errs))

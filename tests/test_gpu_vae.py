@@ -212,6 +212,12 @@ def test_shift_harness_end_to_end(tmp_path):
     assert len(frames) == 2 and frames[0].shape == (1, 3, 3 * 128, 128) and out.exists() and out.stat().st_size > 0
     assert all(np.isfinite(e) and e >= 0 for e in errs)
     assert {k: type(v) for k, v in get_unet_attn_processors(pipe.unet).items()} == before
+    # the batched LOAD pass (default) reproduces the reference's one-run-per-offset loop sample for sample
+    frames_seq, errs_seq = shift_ldm(pipe, num_inference_steps=3, num_shift_steps=2, output_path=None,
+                                     generator=torch.Generator().manual_seed(1), batch_offsets=False)
+    for a, b in zip(frames, frames_seq):
+        assert (a - b).abs().max() <= 1e-4
+    assert np.allclose(errs, errs_seq, rtol=1e-3, atol=1e-9)
 
 
 @pytest.mark.gpu
