@@ -63,7 +63,7 @@ def _load():
         "afldm_af_pack_bytes": ([ip, ip], c_size_t),
         "afldm_af_pack": ([vp, vp, ip, ip, vp, vp], c_int),
         "afldm_af_up2": ([vp, vp, vp, vp, ip, ip, ip, ip, vp], c_int),
-        "afldm_af_lpf_down2": ([vp, vp, vp, vp, ip, ip, ip, ip, vp], c_int),
+        "afldm_af_lpf_down2": ([vp, vp, vp, vp, vp, ip, ip, ip, ip, vp], c_int),
         "afldm_af_resample": ([vp, vp, vp, vp, ip, ip, ip, ip, ip, vp], c_int),
         "afldm_sep_pass": ([POINTER(SepArgs), vp], c_int),
         "afldm_af_resample_hw": ([vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp], c_int),

@@ -656,7 +656,9 @@ __global__ void __launch_bounds__(256) k_axis_contract(const TI* __restrict__ in
 template <typename TI, typename TO, int A, int ROUT>
 __global__ void __launch_bounds__(256) k_axis_contract_reg(const TI* __restrict__ in, TO* __restrict__ out,
                                                            const float* __restrict__ M, int B, int Jd, int C,
-                                                           int axis) {
+                                                           int axis, float* __restrict__ stats = nullptr) {
+  // stats (axis 1 only): a thread owns one output row of 4 channels, so the per-channel GroupNorm partial
+  // sums of the stored values come for free with one split per output row: stats[b][Jd][C][2]
   const int nq = C / 4;
   const size_t total = (size_t)B * Jd * nq;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -675,6 +677,7 @@ __global__ void __launch_bounds__(256) k_axis_contract_reg(const TI* __restrict_
       stride = C;
     }
     float v[A][4];
+    float ps[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < A; ++k) load4<TI>(in + bin + k * stride + c, v[k][0], v[k][1], v[k][2], v[k][3]);
 #pragma unroll 4
@@ -689,6 +692,19 @@ __global__ void __launch_bounds__(256) k_axis_contract_reg(const TI* __restrict_
         a3 = fmaf(m, v[k][3], a3);
       }
       store4<TO>(out + bout + r * stride + c, a0, a1, a2, a3);
+      if (stats) {
+        const float q0 = to_f32(from_f32<TO>(a0)), q1 = to_f32(from_f32<TO>(a1));
+        const float q2 = to_f32(from_f32<TO>(a2)), q3 = to_f32(from_f32<TO>(a3));
+        ps[0] += q0; ps[1] = fmaf(q0, q0, ps[1]);
+        ps[2] += q1; ps[3] = fmaf(q1, q1, ps[3]);
+        ps[4] += q2; ps[5] = fmaf(q2, q2, ps[5]);
+        ps[6] += q3; ps[7] = fmaf(q3, q3, ps[7]);
+      }
+    }
+    if (stats) {
+      float* so = stats + (line * C + c) * 2;
+      *reinterpret_cast<f32x4*>(so) = f32x4{ps[0], ps[1], ps[2], ps[3]};
+      *reinterpret_cast<f32x4*>(so + 4) = f32x4{ps[4], ps[5], ps[6], ps[7]};
     }
   }
 }
@@ -962,7 +978,7 @@ static int af_act_dispatch(const void* x1, int C1, const void* x2, int C2, const
 
 template <typename T>
 static int resample_dispatch(const void* x, const float* M, void* y, float* ws, int B, int N, int C, int Rout,
-                             hipStream_t st) {
+                             hipStream_t st, float* stats = nullptr) {
   // pass 1 contracts H into the fp32 workspace [B][Rout][N][C]; pass 2 contracts W
   if (C % 4 == 0 && (Rout == 2 * N || 2 * Rout == N) && N >= 2 && N <= 32 && (N & (N - 1)) == 0) {
     const size_t t1 = (size_t)B * N * (C / 4), t2 = (size_t)B * Rout * (C / 4);
@@ -971,12 +987,16 @@ static int resample_dispatch(const void* x, const float* M, void* y, float* ws, 
 #define AFLDM_RS(A_, R_)                                                                                      \
   if (N == A_ && Rout == R_) {                                                                                \
     k_axis_contract_reg<T, float, A_, R_><<<g1, 256, 0, st>>>((const T*)x, ws, M, B, N, C, 0);                \
-    k_axis_contract_reg<float, T, A_, R_><<<g2, 256, 0, st>>>(ws, (T*)y, M, B, Rout, C, 1);                   \
+    k_axis_contract_reg<float, T, A_, R_><<<g2, 256, 0, st>>>(ws, (T*)y, M, B, Rout, C, 1, stats);            \
     return check_launch("afldm_af_resample(reg)");                                                            \
   }
     AFLDM_RS(2, 4) AFLDM_RS(4, 8) AFLDM_RS(8, 16) AFLDM_RS(16, 32)
     AFLDM_RS(4, 2) AFLDM_RS(8, 4) AFLDM_RS(16, 8) AFLDM_RS(32, 16)
 #undef AFLDM_RS
+  }
+  if (stats) {
+    set_error("afldm_af_lpf_down2: statistics are emitted by the register-blocked path only (N = %d, C = %d)", N, C);
+    return AFLDM_ESHAPE;
   }
   size_t n1 = (size_t)B * Rout * N * C, n2 = (size_t)B * Rout * Rout * C;
   int g1 = (int)((n1 + 255) / 256 < 8192 ? (n1 + 255) / 256 : 8192);
@@ -1051,13 +1071,13 @@ extern "C" int afldm_af_up2(const void* x, const float* U, void* y, float* works
   return AFLDM_EDTYPE;
 }
 
-extern "C" int afldm_af_lpf_down2(const void* x, const float* D, void* y, float* workspace, int B, int N, int C,
-                                  int dtype, afldm_stream_t stream) {
+extern "C" int afldm_af_lpf_down2(const void* x, const float* D, void* y, float* workspace, float* stats_out, int B, int N,
+                                  int C, int dtype, afldm_stream_t stream) {
   AFLDM_REQUIRE(x && D && y && workspace, AFLDM_ENULL, "afldm_af_lpf_down2: NULL pointer");
   AFLDM_REQUIRE(B > 0 && N >= 2 && N % 2 == 0 && C > 0, AFLDM_ESHAPE, "afldm_af_lpf_down2: bad shape (N=%d must be even)", N);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == AFLDM_F32) return resample_dispatch<float>(x, D, y, workspace, B, N, C, N / 2, st);
-  if (dtype == AFLDM_BF16) return resample_dispatch<bf16>(x, D, y, workspace, B, N, C, N / 2, st);
+  if (dtype == AFLDM_F32) return resample_dispatch<float>(x, D, y, workspace, B, N, C, N / 2, st, stats_out);
+  if (dtype == AFLDM_BF16) return resample_dispatch<bf16>(x, D, y, workspace, B, N, C, N / 2, st, stats_out);
   set_error("afldm_af_lpf_down2: unknown dtype %d", dtype);
   return AFLDM_EDTYPE;
 }

@@ -345,10 +345,15 @@ def af_lpf_down2(x, out=None, workspace=None, want_stats=False):
     if workspace is None:
         workspace = torch.empty(B * (N // 2) * N * C, dtype=torch.float32, device=x.device)
     assert workspace.numel() >= B * (N // 2) * N * C
+    st = None
+    if want_stats and C % 4 == 0 and N <= 32 and N & (N - 1) == 0:
+        st = torch.empty((B, N // 2, C, 2), dtype=torch.float32, device=x.device)    # one split per output row
     tok = _begin()
-    check(lib.afldm_af_lpf_down2(ptr(x), ptr(D), ptr(out), ptr(workspace), B, N, C, _code(x), stream_ptr()),
+    check(lib.afldm_af_lpf_down2(ptr(x), ptr(D), ptr(out), ptr(workspace), ptr(st), B, N, C, _code(x), stream_ptr()),
           "af_lpf_down2")
     _end(tok, "af_lpf_down2", 1.5 * N ** 3 * B * C, 1.25 * B * N * N * C * x.element_size())
+    if st is not None:
+        out.gn_partial = st
     return out
 
 

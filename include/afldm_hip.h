@@ -135,9 +135,11 @@ int afldm_af_pack(const float* U, const float* D, int N, int dtype, void* packed
 int afldm_af_up2(const void* x, const float* U, void* y, float* workspace, int B, int N, int C,
                  int dtype, afldm_stream_t stream);
 /* LPF_RFFT(1/2) + [::2,::2] of AliasFreeDownsample2D (af_blocks.py:149-150):
- * [B,N,N,C] -> [B,N/2,N/2,C];  D: [N/2 x N];  workspace: B*(N/2)*N*C floats. */
-int afldm_af_lpf_down2(const void* x, const float* D, void* y, float* workspace, int B, int N, int C,
-                       int dtype, afldm_stream_t stream);
+ * [B,N,N,C] -> [B,N/2,N/2,C];  D: [N/2 x N];  workspace: B*(N/2)*N*C floats.
+ * stats_out (optional, N a power of two <= 32, C % 4 == 0): per-channel GroupNorm partial sums of y with one
+ * split per output row, [B][N/2][C][2]. */
+int afldm_af_lpf_down2(const void* x, const float* D, void* y, float* workspace, float* stats_out, int B,
+                       int N, int C, int dtype, afldm_stream_t stream);
 
 /* Generic separable product y = M x M^T per (b, c) plane: [B,N,N,C] -> [B,R,R,C], M: [R x N]
  * device fp32.  Serves UpsampleRFFT(up) for any `up` (ImageShifter('ideal', 8):

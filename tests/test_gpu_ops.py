@@ -149,7 +149,13 @@ def test_af_resample(dtype, N, C):
         close(back(ops.af_up2(nhwc(x, dtype))), idf.upsample_rfft(x, 2), dtype, f"af_up2 N={N}", bf16_rms=4e-3)
     if N >= 4:
         ref = idf.lpf_rfft(x)[:, :, ::2, ::2]
-        close(back(ops.af_lpf_down2(nhwc(x, dtype))), ref, dtype, f"af_lpf_down2 N={N}", bf16_rms=4e-3)
+        y = ops.af_lpf_down2(nhwc(x, dtype), want_stats=True)
+        close(back(y), ref, dtype, f"af_lpf_down2 N={N}", bf16_rms=4e-3)
+        st = getattr(y, "gn_partial", None)        # emitted by the resampling kernel itself (one split per row / plane)
+        assert st is not None and st.shape[0] == 2 and st.shape[2:] == (C, 2)
+        yv = y.float()
+        assert (st.sum(1)[..., 0] - yv.sum((1, 2))).abs().max() <= 1e-3 * (1 + yv.sum((1, 2)).abs().max())
+        assert (st.sum(1)[..., 1] - (yv * yv).sum((1, 2))).abs().max() <= 1e-3 * (1 + (yv * yv).sum((1, 2)).max())
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
