@@ -44,6 +44,7 @@ struct ConvP {
   int tap_inner;  // K order of the LDS-DMA kernel (see k_igemm2)
   float* stats_out;  // per-channel GroupNorm partial sums of the output [B][stats_S][Cout][2], or NULL
   int stats_S;
+  int stats_multi;   // the tile spans BM / (H*W) whole samples: statistics per sample with S = 1 (64x64 tiles only)
   int m_fast;     // tile order of the LDS-DMA kernel: 1 = tile_m fastest (weights outweigh pixels)
   int stage_ok;   // leading dimensions / splits allow the LDS-staged 16-byte epilogue
   int dbg;      // AFLDM_CONV_DBG (timing decomposition only): bit 0 skip the LDS-DMA, bit 1 skip the MFMA phase
@@ -675,8 +676,14 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
 #pragma unroll
           for (int e = 0; e < EO; ++e) tvec[e] = to_f32(tv[e]);
         }
+        // rows of a thread: every RPI-th one; CONSECUTIVE ones when the tile spans several whole samples and
+        // statistics are wanted (p.stats_multi), so that all rows of a thread lie in one sample
+        constexpr int RPT = PROWS / RPI;
+        const int row_first = p.stats_multi ? (etid / CPR) * RPT : etid / CPR;
+        const int row_step = p.stats_multi ? 1 : RPI;
+        const int row_end = p.stats_multi ? row_first + RPT : PROWS;
 #pragma unroll 1
-        for (int row = etid / CPR; row < PROWS; row += RPI) {
+        for (int row = row_first; row < row_end; row += row_step) {
           const int mt = row / (TMP * 16), rr = row - mt * (TMP * 16);
           const int m = m0 + mt * WMS + ps * TMP * 16 + rr;
           if (m >= p.M || n >= nhwc_end) continue;
@@ -780,6 +787,23 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
           *reinterpret_cast<f32x2*>(sR + ((tr * BN) + ch * EO + e) * 2) = f32x2{ss1[e], ss2[e]};
       }
       __syncthreads();
+      if (p.stats_multi) {
+        // the tile holds BM / HW whole samples (S = 1): row lane tr owns rows tr * RPT .. + RPT - 1
+        constexpr int RPT = PROWS / RPI;
+        const int ns = BM / HW, lanes_per_sample = HW / RPT;
+        for (int idx = etid; idx < BN * ns; idx += NTC) {
+          const int c = idx % BN, sl = idx / BN;
+          const int b = m0 / HW + sl;
+          if (n0 + c >= p.Cout || (size_t)b * HW >= (size_t)p.M) continue;
+          float a1 = 0.f, a2 = 0.f;
+          for (int tr = sl * lanes_per_sample; tr < (sl + 1) * lanes_per_sample; ++tr) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(sR + ((tr * BN) + c) * 2);
+            a1 += v[0];
+            a2 += v[1];
+          }
+          *reinterpret_cast<f32x2*>(p.stats_out + ((size_t)b * p.Cout + n0 + c) * 2) = f32x2{a1, a2};
+        }
+      } else
       for (int c = etid; c < BN; c += NTC) {
         if (n0 + c >= p.Cout) continue;
         float a1 = 0.f, a2 = 0.f;
@@ -1416,6 +1440,13 @@ static int stats_mode(const afldm_conv_args* a, const Exec& e, int* S) {
     *S = HW / CIN4_BM;
     return ST_EPILOGUE;
   }
+  // 64x64 tiles over planes smaller than a tile (to_out at the 4x4 / 2x2 levels): the tile holds 64 / HW whole
+  // samples and a thread's two rows stay inside one of them (bf16: 32 row lanes x 2 rows, one staging pass)
+  if (sizeof(T) == 2 && e.pl.kind == 0 && e.splitk == 1 && e.vid == 32 && HW < 64 && 64 % HW == 0 && HW % 2 == 0 && vec16 &&
+      !getenv("AFLDM_CONV_NOSTAGE") && !getenv("AFLDM_NO_MULTI_STATS")) {
+    *S = 1;
+    return ST_EPILOGUE;
+  }
   *S = gn_splits(HW);
   return ST_STANDALONE;
 }
@@ -1460,6 +1491,7 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
   int smode = 0;
   p.stats_out = nullptr;
   p.stats_S = 1;
+  p.stats_multi = 0;
   if (a->stats_out) smode = stats_mode<T>(a, ex, &p.stats_S);
   int rc = AFLDM_OK;
   if (lin_wreg_bm(a)) return lin_wreg_launch(a, st);
@@ -1496,7 +1528,10 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
     const int Ct = a->C1 + a->C2;
     p.ksteps = a->KS * a->KS * (Ct / (KCH_DEFAULT * epr<T>()));
     p.splitk = ex.splitk;
-    if (smode == ST_EPILOGUE) p.stats_out = a->stats_out;
+    if (smode == ST_EPILOGUE) {
+      p.stats_out = a->stats_out;
+      p.stats_multi = (a->H * a->W) < kVariants[ex.vid].bm ? 1 : 0;
+    }
     launch_variant<T>(ex.vid, p, st);
     rc = check_launch("afldm_conv2d(igemm)");
     if (rc) return rc;

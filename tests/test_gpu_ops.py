@@ -317,6 +317,8 @@ def test_conv2d_every_gemm_variant(dtype):
     (3, 16, 16, 4, 0, 64, 3, False),       # conv_in shape with 2 statistic splits per sample
     (2, 12, 12, 4, 0, 64, 3, False),       # conv_in shape whose plane is no multiple of 128 pixels: direct kernel
     (2, 16, 16, 192, 0, 192, 1, True),     # 1x1 (attention to_out + residual)
+    (24, 4, 4, 768, 0, 768, 1, True),      # to_out at the 4x4 level: a 64x64 tile holds 4 whole samples (bf16: epilogue statistics)
+    (40, 2, 2, 768, 0, 768, 1, True),      # to_out at the 2x2 level: 16 samples per tile, ragged last tile
 ])
 def test_conv2d_emits_groupnorm_statistics(dtype, case):
     """conv2d(..., want_stats=True): the per-channel partial sums attached to the output must equal
