@@ -80,7 +80,7 @@ def _load():
         "afldm_attention": ([vp, ip, vp, ip, vp, vp, ip, ip, ip, ip, ip, ip, ip, fp, ip, vp], c_int),
         "afldm_ddim_step": ([vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, vp], c_int),
         "afldm_ddim_step_flat": ([vp, vp, vp, fp, fp, fp, fp, c_size_t, vp], c_int),
-        "afldm_select_timestep": ([vp, vp, vp, vp], c_int),
+        "afldm_select_timestep": ([vp, vp, vp, ip, vp], c_int),
     }
     for name, (argtypes, restype) in sigs.items():
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch

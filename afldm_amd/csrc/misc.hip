@@ -108,7 +108,16 @@ __global__ void k_ddim_step(const float* __restrict__ x, const T* __restrict__ e
 // separate tiny kernel so that every block of k_ddim_step reads the same (old) index
 __global__ void k_advance(int* step_idx) { *step_idx += 1; }
 
-__global__ void k_select_timestep(const float* tvals, const int* step_idx, float* t_out) { t_out[0] = tvals[*step_idx]; }
+// pre_advance: the step counter is incremented HERE, at the head of the step (one thread, after every kernel of
+// the previous step), instead of by a k_advance launch behind the previous step's DDIM update
+__global__ void k_select_timestep(const float* tvals, int* step_idx, float* t_out, int pre_advance) {
+  int s = *step_idx;
+  if (pre_advance) {
+    s += 1;
+    *step_idx = s;
+  }
+  t_out[0] = tvals[s];
+}
 
 }  // namespace afldm
 
@@ -201,9 +210,10 @@ extern "C" int afldm_ddim_step(const float* x, const void* eps, float* x_prev, c
   return check_launch("afldm_ddim_step");
 }
 
-extern "C" int afldm_select_timestep(const float* tvals, const int* step_idx, float* t_out, afldm_stream_t stream) {
+extern "C" int afldm_select_timestep(const float* tvals, int* step_idx, float* t_out, int pre_advance,
+                                     afldm_stream_t stream) {
   AFLDM_REQUIRE(tvals && step_idx && t_out, AFLDM_ENULL, "afldm_select_timestep: NULL pointer");
-  k_select_timestep<<<1, 1, 0, (hipStream_t)stream>>>(tvals, step_idx, t_out);
+  k_select_timestep<<<1, 1, 0, (hipStream_t)stream>>>(tvals, step_idx, t_out, pre_advance);
   return check_launch("afldm_select_timestep");
 }
 

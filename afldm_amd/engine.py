@@ -6,10 +6,10 @@ The reference loop costs, per step, ~1100 dependent kernel launches from Python 
 memory — the timestep table, the DDIM coefficient table and a step counter the update kernel
 increments itself — so a replay needs no host value and no synchronisation:
 
-    t      <- t_table[step]                       (afldm_select_timestep)
+    step++; t <- t_table[step]                    (afldm_select_timestep, counter starts at -1)
     x_nhwc <- NCHW fp32 latents                   (afldm_nchw_to_nhwc)
     eps    <- UNet(x_nhwc, t)                     (~450 HIP kernels, all from libafldm_hip.so)
-    lat    <- DDIM(lat, eps, coef[step]); step++  (afldm_ddim_step, in place)
+    lat    <- DDIM(lat, eps, coef[step])          (afldm_ddim_step, in place)
 """
 import torch
 
@@ -28,7 +28,7 @@ class DenoiseEngine:
         self.timesteps = list(scheduler._timesteps_host)
         self.t_table = torch.tensor(self.timesteps, dtype=torch.float32).to(dev)
         self.coef = scheduler.coefficient_table(dev).reshape(-1).contiguous()
-        self.step_idx = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.step_idx = torch.full((1,), -1, dtype=torch.int32, device=dev)
         self.t_cur = torch.zeros(1, dtype=torch.float32, device=dev)
         self.lat = torch.zeros(batch_size, c, s, s, dtype=torch.float32, device=dev)
         self.x_nhwc = torch.empty(batch_size, s, s, c, dtype=unet.dtype, device=dev)
@@ -38,10 +38,11 @@ class DenoiseEngine:
 
     # one denoise step, entirely stream-ordered
     def _step(self):
-        ops.select_timestep(self.t_table, self.step_idx, self.t_cur)
+        # the step counter starts at -1 and is advanced by the first kernel of the step
+        ops.select_timestep(self.t_table, self.step_idx, self.t_cur, pre_advance=True)
         ops.to_nhwc(self.lat, self.unet.dtype, out=self.x_nhwc)
         eps = self.unet.forward_nhwc(self.x_nhwc, self.t_cur)
-        ops.ddim_step(self.lat, eps, self.coef, self.step_idx, advance=True, out=self.lat)
+        ops.ddim_step(self.lat, eps, self.coef, self.step_idx, advance=False, out=self.lat)
 
     def _capture(self):
         keep = self.lat.clone()
@@ -51,19 +52,19 @@ class DenoiseEngine:
             self._step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.step_idx.zero_()
+        self.step_idx.fill_(-1)
         self.lat.copy_(keep)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._step()
         self.graph = g
-        self.step_idx.zero_()
+        self.step_idx.fill_(-1)
         self.lat.copy_(keep)
 
     def reset(self, latents):
         """latents: [B, C, H, W] (any device / float dtype); scaled by init_noise_sigma like the reference."""
         self.lat.copy_(latents.to(device=self.lat.device, dtype=torch.float32) * self.scheduler.init_noise_sigma)
-        self.step_idx.zero_()
+        self.step_idx.fill_(-1)
 
     def step(self, k=1):
         if self.use_graph and self.graph is None:

@@ -642,6 +642,7 @@ def ddim_step_flat(x, eps, coefs, out=None):
     return out
 
 
-def select_timestep(tvals, step_idx, t_out):
-    check(lib.afldm_select_timestep(ptr(tvals), ptr(step_idx), ptr(t_out), stream_ptr()), "select_timestep")
+def select_timestep(tvals, step_idx, t_out, pre_advance=False):
+    check(lib.afldm_select_timestep(ptr(tvals), ptr(step_idx), ptr(t_out), int(pre_advance), stream_ptr()),
+          "select_timestep")
     return t_out

@@ -256,8 +256,10 @@ int afldm_ddim_step(const float* x, const void* eps, float* x_prev, const float*
 int afldm_ddim_step_flat(const float* x, const float* eps, float* x_prev, float sqrt_a_t,
                          float sqrt_1m_a_t, float sqrt_a_prev, float sqrt_1m_a_prev, size_t n,
                          afldm_stream_t stream);
-/* tvals[step] -> t_out[0] (device->device), so the timestep also follows step_idx. */
-int afldm_select_timestep(const float* tvals, const int* step_idx, float* t_out,
+/* tvals[step] -> t_out[0] (device->device), so the timestep also follows step_idx.  pre_advance != 0:
+ * step_idx is incremented first (a sampler loop then starts from step_idx = -1 and needs no `advance`
+ * launch behind afldm_ddim_step). */
+int afldm_select_timestep(const float* tvals, int* step_idx, float* t_out, int pre_advance,
                           afldm_stream_t stream);
 
 /* ---- upfirdn2d ---------------------------------------------------------------------------

@@ -104,7 +104,7 @@ def test_ddim_50_steps_graph_and_eager(golden, dtype, tol):
     eng.step(47)
     out_graph = eng.lat.clone()
     assert rel_rms(out_graph, g["ddim50_final"]) <= tol
-    assert int(eng.step_idx.item()) == 50
+    assert int(eng.step_idx.item()) == 49          # index of the last executed step (the counter starts at -1)
     eager = DenoiseEngine(unet, ffhq_ddim_scheduler(), 2, 50, use_graph=False).run(x)
     assert torch.equal(eager, out_graph), "graph replay must be bit-identical to eager launches"
     again = eng.run(x)
