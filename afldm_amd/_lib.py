@@ -70,6 +70,7 @@ def _load():
         "afldm_af_resample_plane": ([vp, vp, vp, vp, ip, ip, ip, ip, ip, vp], c_int),
         "afldm_upfirdn2d": ([vp, vp, vp] + [ip] * 14 + [fp, ip, vp], c_int),
         "afldm_upfirdn2d_out_size": ([ip] * 6, c_int),
+        "afldm_masked_metrics": ([vp, vp, vp, vp, ip, c_size_t, ip, vp], c_int),
         "afldm_gn_fold": ([vp, ip, vp, ip, ip, ip, vp], c_int),
         "afldm_gn_table": ([vp, ip, vp, vp, vp, ip, ip, ip, ip, fp, vp], c_int),
         "afldm_softmax_rows": ([vp, vp, ctypes.c_longlong, ip, fp, ip, vp], c_int),

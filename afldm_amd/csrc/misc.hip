@@ -119,9 +119,64 @@ __global__ void k_select_timestep(const float* tvals, int* step_idx, float* t_ou
   t_out[0] = tvals[s];
 }
 
+// Masked equivariance metrics in ONE pass (reference shift_utils/metrics.py:5-20): per sample
+// out[b] = { sum ((a - b) m)^2, sum m, max(a m), min(a m), max(b m), min(b m) }.  One workgroup per sample,
+// fixed summation order (strided per-thread partials, xor-shuffle tree, 4 wave partials in order).
+template <typename T>
+__global__ void __launch_bounds__(256) k_masked_metrics(const T* __restrict__ a, const T* __restrict__ b,
+                                                        const float* __restrict__ m, float* __restrict__ out, size_t n) {
+  __shared__ float red[4][6];
+  const size_t base = (size_t)blockIdx.x * n;
+  float v[6] = {0.f, 0.f, -3.4e38f, 3.4e38f, -3.4e38f, 3.4e38f};
+  for (size_t i = threadIdx.x; i < n; i += 256) {
+    const float mk = m[base + i];
+    const float am = to_f32(a[base + i]) * mk, bm = to_f32(b[base + i]) * mk;
+    const float d = am - bm;
+    v[0] = fmaf(d, d, v[0]);
+    v[1] += mk;
+    v[2] = fmaxf(v[2], am);
+    v[3] = fminf(v[3], am);
+    v[4] = fmaxf(v[4], bm);
+    v[5] = fminf(v[5], bm);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    v[0] += __shfl_xor(v[0], o, 64);
+    v[1] += __shfl_xor(v[1], o, 64);
+    v[2] = fmaxf(v[2], __shfl_xor(v[2], o, 64));
+    v[3] = fminf(v[3], __shfl_xor(v[3], o, 64));
+    v[4] = fmaxf(v[4], __shfl_xor(v[4], o, 64));
+    v[5] = fminf(v[5], __shfl_xor(v[5], o, 64));
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) red[wave][k] = v[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* o = out + (size_t)blockIdx.x * 6;
+    o[0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    o[1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    o[2] = fmaxf(fmaxf(red[0][2], red[1][2]), fmaxf(red[2][2], red[3][2]));
+    o[3] = fminf(fminf(red[0][3], red[1][3]), fminf(red[2][3], red[3][3]));
+    o[4] = fmaxf(fmaxf(red[0][4], red[1][4]), fmaxf(red[2][4], red[3][4]));
+    o[5] = fminf(fminf(red[0][5], red[1][5]), fminf(red[2][5], red[3][5]));
+  }
+}
+
 }  // namespace afldm
 
 using namespace afldm;
+
+extern "C" int afldm_masked_metrics(const void* a, const void* b, const float* mask, float* out, int B, size_t n,
+                                    int dtype, afldm_stream_t stream) {
+  AFLDM_REQUIRE(a && b && mask && out, AFLDM_ENULL, "afldm_masked_metrics: NULL pointer");
+  AFLDM_REQUIRE(B > 0 && n > 0, AFLDM_ESHAPE, "afldm_masked_metrics: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, (k_masked_metrics<float><<<B, 256, 0, st>>>((const float*)a, (const float*)b, mask, out, n)),
+             (k_masked_metrics<bf16><<<B, 256, 0, st>>>((const bf16*)a, (const bf16*)b, mask, out, n)), "afldm_masked_metrics");
+  return check_launch("afldm_masked_metrics");
+}
 
 extern "C" int afldm_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int dtype,
                                   afldm_stream_t stream) {

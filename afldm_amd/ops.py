@@ -468,6 +468,21 @@ def af_resample_hw(x, Mh, Mw, out=None, workspace=None):
     return out
 
 
+def masked_metrics(a, b, mask):
+    """afldm_masked_metrics: [B, 6] fp32 = per-sample (sum ((a-b) m)^2, sum m, max a m, min a m, max b m, min b m)."""
+    _dev(a, "a")
+    assert a.shape == b.shape
+    if a.dtype not in (torch.float32, torch.bfloat16) or b.dtype != a.dtype:
+        a, b = a.float(), b.float()
+    a, b = a.contiguous(), b.contiguous()
+    m = mask.to(device=a.device, dtype=torch.float32).expand_as(a).contiguous()
+    B = a.shape[0]
+    out = torch.empty((B, 6), dtype=torch.float32, device=a.device)
+    check(lib.afldm_masked_metrics(ptr(a), ptr(b), ptr(m), ptr(out), B, a.numel() // B, _code(a), stream_ptr()),
+          "masked_metrics")
+    return out
+
+
 # ----------------------------------------------------------------------------- upfirdn2d (NCHW planes)
 def upfirdn2d(x, f, upx=1, upy=1, downx=1, downy=1, padx0=0, padx1=0, pady0=0, pady1=0, flip_filter=False, gain=1.0,
               out=None):

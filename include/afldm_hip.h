@@ -262,6 +262,13 @@ int afldm_ddim_step_flat(const float* x, const float* eps, float* x_prev, float 
 int afldm_select_timestep(const float* tvals, int* step_idx, float* t_out, int pre_advance,
                           afldm_stream_t stream);
 
+/* ---- masked equivariance metrics (shift_utils/metrics.py:5-20) ------------------------------
+ * One pass over a, b [B][n] (dtype) and mask [B][n] fp32: out[b] = { sum ((a - b) mask)^2, sum mask,
+ * max(a mask), min(a mask), max(b mask), min(b mask) } (fp32 [B][6]).  mask_mse = mean_b out[b][0] / out[b][1];
+ * mask_psnr = 10 log10(range^2 / mask_mse) with range = max over both - min over both. */
+int afldm_masked_metrics(const void* a, const void* b, const float* mask, float* out, int B, size_t n,
+                         int dtype, afldm_stream_t stream);
+
 /* ---- upfirdn2d ---------------------------------------------------------------------------
  * Zero-stuffing up-sample (upx, upy) -> pad (negative = crop) -> 2-D FIR -> decimate (downx, downy) on
  * NCHW planes: torch_utils/ops/upfirdn2d.py:140-194 (`_upfirdn2d_ref`; the reference's fast path is the

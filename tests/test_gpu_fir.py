@@ -209,3 +209,27 @@ def test_full_size_image_properties():
     w, _ = sh.shift(band, 3.25, -1.5)
     back, _ = sh.shift(w, -3.25, 1.5)
     assert rel_rms(back, band.cpu()) <= 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_masked_metrics_kernel_vs_oracle(golden, dtype):
+    """mask_mse / mask_psnr / psnr on device tensors (one reduction kernel) against the oracle's torch form
+    (itself bit-equal to the reference fixture), with full and broadcast ([B,1,H,W]) masks."""
+    from afldm_amd.shift_utils import metrics
+    from oracle import shift as osh
+    g5 = golden("g5_shift_metrics.npz")
+    a, b, m = (t(g5[k]) for k in ("ma", "mb", "mm"))
+    assert abs(float(metrics.mask_mse(a.cuda(), b.cuda(), m.cuda())) - float(g5["mask_mse"])) <= 1e-6 * float(g5["mask_mse"])
+    assert abs(float(metrics.mask_psnr(a.cuda(), b.cuda(), m.cuda())) - float(g5["mask_psnr"])) <= 1e-4
+    assert abs(float(metrics.psnr(a.cuda(), b.cuda())) - float(g5["psnr"])) <= 1e-4
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 4, 32, 32, generator=gen).to(dtype)
+    y = (x.float() + 0.1 * torch.randn(3, 4, 32, 32, generator=gen)).to(dtype)
+    for mask in ((torch.rand(3, 4, 32, 32, generator=gen) > 0.3).float(), (torch.rand(3, 1, 32, 32, generator=gen) > 0.5).float()):
+        ref_mse = osh.mask_mse(x.float(), y.float(), mask.expand(3, 4, 32, 32))
+        ref_psnr = osh.mask_psnr(x.float(), y.float(), mask.expand(3, 4, 32, 32))
+        got_mse = metrics.mask_mse(x.cuda(), y.cuda(), mask.cuda())
+        got_psnr = metrics.mask_psnr(x.cuda(), y.cuda(), mask)          # a host mask is moved by the wrapper
+        assert abs(float(got_mse) - float(ref_mse)) <= 2e-6 * float(ref_mse)
+        assert abs(float(got_psnr) - float(ref_psnr)) <= 1e-4
+    assert abs(float(metrics.psnr(x.cuda(), y.cuda(), i_max=2.0)) - float(osh.psnr(x.float(), y.float(), 2.0))) <= 1e-4
