@@ -5,7 +5,6 @@ import torch
 
 from ..schedulers.i2sb import I2SBScheduler
 from .ldm_pipeline import MyLDMPipeline
-from .pipeline_utils import ImagePipelineOutput
 
 
 class I2SBLDMPipeline(MyLDMPipeline):
@@ -19,21 +18,16 @@ class I2SBLDMPipeline(MyLDMPipeline):
         such tensors unchanged)."""
         if self.vae is None:
             raise NotImplementedError("I2SBLDMPipeline needs a VAE to encode the degraded image")
-        x = images.to(device=self.device, dtype=self.unet.dtype)
-        latents = self.vae.encode(x).latent_dist.sample(generator) * self.vae.config.scaling_factor
-        self.scheduler.set_timesteps(num_inference_steps)
-        ts = self.scheduler._timesteps_host
-        for i, t in enumerate(self.progress_bar(ts)):
-            if i == num_inference_steps - 1:
-                break
-            eps = self.unet(self.scheduler.scale_model_input(latents, t), t).sample
-            latents = self.scheduler.step(eps, t, latents, is_ode=is_ode, generator=generator).prev_sample
-        if output_type == "latent":
-            return latents
-        image = self.vae.decode(latents.to(self.vae.dtype) / self.vae.config.scaling_factor).sample
-        if output_type != "pt":
-            image = (image / 2 + 0.5).clamp(0, 1).cpu().permute(0, 2, 3, 1).float().numpy()
-            if output_type == "pil":
-                image = self.numpy_to_pil(image)
-            return ImagePipelineOutput(images=image) if return_dict else (image,)
-        return image
+        start = self.vae.encode(images.to(device=self.device, dtype=self.unet.dtype)).latent_dist.sample(generator)
+        latents = self._bridge(start * self.vae.config.scaling_factor, num_inference_steps, is_ode, generator)
+        return self._deliver(latents, output_type, return_dict)
+
+    def _bridge(self, latents, steps, is_ode, generator):
+        """steps - 1 UNet evaluations from the encoded degraded image towards the clean latent: the reference loop
+        leaves before its last timestep (i2sb_pipeline.py:48-50)."""
+        sched, unet = self.scheduler, self.unet
+        sched.set_timesteps(steps)
+        for t in self.progress_bar(sched._timesteps_host[:steps - 1]):
+            prediction = unet(sched.scale_model_input(latents, t), t).sample
+            latents = sched.step(prediction, t, latents, is_ode=is_ode, generator=generator).prev_sample
+        return latents

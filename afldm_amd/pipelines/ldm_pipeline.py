@@ -55,18 +55,21 @@ class MyLDMPipeline(DiffusionPipeline):
         eng = self._engine(latents.shape[0], num_inference_steps, use_graph)
         eng.scheduler = self.scheduler
         latents = eng.run(latents).to(self.unet.dtype)
+        return self._deliver(latents, output_type, return_dict)
+
+    def _deliver(self, latents, output_type, return_dict):
+        """'latent' -> the latents; 'pt' -> decoded tensor in [-1, 1]; 'np' / 'pil' -> [0, 1] NHWC arrays / PIL images
+        (wrapped in ImagePipelineOutput unless return_dict is False)."""
         if output_type == "latent":
             return latents
         if self.vae is None:
             raise NotImplementedError("this pipeline was built without a VAE: use output_type='latent'")
-        latents = latents.to(self.vae.dtype) / self.vae.config.scaling_factor
-        image = self.vae.decode(latents).sample
-        if output_type != "pt":
-            image = (image / 2 + 0.5).clamp(0, 1).cpu().permute(0, 2, 3, 1).numpy()
-            if output_type == "pil":
-                image = self.numpy_to_pil(image)
-            return ImagePipelineOutput(images=image) if return_dict else (image,)
-        return image
+        decoded = self.vae.decode(latents.to(self.vae.dtype) / self.vae.config.scaling_factor).sample
+        if output_type == "pt":
+            return decoded
+        arrays = (decoded / 2 + 0.5).clamp(0, 1).cpu().permute(0, 2, 3, 1).float().numpy()
+        images = self.numpy_to_pil(arrays) if output_type == "pil" else arrays
+        return ImagePipelineOutput(images=images) if return_dict else (images,)
 
     @torch.no_grad()
     def ddim_inversion(self, latent, bar=True):
