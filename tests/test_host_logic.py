@@ -228,3 +228,64 @@ def test_sr4x_degrade_matrix_matches_oracle():
         for n in (64, 256):
             assert (degrade_matrix(flt, n) - ref(flt, n)).abs().max() < 1e-6
 
+
+
+def test_host_built_filter_matrices_for_general_cutoffs():
+    """af_libs.ideal_lpf builds circulants on the host for cutoffs the C library has no kind for: they must agree
+    with afldm_filter_matrix where both exist and with the oracle's FFT form elsewhere (CPU only: matrices)."""
+    import numpy as np
+    from afldm_amd import _lib
+    from afldm_amd.af_libs import ideal_lpf as L
+    from oracle import ideal_filters as idf
+    for N in (4, 8, 16, 32):
+        lp = L._circulant(L._rect_1d(N, 0.5, 0.0).numpy())
+        assert np.abs(lp - _lib.filter_matrix(2, N).numpy()).max() <= 1e-7
+        up = 2 * L._circulant(L._rect_1d(2 * N, 0.5, 0.5).numpy())[:, ::2]
+        assert np.abs(up - _lib.filter_matrix(0, N, 2).numpy()).max() <= 1e-7
+    # a cutoff only the host path serves: y = C x C^T must equal the rfft2 -> mask -> irfft2 form
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, 2, 24, 24, generator=g, dtype=torch.float64)
+    C = torch.from_numpy(L._circulant(L._rect_1d(24, 0.25, 0.0).numpy()))
+    assert (C @ x @ C.T - idf.lpf_rfft(x.float(), 0.25).double()).abs().max() <= 2e-6
+    R = torch.from_numpy(L._circulant(L._rect_1d(24, 0.25, 0.5).numpy()))
+    assert (R @ x @ R.T - idf.lpf_recon_rfft(x.float(), 0.25).double()).abs().max() <= 2e-6
+    with pytest.raises(IndexError):            # cutoff 2 on N % 4 == 0: the reference's mask indexes out of range
+        L._rect_1d(32, 2, 0.0)
+
+
+def test_phase_circulant_and_translation_masks():
+    """Host pieces of the fourier / lanczos shifters: an integer phase ramp is a cyclic permutation, a fractional
+    one matches the oracle's fft2 form, and the validity boxes of the Lanczos / integer translations match the
+    reference fixtures (CPU only: no kernel is launched)."""
+    import numpy as np
+    from afldm_amd.af_libs import equivariance as eq
+    from afldm_amd.shift_utils import shifters as S
+    from oracle import upfirdn as ou
+    re, im = S._phase_circulant(8, 3)
+    assert np.abs(im).max() <= 1e-12 and np.allclose(re, np.roll(np.eye(8), 3, axis=0), atol=1e-12)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, 1, 16, 16, generator=g, dtype=torch.float64)
+    (hr, hi), (wr, wi) = S._phase_circulant(16, 1.375), S._phase_circulant(16, -0.5)
+    y = torch.from_numpy(hr) @ x @ torch.from_numpy(wr).T - torch.from_numpy(hi) @ x @ torch.from_numpy(wi).T
+    assert (y - ou.fourier_shift_batch(x, 1.375, -0.5)).abs().max() <= 2e-6     # the reference builds its phase ramp in fp32
+    probe = torch.zeros(1, 1, 32, 32)
+    for ix, iy, a in ((3, -2, 3), (0, 0, 3), (40, 1, 3), (-30, 31, 3)):
+        b = a - 1
+        box = eq._box_mask(probe, max(iy + a, 0), min(iy - b, 0) + 32, max(ix + a, 0), min(ix - b, 0) + 32)
+        _, ref = ou.apply_fractional_translation(probe, ix / 32, iy / 32)
+        assert torch.equal(box, ref), (ix, iy)
+
+
+def test_upfirdn2d_host_argument_handling():
+    from afldm_amd.af_libs.torch_utils.ops import upfirdn2d as up
+    from oracle import upfirdn as ou
+    assert up._parse_scaling(3) == (3, 3) and up._parse_scaling([2, 5]) == (2, 5)
+    assert up._parse_padding(2) == (2, 2, 2, 2) and up._parse_padding([1, 3]) == (1, 1, 3, 3)
+    assert up._parse_padding([1, -2, 3, 4]) == (1, -2, 3, 4)
+    with pytest.raises(AssertionError):
+        up._parse_scaling(0)
+    for f, kw in (([1, 3, 3, 1], {}), ([1, 2, 3, 4, 4, 3, 2, 1], {"gain": 2}), ([[1, 2], [3, 4]], {"flip_filter": True}),
+                  (None, {}), ([1, 2, 1], {"normalize": False, "separable": True})):
+        assert torch.equal(up.setup_filter(f, **kw), ou.setup_filter(f, **kw)), (f, kw)
+    with pytest.raises(RuntimeError):          # no CPU path
+        up.upfirdn2d(torch.zeros(1, 1, 4, 4), torch.ones(2, 2))
