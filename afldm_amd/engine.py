@@ -11,13 +11,15 @@ increments itself — so a replay needs no host value and no synchronisation:
     eps    <- UNet(x_nhwc, t)                     (~450 HIP kernels, all from libafldm_hip.so)
     lat    <- DDIM(lat, eps, coef[step])          (afldm_ddim_step, in place)
 """
+import os
+
 import torch
 
 from . import ops
 
 
 class DenoiseEngine:
-    def __init__(self, unet, scheduler, batch_size, num_inference_steps=50, use_graph=True):
+    def __init__(self, unet, scheduler, batch_size, num_inference_steps=50, use_graph=True, steps_per_graph=5):
         if unet.device.type != "cuda":
             raise RuntimeError("DenoiseEngine needs the UNet on an MI355X ('cuda') device; there is no CPU path")
         self.unet, self.scheduler = unet, scheduler
@@ -33,6 +35,10 @@ class DenoiseEngine:
         self.lat = torch.zeros(batch_size, c, s, s, dtype=torch.float32, device=dev)
         self.x_nhwc = torch.empty(batch_size, s, s, c, dtype=unet.dtype, device=dev)
         self.graph = None
+        self.graph_multi = None
+        # a replay boundary costs ~9 us of idle GPU (host launch + graph start): besides the one-step graph a
+        # `steps_per_graph`-step graph is captured and used for every full group of steps
+        self.steps_per_graph = max(1, int(os.environ.get("AFLDM_STEPS_PER_GRAPH", steps_per_graph)))
         self.use_graph = use_graph
         self.kernels_per_step = None
 
@@ -58,6 +64,14 @@ class DenoiseEngine:
         with torch.cuda.graph(g):
             self._step()
         self.graph = g
+        if self.steps_per_graph > 1:
+            self.step_idx.fill_(-1)
+            self.lat.copy_(keep)
+            gm = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gm):
+                for _ in range(self.steps_per_graph):
+                    self._step()
+            self.graph_multi = gm
         self.step_idx.fill_(-1)
         self.lat.copy_(keep)
 
@@ -69,11 +83,15 @@ class DenoiseEngine:
     def step(self, k=1):
         if self.use_graph and self.graph is None:
             self._capture()
-        for _ in range(k):
-            if self.use_graph:
-                self.graph.replay()
-            else:
+        if not self.use_graph:
+            for _ in range(k):
                 self._step()
+            return
+        while self.graph_multi is not None and k >= self.steps_per_graph:
+            self.graph_multi.replay()
+            k -= self.steps_per_graph
+        for _ in range(k):
+            self.graph.replay()
 
     @torch.no_grad()
     def run(self, latents):
