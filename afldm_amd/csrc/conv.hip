@@ -819,6 +819,259 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
   }
 }
 
+// ----------------------------------------------------------------------------- v5: persistent tiles
+// 128x192 tiles, 4 MFMA-only consumer waves + 4 LDS-DMA producer waves (as variant 33), but a workgroup
+// walks SEVERAL tiles and the producers never stop at a tile boundary: while the consumers run the epilogue
+// of tile i the ring already holds the first STAGES-1 K steps of tile i+1, and the epilogue's stores drain
+// under the next tile's MFMAs.  (With one tile per workgroup slot nothing overlaps the fixed part: 14 of
+// the 52 us of a 192->192 3x3 conv at 32x32 remain with both the DMA and the MFMA phase switched off.)
+// The epilogue is wave-private - a consumer wave owns 64 rows x 96 couts, adds bias / time embedding /
+// residual in fp32 in registers, rounds, stages 32 rows at a time through its own LDS patch and stores
+// 192-byte row pieces; GroupNorm partial sums are written per (32-row pass) split, so no workgroup
+// barrier exists outside the K loop and the producers may run ahead.  bf16, H*W % 128 == 0, Cout % 192 == 0,
+// token-major output, no split-K.  Same K order and rounding as k_igemm2: bit-identical results.
+template <typename T, int STAGES>
+__global__ void __launch_bounds__(512, 1) k_igemm3(ConvP p) {
+  typedef Mma<T> MM;
+  typedef typename MM::Chunk Chunk;
+  constexpr int BM = 128, BN = 192, WGN = 2, NWC = 4, NW = 4;
+  constexpr int EPC = MM::EPC, KSTEP = 8 * EPC, ESZ = (int)sizeof(T);
+  constexpr int WMS = 64, WNS = 96, TM = 4, TN = 6;
+  constexpr int XI = BM / 8, WI = BN / 8, XPW = XI / NW, WPW = WI / NW, LPS = XPW + WPW;
+  constexpr int X_STAGE = BM * 128, W_STAGE = BN * 128, STAGE = X_STAGE + W_STAGE;
+  constexpr int SROW = WNS + 8, WSTG = 32 * SROW * ESZ;
+  constexpr unsigned OOB = 0x80000000u;
+  static_assert(sizeof(T) == 2, "bf16 only");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_producer = wave_all >= NWC;
+  const int li = lane & 15, lg = lane >> 4;
+  const int G = gridDim.x;
+  const int tiles_m_ = p.M / BM, ntiles = tiles_m_ * p.tiles_n;
+  const int first = xcd_remap(blockIdx.x, G);
+  const int nmine = first < ntiles ? (ntiles - first + G - 1) / G : 0;
+  const int Ct = p.C1 + p.C2, cblocks = Ct / KSTEP, HW = p.H * p.W, pad = p.KS >> 1;
+  const int ksteps = p.ksteps;
+  auto tile_origin = [&](int ti, int& m0, int& n0) {
+    const int tile = first + ti * G;
+    const int tm = p.m_fast ? tile % tiles_m_ : tile / p.tiles_n;
+    const int tn = p.m_fast ? tile / tiles_m_ : tile % p.tiles_n;
+    m0 = tm * BM;
+    n0 = tn * BN;
+  };
+
+  if (is_producer) {
+    const int wave = wave_all - NWC;
+    const long long x1_bytes = (long long)p.M * p.C1 * ESZ, x2_bytes = (long long)p.M * p.C2 * ESZ;
+    const long long w_bytes = (long long)p.Cout * p.KS * p.KS * Ct * ESZ;
+    __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, (int)x1_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x1), 0, (int)x2_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)w_bytes, 0x00020000);
+    const int lrow = lane >> 3;
+    int xoh[XPW], xow[XPW], xcin[XPW];
+    unsigned xbase[XPW];
+    unsigned xoff1[XPW], xoff2[XPW], woff[WPW];
+    int cur = 0;                       // tile of the NEXT step to issue
+    int is_kt = 0, is_tap = 0, is_ci0 = 0, is_kh = 0, is_kw = 0;
+    auto retap = [&]() {
+      const int dh = is_kh - pad, dw = is_kw - pad;
+      const int dpix = dh * p.W + dw;
+#pragma unroll
+      for (int i = 0; i < XPW; ++i) {
+        const int ih = xoh[i] + dh, iw = xow[i] + dw;
+        const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        const unsigned pixel = (unsigned)((int)xbase[i] + dpix);
+        const unsigned cin = (unsigned)xcin[i];
+        xoff1[i] = ok ? (pixel * (unsigned)p.C1 + cin) * ESZ : OOB;
+        xoff2[i] = ok ? (pixel * (unsigned)p.C2 + cin) * ESZ : OOB;
+      }
+    };
+    auto setup_tile = [&]() {
+      int m0, n0;
+      tile_origin(cur, m0, n0);
+#pragma unroll
+      for (int i = 0; i < XPW; ++i) {
+        const int j = wave + NW * i;
+        xcin[i] = ((lane & 7) ^ ((4 * j + (lane >> 4)) & 7)) * EPC;
+        const int m = m0 + 8 * j + lrow;
+        const int b = m / HW, pix = m - b * HW;
+        xoh[i] = pix / p.W;
+        xow[i] = pix - xoh[i] * p.W;
+        xbase[i] = (unsigned)m;
+      }
+#pragma unroll
+      for (int i = 0; i < WPW; ++i) {
+        const int j = wave + NW * i;
+        const int wc = ((lane & 7) ^ ((4 * j + (lane >> 4)) & 7)) * EPC;
+        const int n = n0 + 8 * j + lrow;
+        woff[i] = ((unsigned)n * (unsigned)(p.KS * p.KS) * (unsigned)Ct + (unsigned)wc) * ESZ;
+      }
+      is_kt = is_tap = is_ci0 = is_kh = is_kw = 0;
+      retap();
+    };
+    if (nmine > 0) setup_tile();
+    auto issue = [&](int slot) {
+      char* sbase = smem + slot * STAGE;
+      const bool live = cur < nmine;
+      const bool second = is_ci0 >= p.C1;
+      const unsigned xs = live ? (unsigned)((second ? is_ci0 - p.C1 : is_ci0) * ESZ) : OOB;
+      const unsigned wsoff = live ? (unsigned)((is_tap * Ct + is_ci0) * ESZ) : OOB;
+#pragma unroll
+      for (int i = 0; i < XPW; ++i) {
+        const int j = wave + NW * i;
+        lds_ptr_t dst = (lds_ptr_t)(sbase + j * 1024);
+        if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, dst, 16, (int)xoff2[i], (int)xs, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx1, dst, 16, (int)xoff1[i], (int)xs, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < WPW; ++i) {
+        const int j = wave + NW * i;
+        lds_ptr_t dst = (lds_ptr_t)(sbase + X_STAGE + j * 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, dst, 16, (int)woff[i], (int)wsoff, 0, 0);
+      }
+      if (!live) return;
+      ++is_kt;
+      is_ci0 += KSTEP;
+      if (is_ci0 >= Ct) {
+        is_ci0 = 0;
+        ++is_tap;
+        if (++is_kw == p.KS) {
+          is_kw = 0;
+          ++is_kh;
+        }
+        if (is_kt < ksteps) retap();
+      }
+      if (is_kt == ksteps) {          // next tile: its first K steps follow immediately (no drain)
+        ++cur;
+        if (cur < nmine) setup_tile();
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < STAGES - 1; ++q) issue(q);
+    int slot = 0;
+    const int total = nmine * ksteps;
+    for (int g = 0; g < total; ++g) {
+      wait_vmcnt<(STAGES - 2) * LPS>();
+      __builtin_amdgcn_s_barrier();
+      int nslot = slot + STAGES - 1;
+      if (nslot >= STAGES) nslot -= STAGES;
+      issue(nslot);
+      slot = slot + 1 == STAGES ? 0 : slot + 1;
+    }
+    wait_vmcnt<0>();
+    return;
+  }
+
+  // ---------------- consumers
+  const int cw = wave_all, wm = cw / WGN, wn = cw % WGN;
+  T* ws = reinterpret_cast<T*>(smem + STAGES * STAGE + cw * WSTG);
+  const T* temb = (const T*)p.temb;
+  const T* res = (const T*)p.residual;
+  int slot = 0;
+  for (int ti = 0; ti < nmine; ++ti) {
+    int m0, n0;
+    tile_origin(ti, m0, n0);
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < ksteps; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      const char* sX = smem + slot * STAGE;
+      const char* sW = sX + X_STAGE;
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        Chunk a[TN], b[TM];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+          const int row = wn * WNS + t * 16 + li;
+          a[t] = ld16<Chunk>(sW + row * 128 + (((kc * 4 + lg) ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+          const int row = wm * WMS + t * 16 + li;
+          b[t] = ld16<Chunk>(sX + row * 128 + (((kc * 4 + lg) ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) MM::mma(acc[tn][tm], a[tn], b[tm]);
+      }
+      slot = slot + 1 == STAGES ? 0 : slot + 1;
+    }
+    // ---- wave-private epilogue: 2 passes of 32 rows
+    const int bsm = m0 / HW;
+    const int split0 = ((m0 - bsm * HW) / BM) * 4 + wm * 2;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + wn * WNS + 16 * tn + 4 * lg;
+        f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 tv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (temb) {
+          const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(temb + (size_t)bsm * p.temb_stride + n % p.temb_mod);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tv[r] = (float)t4[r];
+        }
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tmi = 0; tmi < 2; ++tmi) {
+          const int tm = 2 * ps + tmi;
+          const int m = m0 + wm * WMS + 16 * tm + li;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[tn][tm][r] + bv[r];
+            if (temb) v[r] += tv[r];
+          }
+          if (res) {
+            const bf16x4 rr = *reinterpret_cast<const bf16x4*>(res + (size_t)m * p.res_ld + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+          }
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            o[r] = (bf16)v[r];
+            const float q = (float)o[r];
+            s1[r] += q;
+            s2[r] = fmaf(q, q, s2[r]);
+          }
+          *reinterpret_cast<bf16x4*>(ws + (16 * tmi + li) * SROW + 16 * tn + 4 * lg) = o;
+        }
+        if (p.stats_out) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+              s1[r] += __shfl_xor(s1[r], o, 64);
+              s2[r] += __shfl_xor(s2[r], o, 64);
+            }
+          }
+          if (li == 0) {
+            float* so = p.stats_out + (((size_t)bsm * p.stats_S + split0 + ps) * p.Cout + n) * 2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x2*>(so + 2 * r) = f32x2{s1[r], s2[r]};
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      constexpr int CPR = WNS / 8;     // 16-byte pieces per staged row
+#pragma unroll 2
+      for (int it = 0; it < 32 * CPR / 64; ++it) {
+        const int idx = lane + 64 * it, row = idx / CPR, c = idx - row * CPR;
+        st16<Chunk>((T*)p.y + (size_t)(m0 + wm * WMS + 32 * ps + row) * p.y_ld + n0 + wn * WNS + c * 8,
+                    ld16<Chunk>(ws + row * SROW + c * 8));
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 // split-K reduction that also emits the per-channel GroupNorm partial sums of the output: one
 // workgroup = (sample, row split, 256 / RL channel quads); thread (quad, row lane) owns 4 channels
 // and every RL-th row of the split; the row lanes are combined in a fixed order through LDS.
@@ -1217,6 +1470,7 @@ static const Variant kVariants[] = {
     {64, 192, 4, 2},   // 37  short-K GEMMs: twice the tiles of 128x192 (epilogues of one round overlap the next)
     {64, 128, 4, 2},   // 38
     {64, 192, 4, 3},   // 39
+    {128, 192, 5, 3},  // 40  ver 5 = persistent tiles (k_igemm3): producers run ahead across tile boundaries
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -1333,8 +1587,37 @@ static void launch_igemm2(const ConvP& p0, hipStream_t st) {
 
 
 template <typename T>
+static void launch_igemm3(const ConvP& p0, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    constexpr int STAGES = 3;
+    ConvP p = p0;
+    p.tiles_n = p.Cout / 192;
+    const int tiles = (p.M / 128) * p.tiles_n;
+    constexpr int lds = STAGES * (128 + 192) * 128 + 4 * 32 * (96 + 8) * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)k_igemm3<T, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_set = true;
+    }
+    k_igemm3<T, STAGES><<<tiles < 256 ? tiles : 256, 512, lds, st>>>(p);
+  }
+}
+
+// shapes the persistent-tile kernel covers
+template <typename T>
+static bool igemm3_ok(const afldm_conv_args* a) {
+  const int HW = a->H * a->W;
+  const int Ct = a->C1 + a->C2;
+  return sizeof(T) == 2 && a->out_mode == 0 && !a->y2 && HW % 128 == 0 && a->Cout % 192 == 0 && Ct % 64 == 0 &&
+         (a->C2 == 0 || a->C1 % 64 == 0) && a->y_ld % 8 == 0 && (!a->residual || a->res_ld % 4 == 0) &&
+         (!a->temb || (a->temb_stride % 4 == 0 && (a->temb_mod <= 0 || a->temb_mod % 4 == 0))) && aligned16(a->y) &&
+         (!a->bias || aligned16(a->bias));
+}
+
+template <typename T>
 static bool launch_variant(int id, const ConvP& p, hipStream_t st) {
   switch (id) {
+    case 40: launch_igemm3<T>(p, st); return true;
     case 0: launch_igemm<T, 128, 128, 2, 2>(p, st); return true;
     case 1: launch_igemm<T, 128, 64, 2, 2>(p, st); return true;
     case 2: launch_igemm<T, 64, 128, 2, 2>(p, st); return true;
@@ -1400,6 +1683,13 @@ static Exec resolve_exec(const afldm_conv_args* a) {
   }
   const bool v2_ok = M * (a->C1 > a->C2 ? a->C1 : a->C2) * (long long)sizeof(T) < (1ll << 31) &&
                      (long long)a->Cout * a->KS * a->KS * Ct * (long long)sizeof(T) < (1ll << 31);
+  {
+    // persistent tiles (variant 40) where the 128x192 one-tile-per-slot kernel would run >= 2 rounds of tiles
+    static const int s_persist = getenv("AFLDM_PERSIST") ? atoi(getenv("AFLDM_PERSIST")) : 0;
+    const long long tiles = (M / 128) * (a->Cout / 192);
+    if (s_persist && e.vid == 29 && e.splitk == 1 && tiles >= 512 && igemm3_ok<T>(a)) e.vid = 40;
+    if (e.vid == 40 && (e.splitk != 1 || !igemm3_ok<T>(a))) e.vid = 29;
+  }
   if (kVariants[e.vid].ver >= 2 && !v2_ok) e.vid = kVariants[e.vid].bm == 128 ? (kVariants[e.vid].bn >= 128 ? 0 : 1) : 3;
   return e;
 }
@@ -1430,6 +1720,10 @@ static int stats_mode(const afldm_conv_args* a, const Exec& e, int* S) {
   if (e.pl.kind == 0 && e.splitk > 1 && vec4) {
     *S = reduce_stats_splits(HW);
     return ST_REDUCE;
+  }
+  if (e.pl.kind == 0 && e.splitk == 1 && e.vid == 40) {
+    *S = (HW / 128) * 4;      // one split per (consumer row half, 32-row pass)
+    return ST_EPILOGUE;
   }
   if (e.pl.kind == 0 && e.splitk == 1 && kVariants[e.vid].ver >= 2 && HW % kVariants[e.vid].bm == 0 && vec16 &&
       !getenv("AFLDM_CONV_NOSTAGE")) {

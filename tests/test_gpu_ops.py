@@ -305,6 +305,45 @@ def test_conv2d_every_gemm_variant(dtype):
     assert nvar >= 37
 
 
+@pytest.mark.parametrize("case", [
+    # B, H, W, C1, C2, Cout, KS, temb, residual
+    (6, 32, 32, 192, 0, 192, 3, True, False),     # 48 tiles on <= 256 workgroups: 1 tile each
+    (80, 16, 16, 128, 64, 384, 3, False, True),   # 320 tiles: 64 workgroups walk 2 tiles, virtual concat, residual
+    (72, 16, 16, 192, 0, 768, 1, True, True),     # 576 tiles (3 rounds for some), 1x1, temb + residual, m-fast order
+])
+def test_conv2d_persistent_tile_variant_bit_identical(case):
+    """Variant 40 (k_igemm3: persistent workgroups, producers running ahead across tile boundaries, wave-private
+    epilogue) against variant 29 (one tile per workgroup) on the same call: outputs bit-identical, GroupNorm
+    partial sums equal after folding the splits, deterministic across repeats."""
+    from afldm_amd import _lib
+    ops = _ops()
+    dt = torch.bfloat16
+    B, H, W, C1, C2, Cout, KS, use_temb, use_res = case
+    g = torch.Generator().manual_seed(B + Cout)
+    x1 = torch.randn(B, H, W, C1, generator=g).to(dt).cuda()
+    x2 = torch.randn(B, H, W, C2, generator=g).to(dt).cuda() if C2 else None
+    w = (torch.randn(Cout, KS, KS, C1 + C2, generator=g) / (KS * (C1 + C2) ** 0.5)).to(dt).cuda()
+    bias = torch.randn(Cout, generator=g).cuda()
+    temb = torch.randn(B, Cout, generator=g).to(dt).cuda() if use_temb else None
+    res = torch.randn(B, H, W, Cout, generator=g).to(dt).cuda() if use_res else None
+    outs = {}
+    try:
+        for v in (29, 40, 40):
+            _lib.check(_lib.lib.afldm_conv2d_tune(v, 1), "tune")
+            y = ops.conv2d(x1, w, bias, x2=x2, temb=temb, temb_stride=Cout if use_temb else 0, residual=res, want_stats=True)
+            outs.setdefault(v, []).append((y, y.gn_partial))
+    finally:
+        _lib.lib.afldm_conv2d_tune(-1, -1)
+    y29, st29 = outs[29][0]
+    for y40, st40 in outs[40]:
+        assert torch.equal(y29, y40)
+        assert st40.shape[1] == (H * W // 128) * 4
+        yv = y40.float()
+        assert (st40.double().sum(1)[..., 0].cpu() - yv.double().sum((1, 2)).cpu()).abs().max() <= 1e-3 * (1 + yv.abs().sum((1, 2)).max().item())
+        torch.testing.assert_close(st40.sum(1), st29.sum(1), rtol=1e-4, atol=1e-2)
+    assert torch.equal(outs[40][0][1], outs[40][1][1])
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [
     (2, 32, 32, 64, 0, 192, 3, True),      # H*W % 128 == 0, no split-K: statistics from the GEMM epilogue

@@ -12,6 +12,8 @@ step = rows[idx[-2]:idx[-1]]
 
 
 def short(n):
+    if "k_igemm3" in n:
+        return "igemm3_128x192p"
     if "k_igemm" in n:
         m = re.search(r"Li(\d+)ELi(\d+)ELi\d+ELi\d+ELi\d+E(?:Li(\d+)E)?", n)
         return f"igemm{'2' if 'igemm2' in n else ''}_{m.group(1)}x{m.group(2)}" + (f"s{m.group(3)}" if m.group(3) else "")
