@@ -172,7 +172,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "denoise-steps/sec (FFHQ-256 AF-UNet + DDIM update), ms/step alongside",
+            "metric": "denoise-steps/sec + ms/step, FFHQ-256 AF-UNet, batch 64 @1/2/4/8 GPU",     # BASELINE.json "metric", verbatim
             "value": round(total * args.steps / dt, 2),
             "unit": "denoise-steps/s",
             "n_gpus": world,
