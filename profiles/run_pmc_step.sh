@@ -1,0 +1,49 @@
+#!/bin/bash
+# HBM traffic (PMC) of EVERY kernel of a denoise step (batch 64, bf16, eager launches so that each dispatch is
+# visible to the counters).  Separate passes for FETCH_SIZE and WRITE_SIZE; bytes = (2 * FETCH_SIZE +
+# WRITE_SIZE) * 1024 (MI355X_MICROARCH.md, "HBM" / rocprofv3 sections).  Usage: profiles/run_pmc_step.sh <tag>
+TAG=${1:-r01}
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
+OUT=gpurun_out/pmc_step_$TAG; rm -rf $OUT; mkdir -p $OUT
+CMD="python bench.py --no-graph --steps 4 --warmup 2 --no-cpu-baseline --no-roofline"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o fetch -- $CMD > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o write -- $CMD > $OUT/write.log 2>&1
+python - "$OUT" "$TAG" <<'PY'
+import csv, glob, json, re, sys
+out, tag = sys.argv[1], sys.argv[2]
+
+
+def fam(n):
+    for k in ("k_igemm3", "k_igemm2", "k_igemm", "k_lin_wreg", "k_attn", "k_af_act_plane", "k_af_act_kron", "k_af_act_small",
+              "k_resample_plane", "k_axis_contract", "k_splitk", "k_gn_apply", "k_gn_partial", "k_conv_cin4", "k_conv_small"):
+        if k in n:
+            return k
+    return "other"
+
+
+tot = {}
+nsteps = 0
+for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    f = glob.glob(out + "/**/" + name + "_counter_collection.csv", recursive=True)[0]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == ctr]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    marks = [i for i, r in enumerate(rows) if "k_select_timestep" in r["Kernel_Name"]]
+    lo, hi = marks[2], marks[-1]           # steady state: from the third step's first kernel to the last step's
+    nsteps = len(marks) - 3
+    for r in rows[lo:hi]:
+        d = tot.setdefault(fam(r["Kernel_Name"]), dict(fetch=0.0, write=0.0, n=0))
+        d[name] += float(r["Counter_Value"])
+        if name == "fetch":
+            d["n"] += 1
+STEPS = float(nsteps)
+res = {}
+for k, d in sorted(tot.items(), key=lambda kv: -(2 * kv[1]["fetch"] + kv[1]["write"])):
+    res[k] = dict(launches_per_step=round(d["n"] / STEPS, 1), read_MB_per_step=round(2 * d["fetch"] * 1024 / STEPS / 1e6, 1),
+                  write_MB_per_step=round(d["write"] * 1024 / STEPS / 1e6, 1))
+total = dict(read_MB_per_step=round(sum(v["read_MB_per_step"] for v in res.values()), 1),
+             write_MB_per_step=round(sum(v["write_MB_per_step"] for v in res.values()), 1))
+doc = dict(tag=tag, note="HBM bytes per denoise step by kernel family: (2*FETCH_SIZE, WRITE_SIZE)*1024, separate --pmc passes, eager step",
+           total=total, families=res)
+print(json.dumps(doc, indent=1))
+open("gpurun_out/step_traffic_%s.json" % tag, "w").write(json.dumps(doc, indent=1) + "\n")
+PY
