@@ -289,3 +289,15 @@ def test_upfirdn2d_host_argument_handling():
         assert torch.equal(up.setup_filter(f, **kw), ou.setup_filter(f, **kw)), (f, kw)
     with pytest.raises(RuntimeError):          # no CPU path
         up.upfirdn2d(torch.zeros(1, 1, 4, 4), torch.ones(2, 2))
+
+
+def test_integration_doc_lists_every_entry_point():
+    """INTEGRATION.md's C-ABI summary must name every function include/afldm_hip.h declares."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "afldm_hip.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    names = sorted(set(re.findall(r"\b(afldm_[a-z0-9_]+)\s*\(", header)))
+    assert len(names) >= 36
+    missing = [n for n in names if n not in doc]
+    assert not missing, missing
