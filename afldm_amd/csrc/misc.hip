@@ -88,7 +88,8 @@ __global__ void k_silu(const T* __restrict__ x, T* __restrict__ y, size_t n) {
 
 // ----------------------------------------------------------------------------- DDIM
 template <typename T>
-__global__ void k_ddim_step(const float* __restrict__ x, const T* __restrict__ eps, float* __restrict__ xprev,
+// (x and xprev may alias: the engine updates the latents in place, every thread reads and writes index i only)
+__global__ void k_ddim_step(const float* x, const T* __restrict__ eps, float* xprev,
                             const float* __restrict__ coef, int* __restrict__ step_idx, int advance, int B,
                             int C, int HW) {
   const int s = *step_idx;
@@ -274,8 +275,7 @@ extern "C" int afldm_select_timestep(const float* tvals, int* step_idx, float* t
 
 // Same update with the four coefficients passed by value and flat fp32 tensors (the
 // DDIMScheduler.step(model_output, t, sample) API path, where both tensors are NCHW fp32).
-__global__ void k_ddim_step_flat(const float* __restrict__ x, const float* __restrict__ eps,
-                                 float* __restrict__ xprev, float sa_t, float sb_t, float sa_p, float sb_p,
+__global__ void k_ddim_step_flat(const float* x, const float* __restrict__ eps, float* xprev, float sa_t, float sb_t, float sa_p, float sb_p,
                                  size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float e = eps[i];

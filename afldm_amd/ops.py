@@ -475,11 +475,19 @@ def masked_metrics(a, b, mask):
     if a.dtype not in (torch.float32, torch.bfloat16) or b.dtype != a.dtype:
         a, b = a.float(), b.float()
     a, b = a.contiguous(), b.contiguous()
-    m = mask.to(device=a.device, dtype=torch.float32).expand_as(a).contiguous()
+    mask = mask.to(device=a.device, dtype=torch.float32)
+    m = mask.expand_as(a).contiguous()
     B = a.shape[0]
     out = torch.empty((B, 6), dtype=torch.float32, device=a.device)
     check(lib.afldm_masked_metrics(ptr(a), ptr(b), ptr(m), ptr(out), B, a.numel() // B, _code(a), stream_ptr()),
           "masked_metrics")
+    # The reference divides by mask.sum((1,2,3)) of the mask's OWN shape (metrics.py:6-7): a broadcast
+    # [B,1,H,W] mask (what ImageShifter returns) counts each pixel once, not once per channel.  The kernel
+    # summed the expanded mask: `rep` copies of every mask element.
+    if mask.ndim == a.ndim:
+        rep = (a.numel() // B) // max(mask.numel() // mask.shape[0], 1)
+        if rep > 1:
+            out[:, 1] /= rep
     return out
 
 

@@ -38,7 +38,11 @@ class MyLDMPipeline(DiffusionPipeline):
         return cls(vae, unet, scheduler)
 
     def _engine(self, batch, steps, use_graph):
-        key = (batch, steps, use_graph, self.unet.dtype, str(self.unet.device), id(self.scheduler))
+        # keyed on the scheduler's CONFIG (the coefficient / timestep tables are a function of it), not on the
+        # scheduler object: __call__ re-creates the scheduler every time (like the reference, ldm_pipeline.py:80),
+        # and an identity key made every call rebuild the engine and re-capture its HIP graphs
+        cfg_key = tuple(sorted((k, repr(v)) for k, v in dict(self.scheduler.config).items()))
+        key = (batch, steps, use_graph, self.unet.dtype, str(self.unet.device), cfg_key)
         if key not in self._engines:
             self._engines = {key: DenoiseEngine(self.unet, self.scheduler, batch, steps, use_graph)}
         return self._engines[key]

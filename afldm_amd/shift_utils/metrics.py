@@ -17,7 +17,9 @@ def _stats(a, b, mask):
         return ops.masked_metrics(a, b, mask)
     am, bm = a * mask, b * mask
     dims = tuple(range(1, a.ndim))
-    cols = [(am - bm).square().sum(dims), mask.expand_as(a).sum(dims) if mask.shape != a.shape else mask.sum(dims),
+    # denominator: the mask summed over ITS OWN shape (metrics.py:6-7) - a [B,1,H,W] mask counts a pixel once
+    msum = (mask.sum(tuple(range(1, mask.ndim))) if mask.ndim == a.ndim else mask.expand_as(a).sum(dims)).expand(a.shape[0])
+    cols = [(am - bm).square().sum(dims), msum,
             am.amax(dims), am.amin(dims), bm.amax(dims), bm.amin(dims)]
     return torch.stack([c.to(torch.float32) for c in cols], 1)
 

@@ -318,6 +318,71 @@ def part_e():
     np.savez_compressed(os.path.join(OUT, "g10_upfirdn.npz"), **g)
 
 
+def part_f():
+    """Round-2 oracle vectors: ddim_inversion and the enable_interp attention blend on the tiny config;
+    FFHQ-size multi-step trajectories (3 DDIM steps, 3 I2SB evaluations, B = 1 fp32); the FULL AF-VAE
+    (configs/vae/model_afvae.json topology, 83.65 M parameters) encode + decode of one 256^2 image."""
+    from . import configs, ddim, i2sb, pipeline, unet
+    from . import vae as ov
+    torch.set_num_threads(8)
+    cfg = configs.tiny_unet()
+    sd = unet.randomize_norm_affine(unet.init_unet_params(cfg, seed=0, conv_out_scale=0.1))
+    gen = torch.Generator().manual_seed(4321)
+    g = {}
+    z0 = 0.5 * torch.randn(1, 4, 16, 16, generator=gen)
+    g["inv_in"] = z0.numpy()
+    g["inv_out_6"] = pipeline.ddim_inversion(sd, cfg, z0, 6).numpy()
+    # enable_interp: STORE pass 0 on xa, STORE pass 1 on xb (batch 1 each), LOAD on a batch of 2 with alpha = 0.3
+    xa, xb = torch.randn(1, 4, 16, 16, generator=gen), torch.randn(1, 4, 16, 16, generator=gen)
+    xc = torch.randn(2, 4, 16, 16, generator=gen)
+    cache = unet.AttnCache(enable_interp=True)
+    cache.state, cache.timestep = unet.AttnCache.STORE, 501
+    cache.store_id = 0
+    unet.unet_forward(sd, cfg, xa, 501, cache=cache)
+    cache.store_id = 1
+    unet.unet_forward(sd, cfg, xb, 501, cache=cache)
+    cache.state, cache.alpha = unet.AttnCache.LOAD, 0.3
+    g["interp_xa"], g["interp_xb"], g["interp_xc"] = xa.numpy(), xb.numpy(), xc.numpy()
+    g["interp_y"] = unet.unet_forward(sd, cfg, xc, 501, cache=cache).numpy()
+    cache.alpha = 0.0
+    g["interp_y_alpha0"] = unet.unet_forward(sd, cfg, xc, 501, cache=cache).numpy()
+
+    # FFHQ-size trajectories (SURVEY.md 8c G6 asked for a 3-step one)
+    cfg = configs.FFHQ_UNET
+    sd = unet.init_unet_params(cfg, seed=0, conv_out_scale=0.1)
+    x = torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(1234))
+    g["ffhq_x"] = x.numpy()
+    sched = ddim.DDIM()
+    sched.set_timesteps(50)
+    lat = x * sched.init_noise_sigma
+    for k, t in enumerate(sched.timesteps[:3]):
+        lat = sched.step(unet.unet_forward(sd, cfg, sched.scale_model_input(lat, t), t), t, lat, eta=0.0)
+        g[f"ffhq_ddim_step{k + 1}"] = lat.numpy()
+    s2 = i2sb.I2SB()
+    s2.set_timesteps(50)
+    lat = 0.8 * x
+    g["ffhq_i2sb_start"] = lat.numpy()
+    for k, t in enumerate(s2.timesteps[:3]):
+        lat = s2.step(unet.unet_forward(sd, cfg, lat, t), t, lat)
+        g[f"ffhq_i2sb_eval{k + 1}"] = lat.numpy()
+    np.savez_compressed(os.path.join(OUT, "g11_r02.npz"), **g)
+
+    # full-size AF-VAE, one 256^2 image (seed 7 as SURVEY.md 8d): posterior moments and the decode of a seeded latent
+    vcfg = dict(ov.AF_VAE)
+    vsd = ov.init_vae_params(vcfg, seed=3)
+    gen = torch.Generator().manual_seed(7)
+    img = torch.rand(1, 3, 256, 256, generator=gen) * 2 - 1
+    z = torch.randn(1, 4, 32, 32, generator=gen)
+    g = {"img": img.numpy().astype(np.float16), "z": z.numpy()}
+    img = torch.from_numpy(g["img"].astype(np.float32))
+    g["moments"] = ov.encode_moments(vsd, vcfg, img).numpy()
+    dec = ov.decode(vsd, vcfg, z)
+    g["dec_crop"] = dec[:, :, 96:160, 96:160].numpy()
+    g["dec_ds4"] = dec[:, :, ::4, ::4].numpy()
+    g["dec_sums"] = np.array([float(dec.double().sum()), float((dec.double() ** 2).sum())])
+    np.savez_compressed(os.path.join(OUT, "g12_full_vae.npz"), **g)
+
+
 def idf_warp(x):
     from .ideal_filters import warped_nonlinearity
     return warped_nonlinearity(x)
@@ -336,5 +401,7 @@ if __name__ == "__main__":
         part_d()
     if which in ("e", "all"):
         part_e()
+    if which in ("f", "all"):
+        part_f()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

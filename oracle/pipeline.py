@@ -30,6 +30,27 @@ def ddim_sample(sd, cfg, latents, num_inference_steps=50, af=True, cache=None, d
 
 
 @torch.no_grad()
+def ddim_inversion(sd, cfg, latent, num_inference_steps=50, af=True, ddim_cfg=None):
+    """MyLDMPipeline.ddim_inversion (ldm_pipeline.py:133-160): deterministic DDIM inversion over the
+    REVERSED timesteps of the scheduler's current schedule.  `reversed(tensor)` is `tensor.flip(0)`, so
+    `timesteps[i - 1]` (:144-147) is the next-SMALLER timestep; step 0 uses final_alpha_cumprod.
+        pred_x0 = (latent - sigma_prev eps) / mu_prev ;  latent = mu pred_x0 + sigma eps     (:156-158)
+    The caller must have called scheduler.set_timesteps (shift_ldm_ffhq.py:114-116 does)."""
+    sched = DDIM(ddim_cfg)
+    sched.set_timesteps(num_inference_steps)
+    timesteps = sched.timesteps.flip(0)
+    for i, t in enumerate(timesteps):
+        alpha_prod_t = sched.alphas_cumprod[int(t)]
+        alpha_prod_t_prev = sched.alphas_cumprod[int(timesteps[i - 1])] if i > 0 else sched.final_alpha_cumprod
+        mu, mu_prev = alpha_prod_t ** 0.5, alpha_prod_t_prev ** 0.5
+        sigma, sigma_prev = (1 - alpha_prod_t) ** 0.5, (1 - alpha_prod_t_prev) ** 0.5
+        eps = unet_forward(sd, cfg, latent, t, af=af)
+        pred_x0 = (latent - sigma_prev * eps) / mu_prev
+        latent = mu * pred_x0 + sigma * eps
+    return latent
+
+
+@torch.no_grad()
 def shift_equivariance(sd, cfg, init_latent, offsets, num_inference_steps=50, ratio=8, af=True,
                        cross_frame=True):
     """Latent-space core of shift_ldm (shift_ldm_ffhq.py:124-151): one STORE pass on the

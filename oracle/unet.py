@@ -153,10 +153,14 @@ class AttnCache:
     (AttnState + CrossFrameAttnProcessor.maps, cross_frame_attn.py:6-64)."""
     STORE, LOAD, IDLE = 0, 1, 2
 
-    def __init__(self):
+    def __init__(self, enable_interp=False):
         self.state = AttnCache.IDLE
         self.timestep = 0
-        self.maps = {}          # site -> {t: pre-norm NCHW map}
+        self.maps = {}          # site -> {t: pre-norm NCHW map}            (store_id 0)
+        self.maps1 = {}         # site -> {t: pre-norm NCHW map}            (store_id 1, cross_frame_attn.py:64)
+        self.store_id = 0       # AttnState.store_id (:29-31): which of the two map sets a STORE pass fills
+        self.alpha = 0.0        # AttnState.alpha (:33-35)
+        self.enable_interp = enable_interp   # CrossFrameAttnProcessor(enable_interp=...) (:61-64)
 
 
 class _Ctx:
@@ -200,27 +204,25 @@ def resnet_block(c, prefix, x, emb):
     return out
 
 
-def attention_block(c, prefix, x):
-    """diffusers Attention (deprecated attn-block config) via AttnProcessor2_0, with the
-    reference's CrossFrameAttnProcessor semantics (cross_frame_attn.py:66-130)."""
+def _cached_kv_tokens(c, prefix, m, b, ch, hw):
+    """cross_frame_attn.py:82-98 (and :103-117 for the second map): stored pre-norm NCHW map ->
+    [n, hw, c] tokens -> attn.group_norm -> batch repeat up to the current batch."""
+    n0 = m.shape[0]
+    m = m.view(n0, ch, hw)
+    m = F.group_norm(m, c.groups, c.sd[prefix + ".group_norm.weight"], c.sd[prefix + ".group_norm.bias"],
+                     c.eps).transpose(1, 2)
+    if n0 < b:
+        m = m.unsqueeze(1).repeat(1, b // n0, 1, 1).reshape(b, hw, ch)
+    return m
+
+
+def _attention_core(c, prefix, x, kv_src):
+    """AttnProcessor2_0.__call__ for the deprecated attention-block configuration (group norm on the
+    flattened input, q from the input, k/v from `kv_src` tokens or the normed input, SDPA, to_out,
+    residual connection, rescale_output_factor 1)."""
     sd, cfg = c.sd, c.cfg
     b, ch, hh, ww = x.shape
     heads = ch // cfg["attention_head_dim"]
-    residual = x
-    kv_src = None
-    if c.cache is not None and c.cache.state != AttnCache.IDLE:
-        t = c.cache.timestep
-        if c.cache.state == AttnCache.STORE:
-            c.cache.maps.setdefault(prefix, {})[t] = x.detach().clone()
-        else:   # LOAD: K/V from the cached pre-norm map of the unshifted pass, group-normed
-            m = c.cache.maps[prefix][t]
-            n0 = m.shape[0]
-            m = m.view(n0, ch, hh * ww)
-            m = F.group_norm(m, c.groups, sd[prefix + ".group_norm.weight"],
-                             sd[prefix + ".group_norm.bias"], c.eps).transpose(1, 2)
-            if n0 < b:
-                m = m.unsqueeze(1).repeat(1, b // n0, 1, 1).reshape(b, hh * ww, ch)
-            kv_src = m
     h = x.view(b, ch, hh * ww)
     h = F.group_norm(h, c.groups, sd[prefix + ".group_norm.weight"],
                      sd[prefix + ".group_norm.bias"], c.eps).transpose(1, 2)
@@ -236,7 +238,29 @@ def attention_block(c, prefix, x):
     o = o.transpose(1, 2).reshape(b, -1, ch)
     o = F.linear(o, sd[prefix + ".to_out.0.weight"], sd[prefix + ".to_out.0.bias"])
     o = o.transpose(-1, -2).reshape(b, ch, hh, ww)
-    out = o + residual
+    return o + x
+
+
+def attention_block(c, prefix, x):
+    """diffusers Attention (deprecated attn-block config) via AttnProcessor2_0, with the
+    reference's CrossFrameAttnProcessor semantics (cross_frame_attn.py:66-130), including the
+    `enable_interp` blend of two stored passes (:100-122)."""
+    b, ch, hh, ww = x.shape
+    kv_src = None
+    if c.cache is not None and c.cache.state != AttnCache.IDLE:
+        t = c.cache.timestep
+        if c.cache.state == AttnCache.STORE:
+            maps = c.cache.maps if c.cache.store_id == 0 else c.cache.maps1
+            maps.setdefault(prefix, {})[t] = x.detach().clone()
+        else:   # LOAD: K/V from the cached pre-norm map of the unshifted pass, group-normed
+            kv_src = _cached_kv_tokens(c, prefix, c.cache.maps[prefix][t], b, ch, hh * ww)
+            if c.cache.enable_interp:
+                kv1 = _cached_kv_tokens(c, prefix, c.cache.maps1[prefix][t], b, ch, hh * ww)
+                alpha = c.cache.alpha
+                out = (1 - alpha) * _attention_core(c, prefix, x, kv_src) + alpha * _attention_core(c, prefix, x, kv1)
+                c.tap(prefix, out)
+                return out
+    out = _attention_core(c, prefix, x, kv_src)
     c.tap(prefix, out)
     return out
 

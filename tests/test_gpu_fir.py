@@ -226,8 +226,8 @@ def test_masked_metrics_kernel_vs_oracle(golden, dtype):
     x = torch.randn(3, 4, 32, 32, generator=gen).to(dtype)
     y = (x.float() + 0.1 * torch.randn(3, 4, 32, 32, generator=gen)).to(dtype)
     for mask in ((torch.rand(3, 4, 32, 32, generator=gen) > 0.3).float(), (torch.rand(3, 1, 32, 32, generator=gen) > 0.5).float()):
-        ref_mse = osh.mask_mse(x.float(), y.float(), mask.expand(3, 4, 32, 32))
-        ref_psnr = osh.mask_psnr(x.float(), y.float(), mask.expand(3, 4, 32, 32))
+        ref_mse = osh.mask_mse(x.float(), y.float(), mask)          # un-expanded: the reference sums the mask's own shape
+        ref_psnr = osh.mask_psnr(x.float(), y.float(), mask)
         got_mse = metrics.mask_mse(x.cuda(), y.cuda(), mask.cuda())
         got_psnr = metrics.mask_psnr(x.cuda(), y.cuda(), mask)          # a host mask is moved by the wrapper
         assert abs(float(got_mse) - float(ref_mse)) <= 2e-6 * float(ref_mse)
