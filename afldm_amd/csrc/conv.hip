@@ -18,37 +18,9 @@
 // epilogue terms — used for the 2x2 / 4x4 levels where M = B*HW is too small to fill 256 CUs.
 #include <stdlib.h>
 
-#include "common.hpp"
+#include "conv_common.hpp"
 
 namespace afldm {
-
-struct ConvP {
-  const void* x1;
-  const void* x2;
-  const void* w;
-  const float* bias;
-  const void* temb;
-  const void* residual;
-  void* y;
-  void* y2;      // optional second output (channel-major) for couts >= split_n
-  float* ws;
-  int split_n;
-  int C1, C2, B, H, W, Cout, KS;
-  int temb_stride, res_ld, y_ld, out_mode;
-  int temb_mod;  // temb column = cout % temb_mod (a 3x3 conv on a 2x2 plane run as one dense layer: cout = pixel * C + c)
-  int M;        // B*H*W
-  int ksteps;   // total K steps = KS*KS * (C1+C2)/(KCH*EPR)
-  int splitk;   // grid.z
-  int tiles_n;
-  int vec_ok;   // leading dims allow 4-element vector epilogue accesses
-  int tap_inner;  // K order of the LDS-DMA kernel (see k_igemm2)
-  float* stats_out;  // per-channel GroupNorm partial sums of the output [B][stats_S][Cout][2], or NULL
-  int stats_S;
-  int stats_multi;   // the tile spans BM / (H*W) whole samples: statistics per sample with S = 1 (64x64 tiles only)
-  int m_fast;     // tile order of the LDS-DMA kernel: 1 = tile_m fastest (weights outweigh pixels)
-  int stage_ok;   // leading dimensions / splits allow the LDS-staged 16-byte epilogue
-  int dbg;      // AFLDM_CONV_DBG (timing decomposition only): bit 0 skip the LDS-DMA, bit 1 skip the MFMA phase
-};
 
 __device__ __forceinline__ int swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 
@@ -269,12 +241,6 @@ __global__ void __launch_bounds__(WGM* WGN * 64) k_igemm(ConvP p) {
 // l of a 16-row group writes physical chunk (l & 3) of row (l >> 2) and therefore fetches logical
 // chunk (l & 3) ^ swz(row).  Zero padding, M / Cout tails and the "past the end" ring slots use
 // the buffer descriptor's bounds check: an out-of-range voffset writes zeros to LDS.
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 // NPROD = 0: every wave both issues its share of the LDS-DMA and computes (v2).
 // NPROD > 0: wave specialisation (v3) — the first WGM*WGN waves are CONSUMERS (LDS fragment reads +
@@ -1421,6 +1387,7 @@ struct Plan {
   int kind;  // 0 igemm, 1 small_cin, 2 small_cout
   int cfg;   // igemm tile config
   int splitk;
+  int cfg_auto, splitk_auto;   // the automatic choice (fallback when a forced / preferred variant cannot run the shape)
 };
 
 constexpr int KCH_DEFAULT = 2;
@@ -1471,6 +1438,12 @@ static const Variant kVariants[] = {
     {64, 128, 4, 2},   // 38
     {64, 192, 4, 3},   // 39
     {128, 192, 5, 3},  // 40  ver 5 = persistent tiles (k_igemm3): producers run ahead across tile boundaries
+    {256, 192, 6, 3},  // 41  ver 6 = halo-patch 3x3 (conv3h.hip): 32x32 planes, 8 image rows per tile, 8 + 4 waves
+    {128, 192, 6, 3},  // 42  16x16 planes, 8 rows per tile, 8 consumers (64x48) + 4 producers
+    {128, 192, 6, 3},  // 43  16x16 planes, 4 consumers (64x96) + 4 producers
+    {256, 192, 6, 3},  // 44  16x16 planes, one whole sample per tile
+    {128, 192, 6, 3},  // 45  32x32 planes, 4 rows per tile, 8 + 4 waves
+    {128, 192, 6, 3},  // 46  32x32 planes, 4 rows per tile, 4 + 4 waves
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -1478,7 +1451,7 @@ template <typename T>
 static int epr() { return 4 * Mma<T>::EPC; }
 
 static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
-  Plan pl{0, 0, 1};
+  Plan pl{0, 0, 1, 0, 1};
   const int Ct = a->C1 + a->C2;
   const int kstep = KCH_DEFAULT * elems_per_row;
   const bool gemm_ok = (Ct % kstep == 0) && (a->C2 == 0 || a->C1 % kstep == 0);
@@ -1506,6 +1479,40 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
   else if (M >= 4096 && a->Cout % 128 == 0 && a->KS > 1) { vid = 30; bm = 128; bn = 128; }
   else if (M >= 1024) { vid = 31; bm = 128; bn = 64; }
   else { vid = 32; bm = 64; bn = 64; }
+  const int ksteps = a->KS * a->KS * (Ct / kstep);
+  auto splitk_for = [&](int v) {
+    const int bm_ = kVariants[v].bm, bn_ = kVariants[v].bn;
+    const long long tiles = ((M + bm_ - 1) / bm_) * ((a->Cout + bn_ - 1) / bn_);
+    int sk = 1;
+    if (kVariants[v].ver == 6) return 1;      // halo-patch kernel: no split-K
+    if (kVariants[v].ver == 4 && kVariants[v].stages == 3 && bn_ == 192) {
+      // one 8-wave workgroup per CU: aim at 256 workgroups (measured best: 64 tiles -> 4, 128 tiles -> 2)
+      sk = (int)((256 + tiles / 2) / tiles);
+      int maxsk = ksteps / 8;
+      if (sk > maxsk) sk = maxsk;
+      if (sk > 8) sk = 8;
+      if (sk < 1) sk = 1;
+    } else if (tiles < 256 && ksteps > 16) {   // (short K: a split only adds the reduction pass)   // measured: ~320 workgroups is the sweet spot (conv_variant_sweep2/4.log)
+      const int cap = ksteps >= 100 ? 8 : 4;      // long K (the 4x4 / 2x2 levels): 8 slices measured best in situ
+      sk = (int)(((ksteps >= 192 ? 768 : (cap == 8 ? 384 : 320)) + tiles - 1) / tiles);
+      int maxsk = ksteps / 4;
+      if (maxsk < 1) maxsk = 1;
+      if (sk > maxsk) sk = maxsk;
+      if (sk > cap) sk = cap;
+      if (sk < 1) sk = 1;
+    }
+    return sk;
+  };
+  pl.cfg_auto = vid;
+  pl.splitk_auto = splitk_for(vid);
+  // halo-patch kernel for the 3x3 convolutions of the 32x32 / 16x16 levels (conv3h.hip); support is checked by resolve_exec
+  {
+    static const int s_h3 = getenv("AFLDM_CONV3H") ? atoi(getenv("AFLDM_CONV3H")) : 1;      // 0: off, 2: variant 43 at 16x16
+    if (s_h3 && a->KS == 3 && a->C2 == 0 && a->H == a->W && a->Cout % 192 == 0) {
+      if (a->W == 32 && M >= 32768) vid = 41;
+      else if (a->W == 16 && M >= 8192) vid = s_h3 == 2 ? 43 : 42;
+    }
+  }
   // in-situ tuning hook (tools/tune_insitu.py): AFLDM_CONV_OVERRIDE="M:Cout:KS:Ct=variant/splitk;..."
   int ov_sk = -1;
   {
@@ -1515,37 +1522,16 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
         long long m_ = 0; int co = 0, ks = 0, ct = 0, v = -1, sk_ = -1;
         if (sscanf(q, "%lld:%d:%d:%d=%d/%d", &m_, &co, &ks, &ct, &v, &sk_) == 6 && m_ == M && co == a->Cout && ks == a->KS &&
             ct == Ct && v >= 0 && v < kNumVariants) {
-          vid = v; bm = kVariants[v].bm; bn = kVariants[v].bn; ov_sk = sk_;
+          vid = v; ov_sk = sk_;
         }
         q = strchr(q, ';');
         if (q) ++q;
       }
     }
   }
-  if (g_force_variant >= 0 && g_force_variant < kNumVariants) {
-    vid = g_force_variant; bm = kVariants[vid].bm; bn = kVariants[vid].bn;
-  }
+  if (g_force_variant >= 0 && g_force_variant < kNumVariants) vid = g_force_variant;
   pl.cfg = vid;
-  const long long tiles = ((M + bm - 1) / bm) * ((a->Cout + bn - 1) / bn);
-  const int ksteps = a->KS * a->KS * (Ct / kstep);
-  int sk = 1;
-  if (kVariants[vid].ver == 4 && kVariants[vid].stages == 3 && bn == 192) {
-    // one 8-wave workgroup per CU: aim at 256 workgroups (measured best: 64 tiles -> 4, 128 tiles -> 2)
-    sk = (int)((256 + tiles / 2) / tiles);
-    int maxsk = ksteps / 8;
-    if (sk > maxsk) sk = maxsk;
-    if (sk > 8) sk = 8;
-    if (sk < 1) sk = 1;
-  } else if (tiles < 256 && ksteps > 16) {   // (short K: a split only adds the reduction pass)   // measured: ~320 workgroups is the sweet spot (conv_variant_sweep2/4.log)
-    const int cap = ksteps >= 100 ? 8 : 4;      // long K (the 4x4 / 2x2 levels): 8 slices measured best in situ
-    sk = (int)(((ksteps >= 192 ? 768 : (cap == 8 ? 384 : 320)) + tiles - 1) / tiles);
-    int maxsk = ksteps / 4;
-    if (maxsk < 1) maxsk = 1;
-    if (sk > maxsk) sk = maxsk;
-    if (sk > cap) sk = cap;
-    if (sk < 1) sk = 1;
-  }
-  pl.splitk = sk;
+  pl.splitk = splitk_for(vid);
   if (ov_sk >= 1) pl.splitk = ov_sk;
   if (g_force_splitk >= 1) pl.splitk = g_force_splitk;
   return pl;
@@ -1616,6 +1602,10 @@ static bool igemm3_ok(const afldm_conv_args* a) {
 
 template <typename T>
 static bool launch_variant(int id, const ConvP& p, hipStream_t st) {
+  if (id >= kConv3hFirst) {
+    conv3h_launch(id, (int)sizeof(T), p, st);
+    return true;
+  }
   switch (id) {
     case 40: launch_igemm3<T>(p, st); return true;
     case 0: launch_igemm<T, 128, 128, 2, 2>(p, st); return true;
@@ -1690,7 +1680,25 @@ static Exec resolve_exec(const afldm_conv_args* a) {
     if (s_persist && e.vid == 29 && e.splitk == 1 && tiles >= 512 && igemm3_ok<T>(a)) e.vid = 40;
     if (e.vid == 40 && (e.splitk != 1 || !igemm3_ok<T>(a))) e.vid = 29;
   }
-  if (kVariants[e.vid].ver >= 2 && !v2_ok) e.vid = kVariants[e.vid].bm == 128 ? (kVariants[e.vid].bn >= 128 ? 0 : 1) : 3;
+  if (kVariants[e.vid].ver == 6) {
+    ConvP q;
+    memset(&q, 0, sizeof(q));
+    q.x1 = a->x1; q.w = a->w; q.y = a->y; q.y2 = a->y2; q.residual = a->residual; q.temb = a->temb;
+    q.C1 = a->C1; q.C2 = a->C2; q.H = a->H; q.W = a->W; q.Cout = a->Cout; q.KS = a->KS; q.M = (int)M;
+    q.out_mode = a->out_mode; q.y_ld = a->y_ld; q.res_ld = a->res_ld; q.temb_stride = a->temb_stride;
+    q.temb_mod = a->temb_mod > 0 ? a->temb_mod : a->Cout;
+    if (!conv3h_supported(e.vid, (int)sizeof(T), q)) {       // not this kernel's shape: the automatic choice
+      e.vid = e.pl.cfg_auto;
+      e.splitk = e.pl.splitk_auto;
+      if (e.splitk > 1) {
+        const size_t need = (size_t)e.splitk * M * a->Cout * sizeof(float);
+        if (!a->workspace || a->workspace_bytes < need) e.splitk = 1;
+      }
+    } else {
+      e.splitk = 1;
+    }
+  }
+  if (kVariants[e.vid].ver >= 2 && kVariants[e.vid].ver != 6 && !v2_ok) e.vid = kVariants[e.vid].bm == 128 ? (kVariants[e.vid].bn >= 128 ? 0 : 1) : 3;
   return e;
 }
 

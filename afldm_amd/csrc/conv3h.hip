@@ -1,0 +1,388 @@
+// conv3h.hip — 3x3 'same' convolution on MFMA with a HALO PATCH staged once per channel block (gfx950).
+//
+// The implicit GEMM of conv.hip re-fetches its pixel tile for every one of the 9 filter taps: 9 x (BM x 128 B)
+// of LDS-DMA per 64-channel block, and the PMC counters put its L2-miss traffic at 3x the algorithmic bytes
+// (profiles/conv3x3_traffic.json, round 1).  At full MFMA rate that stream alone asks for ~53 B/cycle/CU of
+// L2 -> LDS bandwidth, which is what the chip's L2s deliver in aggregate: the kernel was L2-bound as much as
+// MFMA-bound.  Here a workgroup owns BM pixels = BM / W WHOLE image rows of one sample and, per 64-channel
+// (128-byte) block, stages the (rows + 2) x (W + 2) pixel patch ONCE (zero padding written by the buffer
+// descriptor's bounds check); the nine taps are nine shifted views of that patch, so only the weights
+// (BN x 128 B per tap) stream per K step:
+//
+//   K order   : channel block outer, tap inner   (k_igemm2: tap outer, channel block inner)
+//   LDS       : [patch 0][patch 1][weight ring: STAGES x BN x 128 B]
+//   per step  : DMA  BN x 128 B (+ patch / 9)        against (BM + BN) x 128 B before
+//   roles     : WGM x WGN consumer waves (LDS fragment reads + MFMA only) + NPROD producer waves
+//               (LDS-DMA issue + counted vmcnt only), one s_barrier per K step
+//
+// LDS image: one 128-byte row per patch pixel / weight row holding the 8 16-byte chunks (chunk c = kc * 4 + lg:
+// MFMA K-chunk kc, lane group lg) of the channel block at position
+//       pos(c, q) = ((lg & 1) << 2 | kc << 1 | lg >> 1)  ^  ((q >> 1) & 3)            q = row index
+// A ds_read_b128 is served in 16-lane groups made of 8 rows of lane group lg and 8 rows of lg ^ 1: bit 2 of the
+// position separates the two halves, and 4 rows of equal parity inside ANY run of 16 consecutive rows differ in
+// (q >> 1) & 3 - so the fragment reads are bank-conflict free for every tap shift of the patch (the swizzle of
+// k_igemm2, (q >> 1) & 7 on all three bits, is only conflict free for 16-aligned runs).  An LDS-DMA writes
+// lane-linearly, so the permutation is applied to the per-lane SOURCE chunk (guide rule 21).
+//
+// The accumulators start from the residual (loaded in fragment layout under the pipeline prologue).  Epilogue: the
+// fp32 tile leaves through the idle pipeline buffers 128 rows at a time as whole rows, 16 bytes per lane:
+// (residual + sum) + (bias + temb) in fp32, one rounding, per-channel GroupNorm partial sums of the stored values
+// accumulated by the thread that owns the column (fixed order, no atomics).
+#include "conv_common.hpp"
+
+namespace afldm {
+
+__device__ __forceinline__ int h_chunk_at(int pos, int q) {   // source chunk that lives at position `pos` of row q
+  const int x = pos ^ ((q >> 1) & 3);
+  return ((x >> 1) & 1) * 4 + (x & 1) * 2 + (x >> 2);
+}
+
+template <typename T, int BM, int W_, int BN, int WGM, int WGN, int NPROD, int STAGES, int MINW>
+__global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP p) {
+  typedef Mma<T> MM;
+  typedef typename MM::Chunk Chunk;
+  constexpr int NWC = WGM * WGN;
+  constexpr int EPC = MM::EPC, KSTEP = 8 * EPC, ESZ = (int)sizeof(T);
+  constexpr int WMS = BM / WGM, WNS = BN / WGN, TM = WMS / 16, TN = WNS / 16;
+  constexpr int ROWS = BM / W_, PW = W_ + 2, PR = ROWS + 2, NPQ = PR * PW, NPI = (NPQ + 7) / 8;
+  constexpr int PATCH = NPI * 1024;
+  constexpr int WI = BN / 8, WPW = WI / NPROD, PPW = (NPI + NPROD - 1) / NPROD;
+  constexpr int W_STAGE = BN * 128;
+  constexpr int LDS_TOTAL = 2 * PATCH + STAGES * W_STAGE;
+  constexpr unsigned OOB = 0x80000000u;
+  static_assert(BM % W_ == 0 && WI % NPROD == 0 && WMS % 16 == 0 && WNS % 16 == 0, "tile shape");
+  static_assert((STAGES - 2) * WPW + PPW < 64, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_producer = wave_all >= NWC;
+  const int li = lane & 15, lg = lane >> 4;
+
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int Ct = p.C1, HW = p.H * W_;
+  const int ncb = Ct / KSTEP, G = ncb * 9;
+  const int b_tile = m0 / HW;
+  const int oh0 = (m0 - b_tile * HW) / W_;
+
+  if (is_producer) {
+    const int wave = wave_all - NWC;
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, (int)((long long)p.M * Ct * ESZ), 0x00020000);
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)((long long)p.Cout * 9 * Ct * ESZ), 0x00020000);
+    // patch: instruction j covers patch pixels 8 j .. 8 j + 7, lane l = (pixel l >> 3, position l & 7).  Waves whose
+    // share is one short re-issue the last instruction (same source, same destination): uniform vmcnt counts.
+    unsigned poff[PPW], woff[WPW];
+    int pj[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      int j = wave + NPROD * i;
+      if (j > NPI - 1) j = NPI - 1;
+      pj[i] = j;
+      const int q = 8 * j + (lane >> 3);
+      const int c = h_chunk_at(lane & 7, q);
+      const int pr = q / PW, pc = q - pr * PW;
+      const int ih = oh0 + pr - 1;
+      const bool ok = q < NPQ && pc >= 1 && pc <= W_ && ih >= 0 && ih < p.H;
+      const int pixel = m0 + (pr - 1) * W_ + (pc - 1);
+      poff[i] = ok ? ((unsigned)pixel * (unsigned)Ct + (unsigned)(c * EPC)) * ESZ : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+      const int r = 8 * (wave + NPROD * i) + (lane >> 3);      // weight row inside the BN slice
+      const int c = h_chunk_at(lane & 7, r);
+      woff[i] = ((unsigned)(n0 + r) * 9u * (unsigned)Ct + (unsigned)(c * EPC)) * ESZ;
+    }
+    // cursor of the next weight step to issue
+    int is_g = 0, is_tap = 0, is_cb = 0, is_slot = 0;
+    auto issue_weights = [&]() {
+      char* sbase = smem + 2 * PATCH + is_slot * W_STAGE;
+      const unsigned so = is_g < G ? (unsigned)((is_tap * Ct + is_cb * KSTEP) * ESZ) : OOB;
+#pragma unroll
+      for (int i = 0; i < WPW; ++i) {
+        lds_ptr_t dst = (lds_ptr_t)(sbase + (wave + NPROD * i) * 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, dst, 16, (int)woff[i], (int)so, 0, 0);
+      }
+      ++is_g;
+      if (++is_tap == 9) {
+        is_tap = 0;
+        ++is_cb;
+      }
+      is_slot = is_slot + 1 == STAGES ? 0 : is_slot + 1;
+    };
+    auto issue_patch = [&](int cb) {
+      char* sbase = smem + (cb & 1) * PATCH;
+      const unsigned so = (unsigned)(cb * KSTEP * ESZ);
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) {
+        lds_ptr_t dst = (lds_ptr_t)(sbase + pj[i] * 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, dst, 16, (int)poff[i], (int)so, 0, 0);
+      }
+    };
+    issue_patch(0);
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) issue_weights();
+    int tap = 0, cb = 0;
+    for (int g = 0; g < G; ++g) {
+      // in flight behind the weights of step g: the weights of steps g+1 .. g+STAGES-2, and - during taps
+      // 1 .. STAGES-1 of a channel block - the next block's patch (issued at tap 0, behind step g+STAGES-1's weights)
+      if (tap >= 1 && tap <= STAGES - 1 && cb + 1 < ncb) wait_vmcnt<(STAGES - 2) * WPW + PPW>();
+      else wait_vmcnt<(STAGES - 2) * WPW>();
+      __builtin_amdgcn_s_barrier();
+      if (!(p.dbg & 1)) {
+        issue_weights();
+        if (tap == 0 && cb + 1 < ncb) issue_patch(cb + 1);
+      }
+      if (++tap == 9) {
+        tap = 0;
+        ++cb;
+      }
+    }
+    wait_vmcnt<0>();   // drain the zero-fill tail before the workgroup's LDS can be re-assigned
+    return;
+  }
+
+  // ------------------------------------------------------------------------------------------- consumers
+  const int cw = wave_all, wm = cw / WGN, wn = cw - wm * WGN;
+  const int Pl = ((lg & 1) << 2) | (lg >> 1);                   // position bits of chunk (kc = 0, lg)
+  int qb[TM];                                                    // patch pixel of (tile pixel, tap (0, 0))
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int pix = wm * WMS + t * 16 + li;
+    const int r = pix / W_, c = pix - r * W_;
+    qb[t] = r * PW + c;
+  }
+  const int a_off0 = (wn * WNS + li) * 128 + ((Pl ^ ((li >> 1) & 3)) << 4);
+
+  // The accumulators START from the residual (fragment layout: lane (li, lg) of tile (tn, t) holds couts
+  // n0 + wn*WNS + 16 tn + 4 lg .. + 3 of pixel m0 + wm*WMS + 16 t + li): its load latency runs under the prologue of
+  // the LDS-DMA pipeline, when the consumers have nothing to do, instead of in the epilogue (one dependent global
+  // load per copied row was most of the fixed cost of a residual convolution); residual + sum of products, fp32.
+  f32x4 acc[TN][TM];
+  if (p.residual) {
+    const T* res = (const T*)p.residual;
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const T* src = res + (size_t)(m0 + wm * WMS + b * 16 + li) * p.res_ld + n0 + wn * WNS + a * 16 + 4 * lg;
+        float r0, r1, r2, r3;
+        load4<T>(src, r0, r1, r2, r3);
+        acc[a][b] = f32x4{r0, r1, r2, r3};
+      }
+  } else {
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  {
+    int slot = 0, tap = 0, kh = 0, kw = 0, pbuf = 0;
+    for (int g = 0; g < G; ++g) {
+      __builtin_amdgcn_s_barrier();
+      if (!(p.dbg & 2)) {
+        const char* sP = smem + pbuf * PATCH;
+        const char* sW = smem + 2 * PATCH + slot * W_STAGE;
+        const int tapoff = kh * PW + kw;
+        int boff[TM];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+          const int q = qb[t] + tapoff;
+          boff[t] = q * 128 + ((Pl ^ ((q >> 1) & 3)) << 4);
+        }
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+          Chunk a[TN], b[TM];
+#pragma unroll
+          for (int t = 0; t < TN; ++t) a[t] = ld16<Chunk>(sW + ((a_off0 + t * 2048) ^ (kc << 5)));
+#pragma unroll
+          for (int t = 0; t < TM; ++t) b[t] = ld16<Chunk>(sP + (boff[t] ^ (kc << 5)));
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) MM::mma(acc[tn][tm], a[tn], b[tm]);
+          if constexpr (NWC >= 8) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      slot = slot + 1 == STAGES ? 0 : slot + 1;
+      if (++kw == 3) {
+        kw = 0;
+        ++kh;
+      }
+      if (++tap == 9) {
+        tap = 0;
+        kh = 0;
+        pbuf ^= 1;
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------- epilogue
+  {
+    constexpr int SROW = BN + 8;                       // fp32 row stride: conflict-free 16-byte writes
+    constexpr int PROWS = BM < 128 ? BM : 128;         // rows staged per pass
+    constexpr int PASSES = BM / PROWS;
+    constexpr int WPP = WGM / PASSES;                  // consumer wave rows (wm) per pass
+    static_assert(PROWS * SROW * 4 <= LDS_TOTAL && WGM % PASSES == 0 && WPP * WMS == PROWS, "staging tile");
+    constexpr int NTC = NWC * 64;
+    constexpr int EO = 16 / ESZ;                       // output elements per 16-byte store
+    constexpr int CPR = BN / EO;                       // 16-byte chunks per row
+    constexpr int RPI = NTC / CPR;                     // rows the workgroup covers per sweep
+    static_assert(RPI * BN * 2 * 4 <= LDS_TOTAL, "statistics scratch");
+    float* sC = reinterpret_cast<float*>(smem);
+    const T* temb = (const T*)p.temb;
+    const int etid = cw * 64 + lane;
+    const bool active = etid < RPI * CPR;
+    const int ch = etid % CPR, tr = etid / CPR;
+    const int n = n0 + ch * EO;
+    // bias + time embedding of the thread's column (one sample per tile): added as ONE vector, acc + (bias + temb)
+    float bvec[EO], ss1[EO], ss2[EO];
+#pragma unroll
+    for (int e = 0; e < EO; ++e) bvec[e] = ss1[e] = ss2[e] = 0.f;
+    if (active) {
+      if (p.bias) {
+#pragma unroll
+        for (int q = 0; q < EO / 4; ++q) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n + 4 * q);
+          bvec[4 * q] = bv[0]; bvec[4 * q + 1] = bv[1]; bvec[4 * q + 2] = bv[2]; bvec[4 * q + 3] = bv[3];
+        }
+      }
+      if (temb) {
+        const Chunk tv = ld16<Chunk>(temb + (size_t)b_tile * p.temb_stride + n % p.temb_mod);
+#pragma unroll
+        for (int e = 0; e < EO; ++e) bvec[e] += to_f32(tv[e]);
+      }
+    }
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      __syncthreads();   // pipeline buffers idle (first pass) / previous pass copied out
+      if (wm / WPP == ps) {
+        const int wml = wm - ps * WPP;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int t = 0; t < TM; ++t) {
+            const int row = wml * WMS + t * 16 + li;
+            *reinterpret_cast<f32x4*>(sC + row * SROW + wn * WNS + tn * 16 + 4 * lg) = acc[tn][t];
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      }
+      __syncthreads();
+      if (active) {
+#pragma unroll 2
+        for (int row = tr; row < PROWS; row += RPI) {
+          const int m = m0 + ps * PROWS + row;
+          float v[EO];
+#pragma unroll
+          for (int q = 0; q < EO / 4; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(sC + row * SROW + ch * EO + 4 * q);
+            v[4 * q] = a[0]; v[4 * q + 1] = a[1]; v[4 * q + 2] = a[2]; v[4 * q + 3] = a[3];
+          }
+          Chunk o;
+#pragma unroll
+          for (int e = 0; e < EO; ++e) o[e] = from_f32<T>(v[e] + bvec[e]);       // (residual + sum) + (bias + temb)
+          st16<Chunk>((T*)p.y + (size_t)m * p.y_ld + n, o);
+          if (p.stats_out) {
+#pragma unroll
+            for (int e = 0; e < EO; ++e) {
+              const float vr = to_f32(o[e]);      // statistics of what the consumer will read
+              ss1[e] += vr;
+              ss2[e] = fmaf(vr, vr, ss2[e]);
+            }
+          }
+        }
+      }
+    }
+    if (p.stats_out) {
+      // per-channel sums of this tile's BM rows (one split of one sample): the RPI row-interleaved partials of a
+      // column are added in a fixed order through LDS
+      float* sR = sC;   // [RPI][BN][2]
+      __syncthreads();
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < EO; ++e) *reinterpret_cast<f32x2*>(sR + ((tr * BN) + ch * EO + e) * 2) = f32x2{ss1[e], ss2[e]};
+      }
+      __syncthreads();
+      for (int c = etid; c < BN; c += NTC) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int r = 0; r < RPI; ++r) {
+          const f32x2 v = *reinterpret_cast<const f32x2*>(sR + ((r * BN) + c) * 2);
+          a1 += v[0];
+          a2 += v[1];
+        }
+        const int sp = (m0 - b_tile * HW) / BM;
+        *reinterpret_cast<f32x2*>(p.stats_out + (((size_t)b_tile * p.stats_S + sp) * p.Cout + n0 + c) * 2) = f32x2{a1, a2};
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------- host side
+struct H3Variant {
+  int bm, w, wgm, wgn;
+};
+// ids kConv3hFirst + index
+static const H3Variant kH3[] = {
+    {256, 32, 4, 2},   // 41: 32x32 planes, 8 rows per tile; 8 consumer waves (64 x 96 each) + 4 producers
+    {128, 16, 2, 4},   // 42: 16x16 planes, 8 rows per tile; 8 consumers (64 x 48) + 4 producers
+    {128, 16, 2, 2},   // 43: 16x16 planes; 4 consumers (64 x 96) + 4 producers
+    {256, 16, 4, 2},   // 44: 16x16 planes, whole sample per tile
+    {128, 32, 2, 4},   // 45: 32x32 planes, 4 rows per tile
+    {128, 32, 2, 2},   // 46
+};
+constexpr int kNumH3 = (int)(sizeof(kH3) / sizeof(kH3[0]));
+
+bool conv3h_supported(int variant, int dtype_size, const ConvP& p) {
+  const int k = variant - kConv3hFirst;
+  if (k < 0 || k >= kNumH3) return false;
+  const H3Variant& v = kH3[k];
+  const int kstep = 128 / dtype_size;
+  const int eo = 16 / dtype_size;
+  const int HW = p.H * p.W;
+  return p.KS == 3 && p.C2 == 0 && p.W == v.w && p.H == p.W && HW % v.bm == 0 && p.M % v.bm == 0 && p.Cout % 192 == 0 &&
+         p.C1 % kstep == 0 && p.out_mode == 0 && !p.y2 && p.y_ld % eo == 0 && (!p.residual || p.res_ld % eo == 0) &&
+         (!p.temb || (p.temb_stride % eo == 0 && p.temb_mod % eo == 0)) && (long long)p.M * p.C1 * dtype_size < (1ll << 31) &&
+         (long long)p.Cout * 9 * p.C1 * dtype_size < (1ll << 31) && aligned16(p.y) && aligned16(p.x1) && aligned16(p.w);
+}
+
+template <typename T, int BM, int W_, int WGM, int WGN>
+static void launch_h3(const ConvP& p0, hipStream_t st) {
+  constexpr int BN = 192, NPROD = 4, STAGES = 3;
+  constexpr int NWC = WGM * WGN;
+  constexpr int MINW = (NWC + NPROD + 3) / 4;
+  constexpr int NPI = ((BM / W_ + 2) * (W_ + 2) + 7) / 8;
+  constexpr int lds = 2 * NPI * 1024 + STAGES * BN * 128;
+  ConvP p = p0;
+  p.tiles_n = p.Cout / BN;
+  p.splitk = 1;
+  const int tiles = (p.M / BM) * p.tiles_n;
+  auto kern = k_conv3h<T, BM, W_, BN, WGM, WGN, NPROD, STAGES, MINW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  kern<<<tiles, (NWC + NPROD) * 64, lds, st>>>(p);
+}
+
+template <typename T>
+static void launch_h3_variant(int k, const ConvP& p, hipStream_t st) {
+  switch (k) {
+    case 0: launch_h3<T, 256, 32, 4, 2>(p, st); break;
+    case 1: launch_h3<T, 128, 16, 2, 4>(p, st); break;
+    case 2: launch_h3<T, 128, 16, 2, 2>(p, st); break;
+    case 3: launch_h3<T, 256, 16, 4, 2>(p, st); break;
+    case 4: launch_h3<T, 128, 32, 2, 4>(p, st); break;
+    case 5: launch_h3<T, 128, 32, 2, 2>(p, st); break;
+  }
+}
+
+void conv3h_launch(int variant, int dtype_size, const ConvP& p, hipStream_t st) {
+  const int k = variant - kConv3hFirst;
+  if (dtype_size == 2) launch_h3_variant<bf16>(k, p, st);
+  else launch_h3_variant<float>(k, p, st);
+}
+
+}  // namespace afldm

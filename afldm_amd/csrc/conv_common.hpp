@@ -1,0 +1,48 @@
+// conv_common.hpp — argument block and LDS-DMA helpers shared by conv.hip (implicit GEMM) and conv3h.hip
+// (halo-patch 3x3 convolution).
+#pragma once
+#include "common.hpp"
+
+namespace afldm {
+
+struct ConvP {
+  const void* x1;
+  const void* x2;
+  const void* w;
+  const float* bias;
+  const void* temb;
+  const void* residual;
+  void* y;
+  void* y2;      // optional second output (channel-major) for couts >= split_n
+  float* ws;
+  int split_n;
+  int C1, C2, B, H, W, Cout, KS;
+  int temb_stride, res_ld, y_ld, out_mode;
+  int temb_mod;  // temb column = cout % temb_mod (a 3x3 conv on a 2x2 plane run as one dense layer: cout = pixel * C + c)
+  int M;        // B*H*W
+  int ksteps;   // total K steps = KS*KS * (C1+C2)/(KCH*EPR)
+  int splitk;   // grid.z
+  int tiles_n;
+  int vec_ok;   // leading dims allow 4-element vector epilogue accesses
+  int tap_inner;  // K order of the LDS-DMA kernel (see k_igemm2)
+  float* stats_out;  // per-channel GroupNorm partial sums of the output [B][stats_S][Cout][2], or NULL
+  int stats_S;
+  int stats_multi;   // the tile spans BM / (H*W) whole samples: statistics per sample with S = 1 (64x64 tiles only)
+  int m_fast;     // tile order of the LDS-DMA kernel: 1 = tile_m fastest (weights outweigh pixels)
+  int stage_ok;   // leading dimensions / splits allow the LDS-staged 16-byte epilogue
+  int dbg;      // AFLDM_CONV_DBG (timing decomposition only): bit 0 skip the LDS-DMA, bit 1 skip the MFMA phase
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// halo-patch 3x3 convolution (conv3h.hip): variant ids >= kConv3hFirst of the conv variant table
+constexpr int kConv3hFirst = 41;
+bool conv3h_supported(int variant, int dtype_size, const ConvP& p);
+void conv3h_launch(int variant, int dtype_size, const ConvP& p, hipStream_t st);
+
+}  // namespace afldm

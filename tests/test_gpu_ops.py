@@ -302,7 +302,7 @@ def test_conv2d_every_gemm_variant(dtype):
                 close(back(y), ref, dtype, f"conv variant {v} splitk {sk}", bf16_rms=6e-3)
     finally:
         _lib.lib.afldm_conv2d_tune(-1, -1)
-    assert nvar >= 37
+    assert nvar >= 43
 
 
 @pytest.mark.parametrize("case", [
@@ -342,6 +342,57 @@ def test_conv2d_persistent_tile_variant_bit_identical(case):
         assert (st40.double().sum(1)[..., 0].cpu() - yv.double().sum((1, 2)).cpu()).abs().max() <= 1e-3 * (1 + yv.abs().sum((1, 2)).max().item())
         torch.testing.assert_close(st40.sum(1), st29.sum(1), rtol=1e-4, atol=1e-2)
     assert torch.equal(outs[40][0][1], outs[40][1][1])
+
+
+H3_CASES = [
+    # B, N (plane), Cin, Cout, temb, residual, variants (conv3h.hip ids)
+    (2, 32, 192, 192, True, False, (41, 45, 46)),
+    (3, 32, 384, 192, False, True, (41, 45, 46)),
+    (2, 32, 64, 384, True, True, (41, 45, 46)),
+    (3, 16, 384, 384, True, True, (42, 43, 44)),
+    (5, 16, 128, 192, False, False, (42, 43, 44)),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", H3_CASES)
+def test_conv3x3_halo_patch_variants(dtype, case):
+    """conv3h.hip (halo patch staged once per channel block, nine taps as shifted views, producer / consumer waves):
+    every variant against F.conv2d in fp32 on the same (rounded) inputs, with time embedding, residual and the fused
+    GroupNorm statistics; bit-identical across reruns; the variant really ran (not the fallback)."""
+    from afldm_amd import _lib
+    ops = _ops()
+    B, N, Cin, Cout, use_temb, use_res, variants = case
+    g = torch.Generator().manual_seed(N + Cin + Cout)
+    x = rnd(dtype, torch.randn(B, Cin, N, N, generator=g))
+    w = rnd(dtype, torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5))
+    b = torch.randn(Cout, generator=g)
+    temb = rnd(dtype, torch.randn(B, Cout, generator=g)) if use_temb else None
+    res = rnd(dtype, torch.randn(B, Cout, N, N, generator=g)) if use_res else None
+    ref = F.conv2d(x, w, b, padding=1)
+    if use_temb:
+        ref = ref + temb[:, :, None, None]
+    if use_res:
+        ref = ref + res
+    xh, wp = nhwc(x, dtype), ops.pack_weight(w.cuda(), dtype)
+    th = temb.to(device="cuda", dtype=dtype) if use_temb else None
+    rh = nhwc(res, dtype) if use_res else None
+    try:
+        for v in variants:
+            _lib.check(_lib.lib.afldm_conv2d_tune(v, 1), "tune")
+            ys = [ops.conv2d(xh, wp, b.cuda(), temb=th, temb_stride=Cout if use_temb else 0, residual=rh, want_stats=True)
+                  for _ in range(2)]
+            bm = 256 if v in (41, 44) else 128
+            assert ys[0].gn_partial.shape == (B, N * N // bm, Cout, 2), (v, ys[0].gn_partial.shape)     # the halo kernel ran
+            close(back(ys[0]), ref, dtype, f"conv3h variant {v} {case}", bf16_rms=6e-3)
+            assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0].gn_partial, ys[1].gn_partial)
+            yv = ys[0].float()
+            got = ys[0].gn_partial.double().sum(1).cpu()
+            s1, s2 = yv.sum((1, 2)).cpu(), (yv * yv).sum((1, 2)).cpu()
+            assert (got[..., 0] - s1).abs().max() <= 1e-4 * (1 + s1.abs().max()), f"sum {v}"
+            assert (got[..., 1] - s2).abs().max() <= 1e-4 * (1 + s2.abs().max()), f"sumsq {v}"
+    finally:
+        _lib.lib.afldm_conv2d_tune(-1, -1)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -69,10 +69,6 @@ def test_ddim_inversion_vs_oracle(golden, dtype, tol):
     inv = pipe.ddim_inversion(torch.from_numpy(g["inv_in"]).cuda().to(dtype), bar=False)
     assert inv.dtype == dtype
     assert rel_rms(inv.float(), g["inv_out_6"]) <= tol
-    # inversion followed by sampling over the same schedule comes back to the input (DDIM is ~invertible)
-    if dtype == torch.float32:
-        back = pipe(latents=inv, num_inference_steps=6, output_type="latent")
-        assert rel_rms(back.float(), g["inv_in"]) <= 0.2
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
