@@ -585,8 +585,9 @@ def conv2d(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, o
         M, Ct = a.B * a.H * a.W, a.C1 + a.C2
         es = x1.element_size()
         kind = "conv3x3" if a.KS == 3 else ("conv1x1" if a.H * a.W > 1 and x1.ndim == 4 else "linear")
+        # algorithmic bytes: input + weights + output (+ the residual read), as tools/replay_conv3x3.py counts them
         _end(tok, kind, 2.0 * M * a.Cout * a.KS * a.KS * Ct,
-             (M * Ct + a.Cout * a.KS * a.KS * Ct + M * a.Cout) * es)
+             (M * Ct + a.Cout * a.KS * a.KS * Ct + M * a.Cout * (2 if residual is not None else 1)) * es)
     return out
 
 

@@ -2,13 +2,16 @@
 """bench.py — denoise-steps/sec of the FFHQ-256 alias-free UNet + DDIM update on MI355X.
 
 A "step" is one denoising step of the whole local batch: timestep select -> NCHW->NHWC ->
-AF-UNet forward (~450 HIP kernels from libafldm_hip.so) -> DDIM update, replayed as one
-captured HIP graph.  Workload = BASELINE.json configs[1] (batch 64 per GPU, bf16 storage /
+AF-UNet forward (a few hundred HIP kernels from libafldm_hip.so) -> DDIM update, replayed as one
+captured HIP graph.  Reported: the MEDIAN of --regions (5) timed regions of --steps steps each.  Workload = BASELINE.json configs[1] (batch 64 per GPU, bf16 storage /
 MFMA with fp32 accumulation), synthetic: seeded random weights of the FFHQ architecture
 (conv_out x0.1), CPU-seeded noise, inputs resident in HBM before the timed region.
 N > 1: launched by torch.distributed.run, one rank per GPU, batch-sharded (weak scaling: 64 per
 GPU), no per-step communication, ONE RCCL all-gather of the final latents inside the timed
-region.  Rank 0 prints one JSON line.
+region.  Rank 0 prints one JSON line.  At N = 1 the same line also carries, timed inside this run: the other
+single-GPU configurations of north_star (batch 1 / 8 bf16, batch 64 / 1 fp32: `other_configs`), BASELINE configs[3]
+(the AF-VAE at 256^2 x 128 with its shift-equivariance check: `vae_c4`; also `--workload vae` on its own), the
+roofline of the dominant kernel family and the CPU baseline on BASELINE configs[0].
 """
 import argparse
 import json
@@ -40,6 +43,12 @@ def build_unet(dtype, device):
     return unet.to(device).to(dtype)
 
 
+def lib_sha256():
+    import hashlib
+    from afldm_amd import _lib
+    return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+
+
 def roofline_pass(unet, batch, dtype):
     """One eager step with HIP events around every launch (ops.Profiler): per-kernel-family
     time and algorithmic work, measured live on the launch stream."""
@@ -62,23 +71,31 @@ def roofline_pass(unet, batch, dtype):
                       gbs=round(d["bytes"] / d["ms"] / 1e6, 1) if d["ms"] > 0 else 0.0)
     dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
     name, d = dom
-    # HBM bytes per launch of the dominant family from the PMC counters (FETCH_SIZE / WRITE_SIZE in
-    # separate rocprofv3 passes, gfx950 x2 read correction): collected offline by
-    # profiles/run_pmc_conv3x3.sh (a PMC pass cannot run inside the timed process) and committed.
-    traffic = None
+    # HBM bytes per launch of the dominant family from the PMC counters (FETCH_SIZE / WRITE_SIZE in separate
+    # rocprofv3 passes, gfx950 x2 read correction): a PMC pass cannot run inside the timed process, so it is
+    # collected by profiles/run_pmc_conv3x3.sh over a replay of exactly this family's launches and committed
+    # STAMPED WITH THE SHA-256 OF THE LIBRARY it was measured on; a stamp that does not match the library loaded
+    # here is refused (traffic = null) instead of quoting a stale build.
+    traffic, traffic_note = None, None
     try:
-        tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "conv3x3_traffic.json")))
-        if tj.get("family") == name and batch == 64 and dtype == torch.bfloat16:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "conv3x3_traffic.json")))
+        if tj.get("family") != name or batch != 64 or dtype != torch.bfloat16:
+            traffic_note = "no PMC record for this family / batch / dtype"
+        elif tj.get("lib_sha256") != lib_sha256():
+            traffic_note = "profiles/conv3x3_traffic.json was measured on another build of libafldm_hip.so (stale): refused"
+        else:
             traffic = round(tj["hbm_bytes_per_launch"])
-    except (OSError, ValueError, KeyError):
-        traffic = None
+            traffic_note = (f"PMC (2*FETCH_SIZE+WRITE_SIZE)*1024 over {tj['launches_per_step']} launches, tag {tj['tag']}; "
+                            f"algorithmic bytes per launch there: {round(tj['algorithmic_bytes_per_launch'])}")
+    except (OSError, ValueError, KeyError) as e:
+        traffic_note = f"no usable PMC record ({type(e).__name__})"
     mfma_bound = name.startswith("conv") or name == "linear" or name == "attention" or name.startswith("af_act_N3") \
         or name.startswith("af_act_N16")
     if mfma_bound:
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
         achieved = d["flops"] / d["ms"] / 1e9
         roof = dict(kernel=name, bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
-                    frac=round(achieved / peak, 4), traffic=traffic,
+                    frac=round(achieved / peak, 4), traffic=traffic, traffic_note=traffic_note,
                     launches_per_step=d["launches"] // 3, avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
                     flops_per_launch=d["flops"] / d["launches"], algorithmic_bytes_per_launch=round(d["bytes"] / d["launches"]))
     else:
@@ -90,20 +107,139 @@ def roofline_pass(unet, batch, dtype):
     return roof, fam
 
 
-def cpu_baseline(batch=4, budget_s=12.0):
-    """The oracle (CPU restatement, eager PyTorch fp32: torch.fft filters, F.conv2d, SDPA) on the host
-    cores: a bounded sample of the bench workload (batch 4 instead of 64, as many denoise steps as fit
-    ~12 s, at most 49).  A reported baseline, never the thing measured above."""
+def cpu_baseline(budget_s=14.0):
+    """BASELINE configs[0] (C1) on the host: the oracle (CPU restatement: torch.fft filters, F.conv2d, SDPA, eager
+    PyTorch fp32) at batch 1 over the 50-step DDIM schedule, on the host cores - a bounded sample: as many of the
+    50 steps as fit `budget_s` - plus a short single-thread sample.  A reported baseline, never the thing measured."""
     from oracle import configs as oc, pipeline as op, unet as ou
-    # eager ops at this size do not scale past a few tens of threads (256 threads measured 100x SLOWER
-    # than 8 on the MI355X host: oversubscribed OpenMP barriers), so the thread count is capped.
-    cores = min(os.cpu_count() or 1, 16)
+    # eager ops at this size do not scale past a few tens of threads (256 threads measured 100x SLOWER than 8 on the
+    # MI355X host: oversubscribed OpenMP barriers), so "all cores" is capped at 32.
+    cores = min(os.cpu_count() or 1, 32)
     sd = ou.init_unet_params(oc.FFHQ_UNET, seed=0, conv_out_scale=0.1)
-    sec, steps = op.time_denoise_steps(sd, oc.FFHQ_UNET, batch=batch, steps=49, threads=cores, budget_s=budget_s)
-    return dict(value=round(batch / sec, 4), unit="denoise-steps/s", cores=cores, kind="port",
+    sec, steps = op.time_denoise_steps(sd, oc.FFHQ_UNET, batch=1, steps=49, threads=cores, budget_s=budget_s)
+    sec1, steps1 = op.time_denoise_steps(sd, oc.FFHQ_UNET, batch=1, steps=6, threads=1, budget_s=6.0)
+    torch.set_num_threads(cores)
+    return dict(value=round(1.0 / sec, 4), unit="denoise-steps/s", cores=cores, kind="port",
                 ms_per_step=round(sec * 1e3, 2),
-                sample=f"oracle CPU restatement, FFHQ AF-UNet + DDIM update, batch {batch} fp32, {steps} steps "
-                       f"({sec * steps:.1f} s) after 1 warm-up step")
+                single_thread=dict(value=round(1.0 / sec1, 4), ms_per_step=round(sec1 * 1e3, 2), steps=steps1),
+                sample=f"BASELINE configs[0]: oracle CPU restatement, FFHQ AF-UNet + DDIM update, batch 1 fp32, {steps} of the "
+                       f"50 DDIM steps ({sec * steps:.1f} s) on {cores} threads after 1 warm-up step; single-thread: {steps1} steps")
+
+
+def timed_regions(run_steps, k, regions, world, dev):
+    """`regions` timed regions of exactly k steps each, every one bracketed by barrier + synchronize on both sides,
+    MAX over ranks per region; returns the per-region seconds."""
+    from afldm_amd import parallel
+    out = []
+    for _ in range(regions):
+        torch.cuda.synchronize()
+        parallel.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(k)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tt.item())
+        out.append(dt)
+    return out
+
+
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def side_config(batch, dtype, steps=20, regions=3):
+    """north_star's other single-GPU configurations (batch 1 / 8 bf16, fp32 = the reference's precision), timed the
+    same way inside this run (graph replay, median of `regions` regions of `steps` steps)."""
+    from afldm_amd.engine import DenoiseEngine
+    from afldm_amd.schedulers.ddim import ffhq_ddim_scheduler
+    unet = build_unet(dtype, torch.device("cuda", torch.cuda.current_device()))
+    eng = DenoiseEngine(unet, ffhq_ddim_scheduler(), batch, 50, use_graph=True)
+    noise = torch.randn(batch, 4, 32, 32, generator=torch.Generator().manual_seed(1234))
+    eng.reset(noise)
+    eng.step(6)
+    ts = []
+    for _ in range(regions):
+        eng.reset(noise)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.step(steps)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    dt = median(ts)
+    finite = bool(torch.isfinite(eng.lat).all().item())
+    del eng, unet
+    torch.cuda.empty_cache()
+    return dict(batch=batch, dtype="bf16" if dtype == torch.bfloat16 else "fp32", steps=steps, regions=regions,
+                ms_per_step=round(1e3 * dt / steps, 4), value=round(batch * steps / dt, 2), unit="denoise-steps/s",
+                latents_finite=finite)
+
+
+def build_vae(dtype, device):
+    """The reference's AF-VAE (configs/vae/model_afvae.json: [128, 256, 512, 512], 2 layers per block, 83.65 M
+    parameters) with seeded PyTorch default-init weights."""
+    from afldm_amd.af_modules.af_api import make_af_vae_from_config
+    from afldm_amd.models.vae import AutoencoderKL
+    torch.manual_seed(3)
+    vae = AutoencoderKL(in_channels=3, out_channels=3, down_block_types=["DownEncoderBlock2D"] * 4,
+                        up_block_types=["UpDecoderBlock2D"] * 4, block_out_channels=[128, 256, 512, 512],
+                        layers_per_block=2, latent_channels=4, norm_num_groups=32, scaling_factor=0.6, mid_act=True,
+                        down_filtered_act=[False, True, True, True], up_filtered_act=[True, True, True, False],
+                        up_rescale=[True, True, True])
+    make_af_vae_from_config(vae)
+    return vae.to(device).to(dtype)
+
+
+def vae_workload(batch=128, dtype=torch.bfloat16, passes=3):
+    """BASELINE configs[3] (C4): alias-free AutoencoderKL encode + decode of `batch` 256x256 images on one GPU, with
+    the fractional-shift equivariance check of SURVEY.md 8d (mask_psnr of decode(T z) against T(decode z), tj = 1/8
+    and 1/2 latent pixels).  Images resident in HBM; median of `passes` encode+decode passes."""
+    from afldm_amd.shift_utils.metrics import mask_psnr
+    from afldm_amd.shift_utils.shifters import ImageShifter
+    dev = torch.device("cuda", torch.cuda.current_device())
+    vae = build_vae(dtype, dev)
+    imgs = (torch.rand(batch, 3, 256, 256, generator=torch.Generator().manual_seed(7)) * 2 - 1).to(dev)
+    z = vae.encode(imgs).latent_dist.mode()
+    vae.decode(z, return_dict=False)
+    enc, dec = [], []
+    for _ in range(passes):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        z = vae.encode(imgs).latent_dist.mode()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        img = vae.decode(z, return_dict=False)[0]
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        enc.append(t1 - t0)
+        dec.append(t2 - t1)
+    te, td = median(enc), median(dec)
+    eq = {}
+    zr = torch.randn(8, 4, 32, 32, generator=torch.Generator().manual_seed(8)).to(dev).to(dtype)
+    base = vae.decode(zr, return_dict=False)[0].float()
+    for tj in (0.125, 0.5):
+        zs, _ = ImageShifter("ideal", 8).shift(zr.float(), 0, tj)
+        got = vae.decode(zs.to(dtype), return_dict=False)[0].float()
+        gt, m = ImageShifter().shift(base, 0, tj * 8)
+        mask = m.clone().expand_as(base).contiguous()
+        mask[..., :32] = 0
+        mask[..., -32:] = 0
+        eq[f"mask_psnr_db_tj_{tj}"] = round(float(mask_psnr(got, gt, mask)), 2)
+    finite = bool(torch.isfinite(img.float()).all().item())
+    del vae
+    torch.cuda.empty_cache()
+    return dict(workload="AF-VAE encode + decode 256x256 (BASELINE configs[3])", batch=batch,
+                dtype="bf16" if dtype == torch.bfloat16 else "fp32",
+                encode_ms=round(te * 1e3, 2), decode_ms=round(td * 1e3, 2),
+                value=round(batch / (te + td), 2), unit="images/s (encode+decode)",
+                encode_images_per_s=round(batch / te, 1), decode_images_per_s=round(batch / td, 1),
+                equivariance=eq, outputs_finite=finite)
 
 
 def main():
@@ -113,9 +249,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--regions", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--workload", default="unet", choices=["unet", "vae"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the batch 1 / 8 / fp32 / AF-VAE side measurements")
     args = ap.parse_args()
 
     from afldm_amd import parallel
@@ -129,45 +268,45 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    if args.workload == "vae":
+        r = vae_workload(batch=args.batch if args.batch != 64 else 128, dtype=dtype)
+        if rank == 0:
+            print(json.dumps({"metric": "AF-VAE encode+decode images/sec, 256x256, batch 128 (BASELINE configs[3])",
+                              "value": r["value"], "unit": "images/s", "n_gpus": 1, "higher_is_better": True,
+                              "dtype": args.dtype, "data": "synthetic (seeded random AF-VAE weights, uniform images)",
+                              "config": r}), flush=True)
+        return
+
     B = args.batch
     total = B * world
-
     unet = build_unet(dtype, dev)
     eng = DenoiseEngine(unet, ffhq_ddim_scheduler(), B, 50, use_graph=not args.no_graph)
     s, e = parallel.shard_range(total, rank, world)
     noise = parallel.global_noise(total, (4, 32, 32), 1234)[s:e].to(dev)     # resident before timing
     final = torch.empty((total, 4, 32, 32), dtype=torch.float32, device=dev) if world > 1 else None
+    pos = [0]
 
-    def run_steps(k):
+    def run_steps(k, gather=True):
         done = 0
         while done < k:
-            pos = int(done % 50)
-            if pos == 0:
+            if pos[0] == 0:
                 eng.reset(noise)                  # device->device copy of 1 MiB + counter reset
-            n = min(50 - pos, k - done)
+            n = min(50 - pos[0], k - done)
             eng.step(n)
             done += n
+            pos[0] = (pos[0] + n) % 50
+        if world > 1 and gather:
+            torch.distributed.all_gather_into_tensor(final, eng.lat)        # the ONE collective of the sampler
 
-    run_steps(args.warmup if args.warmup > 0 else 1)       # includes graph capture
+    run_steps(args.warmup if args.warmup > 0 else 1, gather=False)       # includes graph capture
     if world > 1:
         # RCCL builds its communicator rings / channels lazily on the first collective of a kind:
         # that one-off set-up belongs to the warm-up, not to the timed steps
         torch.distributed.all_gather_into_tensor(final, eng.lat)
-    torch.cuda.synchronize()
-    parallel.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    if world > 1:
-        torch.distributed.all_gather_into_tensor(final, eng.lat)        # the ONE collective of the sampler
-    torch.cuda.synchronize()
-    parallel.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+    pos[0] = 0
+    regions = timed_regions(run_steps, args.steps, max(1, args.regions), world, dev)
+    dt = median(regions)
     finite = bool(torch.isfinite(eng.lat).all().item())
 
     if rank == 0:
@@ -185,13 +324,24 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic (seeded random FFHQ AF-UNet weights, CPU-seeded noise)",
             "config": {"workload": "FFHQ-256 AF-UNet single denoise step, batch 64 per GPU (BASELINE configs[1])",
-                       "batch_per_gpu": B, "global_batch": total, "sharding": "batch, one all-gather of final latents",
-                       "hip_graph": not args.no_graph, "latents_finite": finite},
+                       "batch_per_gpu": B, "global_batch": total, "sharding": "batch, one all-gather of final latents per region",
+                       "hip_graph": not args.no_graph, "latents_finite": finite,
+                       "timing": f"median of {len(regions)} timed regions of {args.steps} steps, each bracketed by barrier + "
+                                 "synchronize, MAX over ranks",
+                       "regions_ms_per_step": [round(1e3 * r / args.steps, 4) for r in regions]},
         }
         if not args.no_roofline:
             roof, fam = roofline_pass(unet, B, dtype)
             out["roofline"] = roof
             out["kernel_families"] = fam
+        del eng
+        if world == 1 and not args.no_extras:
+            # north_star: "batch 1/8/64 on 1 GPU" + the reference's precision, and configs[3], driver-timed in this run
+            del unet
+            torch.cuda.empty_cache()
+            out["other_configs"] = [side_config(1, torch.bfloat16), side_config(8, torch.bfloat16),
+                                    side_config(64, torch.float32, steps=10), side_config(1, torch.float32)]
+            out["vae_c4"] = vae_workload()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

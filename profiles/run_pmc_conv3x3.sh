@@ -21,18 +21,20 @@ for name in ("fetch", "write"):
     s, k = 0.0, 0
     for r in csv.DictReader(open(f)):
         kn = r["Kernel_Name"]
-        if ("k_igemm" in kn or "k_splitk" in kn or "k_conv_" in kn) and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+        if ("k_igemm" in kn or "k_splitk" in kn or "k_conv_" in kn or "k_conv3h" in kn) and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             s += float(r["Counter_Value"]); k += 1
     tot[name], n[name] = s, k
 reps = 3
 launches = rec["launches"]
 fetch_b = 2.0 * tot["fetch"] * 1024 / reps
 write_b = tot["write"] * 1024 / reps
-res = dict(tag=tag, family="conv3x3", launches_per_step=launches, kernel_dispatches_counted=n["fetch"] // reps,
+import hashlib
+sha = hashlib.sha256(open("afldm_amd/lib/libafldm_hip.so", "rb").read()).hexdigest()
+res = dict(tag=tag, family="conv3x3", lib_sha256=sha, launches_per_step=launches, kernel_dispatches_counted=n["fetch"] // reps,
            fetch_bytes_per_step=fetch_b, write_bytes_per_step=write_b,
            hbm_bytes_per_launch=(fetch_b + write_b) / launches,
            algorithmic_bytes_per_launch=rec["algorithmic_bytes_per_step"] / launches,
-           note="bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes, 3 replays of the 64 conv3x3 launches of one step averaged")
+           note="bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes, 3 replays of the conv3x3 launches of one step averaged; lib_sha256 = the library measured (bench.py refuses another build)")
 print(json.dumps(res))
 open("gpurun_out/conv3x3_traffic_%s.json" % tag, "w").write(json.dumps(res, indent=1) + "\n")
 PY
