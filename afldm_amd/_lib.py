@@ -23,7 +23,7 @@ class ConvArgs(Structure):
         ("C1", c_int), ("C2", c_int), ("B", c_int), ("H", c_int), ("W", c_int), ("Cout", c_int),
         ("KS", c_int), ("temb_stride", c_int), ("res_ld", c_int), ("y_ld", c_int),
         ("out_mode", c_int), ("dtype", c_int), ("y2", c_void_p), ("split_n", c_int),
-        ("stats_out", c_void_p), ("temb_mod", c_int),
+        ("stats_out", c_void_p), ("temb_mod", c_int), ("sync", c_void_p), ("sync_bytes", c_size_t),
     ]
 
 
@@ -78,6 +78,7 @@ def _load():
         "afldm_conv2d_workspace": ([POINTER(ConvArgs)], c_size_t),
         "afldm_conv2d_stats_splits": ([POINTER(ConvArgs)], c_int),
         "afldm_conv2d_tune": ([ip, ip], c_int),
+        "afldm_conv2d_fused_splitk": ([ip], c_int),
         "afldm_attention": ([vp, ip, vp, ip, vp, vp, ip, ip, ip, ip, ip, ip, ip, fp, ip, vp], c_int),
         "afldm_ddim_step": ([vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, vp], c_int),
         "afldm_ddim_step_flat": ([vp, vp, vp, fp, fp, fp, fp, c_size_t, vp], c_int),

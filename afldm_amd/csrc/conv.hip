@@ -232,6 +232,126 @@ __global__ void __launch_bounds__(WGM* WGN * 64) k_igemm(ConvP p) {
   }
 }
 
+// ----------------------------------------------------------------------------- in-kernel split-K reduction
+// The K slices of one output tile used to meet in a second launch (k_splitk_reduce*): a kernel boundary plus a
+// full re-read of every slab by a grid that starts cold.  Here the `splitk` workgroups of a tile reduce it
+// themselves, reduce-scatter style: each writes its fp32 slab WRITE-THROUGH (sc1 stores: no release fence, the
+// per-XCD L2s are not coherent), drains, arrives on the tile's counter, waits (one lane, relaxed sc1 poll) until all
+// `splitk` slices have arrived, takes ONE agent-scope acquire, and then finishes rows [ks, ks + 1) * BM / splitk of
+// the tile: slabs added in slice order with sc1 loads, ((sum + bias) + temb) + residual, one rounding, store,
+// per-channel GroupNorm partial sums - the same arithmetic, in the same order, as k_splitk_reduce_stats, so the two
+// paths are bit-identical.  The last workgroup to leave zeroes the tile's two words again (they are zero between
+// launches; a graph replay needs no memset node).  Recipe: cdna_hip_programming.md section 5 item 2 / Guideline 16
+// (counter form).  The host only enables it when tiles * splitk <= the CU count: every workgroup of the launch is
+// resident, so the wait cannot deadlock; the spin is bounded all the same.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+template <typename T, int BM, int BN, int NTC>
+__device__ __forceinline__ void splitk_fused_reduce(const ConvP& p, int m0, int n0, int ks, int tile, int etid, float* sR) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave: its write-through slab stores have left
+  __syncthreads();
+  unsigned* cnt = p.sync + 2 * tile;
+  unsigned* flag = reinterpret_cast<unsigned*>(sR);
+  if (etid == 0) {
+    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0, ok = 1;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.splitk) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1u << 22)) {      // ~1 s: a slice that never arrives must not hang the device
+        ok = 0;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    flag[0] = ok;
+  }
+  __syncthreads();
+  const unsigned ok = flag[0];
+  __syncthreads();                                      // flag read by everyone before sR is reused
+  if (!ok) {
+    if (etid == 0) __hip_atomic_store(p.sync + 2 * 4096, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // error word
+    return;
+  }
+  constexpr int QPR = BN / 4;                           // fp32 quads per tile row
+  constexpr int RL = NTC / QPR;                         // row lanes
+  const int q = etid % QPR, tr = etid / QPR;
+  const bool act = etid < RL * QPR && n0 + 4 * q < p.Cout;
+  const int n = n0 + 4 * q;
+  const int HW = p.H * p.W;
+  const int RW = BM / p.splitk;                         // rows this slice finishes
+  const int r0 = ks * RW;
+  const int seg = RW < HW ? RW : HW;                    // rows of one statistics segment (inside one sample)
+  const T* temb = (const T*)p.temb;
+  const T* res = (const T*)p.residual;
+  __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc((void*)p.ws, 0, (int)((long long)p.splitk * p.M * p.Cout * 4), 0x00020000);
+  f32x4 bt = {0.f, 0.f, 0.f, 0.f};
+  if (act && p.bias) bt = *reinterpret_cast<const f32x4*>(p.bias + n);
+  for (int s0 = 0; s0 < RW; s0 += seg) {
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (act) {
+      for (int row = s0 + tr; row < s0 + seg; row += RL) {
+        const int m = m0 + r0 + row;
+        if (m >= p.M) break;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int sl = 0; sl < p.splitk; ++sl) {
+          const unsigned off = (unsigned)((((size_t)sl * p.M + m) * p.Cout + n) * 4);
+          v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, (int)off, 0, 16));
+        }
+        if (p.bias) v += bt;
+        if (temb) {
+          float t0, t1, t2, t3;
+          load4<T>(temb + (size_t)(m / HW) * p.temb_stride + n % p.temb_mod, t0, t1, t2, t3);
+          v[0] += t0; v[1] += t1; v[2] += t2; v[3] += t3;
+        }
+        if (res) {
+          float a0, a1, a2, a3;
+          load4<T>(res + (size_t)m * p.res_ld + n, a0, a1, a2, a3);
+          v[0] += a0; v[1] += a1; v[2] += a2; v[3] += a3;
+        }
+        float vr[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vr[e] = to_f32(from_f32<T>(v[e]));            // statistics of what the consumer will read
+          s1[e] += vr[e];
+          s2[e] = fmaf(vr[e], vr[e], s2[e]);
+        }
+        store4<T>((T*)p.y + (size_t)m * p.y_ld + n, vr[0], vr[1], vr[2], vr[3]);
+      }
+    }
+    if (p.stats_out) {
+      // the RL row lanes of a column quad are added in a fixed order through LDS
+      if (etid < RL * QPR) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x2*>(sR + ((tr * QPR + q) * 4 + e) * 2) = f32x2{s1[e], s2[e]};
+      }
+      __syncthreads();
+      const int mseg = m0 + r0 + s0;
+      if (tr == 0 && act && mseg < p.M) {
+        const int b = mseg / HW, sp = (mseg - b * HW) / seg;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a1 = 0.f, a2 = 0.f;
+          for (int r = 0; r < RL; ++r) {
+            const f32x2 t = *reinterpret_cast<const f32x2*>(sR + ((r * QPR + q) * 4 + e) * 2);
+            a1 += t[0];
+            a2 += t[1];
+          }
+          *reinterpret_cast<f32x2*>(p.stats_out + (((size_t)b * p.stats_S + sp) * p.Cout + n + e) * 2) = f32x2{a1, a2};
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // leave: the last of the tile's workgroups re-zeroes its words (every slice has passed its poll by then)
+  if (etid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (unsigned)p.splitk - 1) {
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------- v2: LDS-DMA pipeline
 // Same tiling / LDS image / epilogue as k_igemm, but the operands go HBM -> LDS directly
 // (buffer_load_dwordx4 ... lds: no staging VGPRs, no ds_write pass) through a STAGES-deep ring
@@ -608,7 +728,10 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
           if (m >= p.M || n >= p.Cout) continue;
           const f32x4 a = *reinterpret_cast<const f32x4*>(sC + row * SROW + 4 * q);
           float* dst = p.ws + ((size_t)ks * p.M + m) * p.Cout + n;
-          if (v4 && n + 3 < p.Cout) *reinterpret_cast<f32x4*>(dst) = a;
+          if (p.sync) {     // in-kernel reduction: write-through (sc1) so that the other slices' workgroups can read it
+            __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc((void*)p.ws, 0, (int)((long long)p.splitk * p.M * p.Cout * 4), 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), rws, (int)((((size_t)ks * p.M + m) * p.Cout + n) * 4), 0, 16);
+          } else if (v4 && n + 3 < p.Cout) *reinterpret_cast<f32x4*>(dst) = a;
           else
             for (int r = 0; r < 4 && n + r < p.Cout; ++r) dst[r] = a[r];
         }
@@ -740,6 +863,10 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
           }
         }
       }
+    }
+    if (p.splitk > 1) {
+      if (p.sync) splitk_fused_reduce<T, BM, BN, NTC>(p, m0, n0, ks, tile, etid, sC);
+      return;
     }
     if (p.stats_out) {
       // per-channel sums of this tile (BM rows of ONE sample: the host only asks when H*W % BM == 0):
@@ -1381,7 +1508,7 @@ __global__ void __launch_bounds__(256) k_conv_small_cout(ConvP p) {
 
 // ----------------------------------------------------------------------------- host dispatch
 // tuning overrides (afldm_conv2d_tune): -1 = automatic
-static int g_force_variant = -1, g_force_splitk = -1;
+static int g_force_variant = -1, g_force_splitk = -1, g_fused_splitk = 0;
 
 struct Plan {
   int kind;  // 0 igemm, 1 small_cin, 2 small_cout
@@ -1657,7 +1784,19 @@ struct Exec {
   Plan pl;
   int vid;       // igemm variant actually launched
   int splitk;    // after the workspace check
+  int fused;     // split-K slices reduced inside the GEMM launch (splitk_fused_reduce)
 };
+
+static int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
+    else cus = -1;
+  }
+  return cus;
+}
 template <typename T>
 static Exec resolve_exec(const afldm_conv_args* a) {
   Exec e;
@@ -1699,6 +1838,28 @@ static Exec resolve_exec(const afldm_conv_args* a) {
     }
   }
   if (kVariants[e.vid].ver >= 2 && kVariants[e.vid].ver != 6 && !v2_ok) e.vid = kVariants[e.vid].bm == 128 ? (kVariants[e.vid].bn >= 128 ? 0 : 1) : 3;
+  e.fused = 0;
+  {
+    // in-kernel split-K reduction: every workgroup of the launch must be resident (tiles * splitk <= CUs), the slice
+    // count must divide the tile's rows, and a slice's row range must be whole statistics segments
+    // OFF by default: measured in the step it LOSES to the two-launch form (batch 64: 6.10 vs 5.54 ms/step, batch 8:
+    // 3.26 vs 2.95, batch 1: 2.66 vs 2.55 - profiles/r02/fused_splitk_ab.txt): the 256 workgroups of the launch read
+    // their 98 KB of slabs with far less memory-level parallelism than the 1536-workgroup reduction kernel, the
+    // write-through stores are slower than plain ones, and every slice waits for the slowest.  The guide's verdict
+    // for this seam (cut it) holds here; afldm_conv2d_fused_splitk(1) / AFLDM_FUSED_SPLITK=1 re-enable it.
+    static const bool env_on = getenv("AFLDM_FUSED_SPLITK") && atoi(getenv("AFLDM_FUSED_SPLITK")) != 0;
+    const Variant& v = kVariants[e.vid];
+    const int HW = a->H * a->W, z = e.splitk;
+    if ((env_on || g_fused_splitk) && z > 1 && v.ver >= 2 && v.ver <= 4 && a->sync && a->sync_bytes >= 40960 && (z == 2 || z == 4 || z == 8) &&
+        v.bm % z == 0 && a->out_mode == 0 && !a->y2 && a->Cout % 4 == 0 && a->y_ld % 4 == 0 &&
+        (!a->residual || a->res_ld % 4 == 0) && (!a->temb || a->temb_stride % 4 == 0) &&
+        (size_t)z * M * a->Cout * 4 < ((size_t)1 << 31)) {
+      const int rw = v.bm / z;
+      const long long tiles = ((M + v.bm - 1) / v.bm) * ((a->Cout + v.bn - 1) / v.bn);
+      const bool seg_ok = rw >= HW ? (rw % HW == 0) : (HW % rw == 0 && (HW % v.bm == 0 || v.bm % HW == 0));
+      if (seg_ok && tiles <= 4096 && tiles * z <= device_cus()) e.fused = 1;
+    }
+  }
   return e;
 }
 
@@ -1716,7 +1877,7 @@ static bool cin4_mfma_ok(const afldm_conv_args* a) {
 }
 
 // Where the GroupNorm partial sums of the output come from, and their split count S.
-enum { ST_EPILOGUE = 1, ST_REDUCE = 2, ST_STANDALONE = 3 };
+enum { ST_EPILOGUE = 1, ST_REDUCE = 2, ST_STANDALONE = 3, ST_FUSED = 4 };
 static int reduce_stats_splits(int HW) { return HW >= 64 ? (HW / 16 > 32 ? 32 : HW / 16) : 1; }
 template <typename T>
 static int stats_mode(const afldm_conv_args* a, const Exec& e, int* S) {
@@ -1725,6 +1886,11 @@ static int stats_mode(const afldm_conv_args* a, const Exec& e, int* S) {
                     a->Cout % 4 == 0;
   const bool vec16 = a->y_ld % eo == 0 && (!a->residual || a->res_ld % eo == 0) && (!a->temb || a->temb_stride % eo == 0) &&
                      a->Cout % eo == 0;
+  if (e.pl.kind == 0 && e.splitk > 1 && e.fused) {
+    const int rw = kVariants[e.vid].bm / e.splitk;
+    *S = rw >= HW ? 1 : HW / rw;
+    return ST_FUSED;
+  }
   if (e.pl.kind == 0 && e.splitk > 1 && vec4) {
     *S = reduce_stats_splits(HW);
     return ST_REDUCE;
@@ -1765,7 +1931,7 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
   p.temb_stride = a->temb_stride; p.res_ld = a->res_ld; p.y_ld = a->y_ld; p.out_mode = a->out_mode;
   p.temb_mod = a->temb_mod > 0 ? a->temb_mod : a->Cout;
   p.M = a->B * a->H * a->W;
-  p.splitk = 1; p.tiles_n = 1; p.ksteps = 0;
+  p.splitk = 1; p.tiles_n = 1; p.ksteps = 0; p.sync = nullptr;
   static const int s_dbg = getenv("AFLDM_CONV_DBG") ? atoi(getenv("AFLDM_CONV_DBG")) : 0;
   p.dbg = s_dbg;
   static const int s_tapin = getenv("AFLDM_CONV_TAPINNER") ? atoi(getenv("AFLDM_CONV_TAPINNER")) : 0;
@@ -1834,10 +2000,12 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
       p.stats_out = a->stats_out;
       p.stats_multi = (a->H * a->W) < kVariants[ex.vid].bm ? 1 : 0;
     }
+    p.sync = ex.fused ? a->sync : nullptr;
+    if (ex.fused && smode == ST_FUSED) p.stats_out = a->stats_out;
     launch_variant<T>(ex.vid, p, st);
     rc = check_launch("afldm_conv2d(igemm)");
     if (rc) return rc;
-    if (p.splitk > 1) {
+    if (p.splitk > 1 && !ex.fused) {
       if (smode == ST_REDUCE) {
         p.stats_out = a->stats_out;
         const int HW = a->H * a->W;
@@ -1896,6 +2064,11 @@ extern "C" int afldm_conv2d_tune(int variant, int splitk) {
   AFLDM_REQUIRE(variant < kNumVariants, AFLDM_ESHAPE, "afldm_conv2d_tune: variant %d out of range (%d)", variant, kNumVariants);
   g_force_variant = variant;
   g_force_splitk = splitk;
+  return AFLDM_OK;
+}
+
+extern "C" int afldm_conv2d_fused_splitk(int enable) {
+  g_fused_splitk = enable ? 1 : 0;
   return AFLDM_OK;
 }
 

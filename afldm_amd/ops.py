@@ -516,6 +516,18 @@ def upfirdn2d(x, f, upx=1, upy=1, downx=1, downy=1, padx0=0, padx1=0, pady0=0, p
 
 
 # ----------------------------------------------------------------------------- conv / linear
+_SYNC = {}
+
+
+def _sync_words(device):
+    """Zero-initialised counter words for the in-kernel split-K reduction (afldm_conv_args.sync): one buffer per
+    device, shared by every launch in stream order - each launch leaves it zero."""
+    key = str(device)
+    if key not in _SYNC:
+        _SYNC[key] = torch.zeros(16384, dtype=torch.int32, device=device)
+    return _SYNC[key]
+
+
 def conv_args(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, out=None, out_mode=0,
               workspace=None, y_ld=None, out2=None, split_n=0, temb_mod=0):
     """Build the afldm_conv_args struct (keeps references to the tensors alive in `.keep`)."""
@@ -542,7 +554,9 @@ def conv_args(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None
     a.temb_mod = int(temb_mod)
     if out2 is not None and y_ld is None:
         a.y_ld = int(split_n)
-    a.keep = (x1, x2, w, bias, temb, residual, out, workspace)
+    sync = _sync_words(x1.device)
+    a.sync, a.sync_bytes = ptr(sync), sync.numel() * 4
+    a.keep = (x1, x2, w, bias, temb, residual, out, workspace, sync)
     return a
 
 

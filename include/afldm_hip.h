@@ -220,11 +220,21 @@ typedef struct {
    * convolution on a 2x2 plane executed as ONE dense layer over the flattened plane: cout index =
    * pixel * C + c, every pixel takes the same per-channel time embedding; must divide Cout). */
   int temb_mod;
+  /* optional: `sync_bytes` >= 40960 bytes of device memory that is ZERO before the first call and is left zero by
+   * every call (one buffer serves all launches of a stream).  With it - and afldm_conv2d_fused_splitk(1) - a split-K
+   * convolution whose workgroups all fit on the chip at once reduces its K slices inside the GEMM launch (arrival counter per output tile, slabs
+   * written through, each slice finishing 1/splitk of the tile's rows) instead of in a second kernel; results are
+   * bit-identical.  NULL = always the two-launch form. */
+  unsigned int* sync;
+  size_t sync_bytes;
 } afldm_conv_args;
 int afldm_conv2d(const afldm_conv_args* args, afldm_stream_t stream);
 /* Tuning hook (benchmarks only): force tile/pipeline variant `variant` (>= 0) and/or a split-K
  * factor (>= 1) for subsequent afldm_conv2d calls; -1 restores the automatic choice. */
 int afldm_conv2d_tune(int variant, int splitk);
+/* Enable (1) / disable (0, the default) the in-kernel split-K reduction for calls that pass `sync` words: measured
+ * slower than the two-launch form on MI355X, kept as a tested option. */
+int afldm_conv2d_fused_splitk(int enable);
 /* bytes of split-K workspace afldm_conv2d may use for this problem (0 if none). */
 size_t afldm_conv2d_workspace(const afldm_conv_args* args);
 /* split count S of the statistics afldm_conv2d writes to stats_out for this problem (> 0). */

@@ -344,6 +344,70 @@ def test_conv2d_persistent_tile_variant_bit_identical(case):
     assert torch.equal(outs[40][0][1], outs[40][1][1])
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, KS, temb, residual
+    (64, 4, 4, 768, 768, 3, True, True),      # 128x192 tiles, 8 slices of one 4x4 sample each
+    (64, 8, 8, 384, 384, 3, True, False),     # 128x192 tiles, 4 slices = half a sample each
+    (64, 1, 1, 3072, 3072, 1, False, True),   # the dense form of a 3x3 convolution on a 2x2 plane: 64x64 tiles
+    (8, 8, 8, 768, 384, 3, False, True),      # batch-8 shapes
+    (8, 16, 16, 384, 384, 3, True, True),
+    (3, 4, 4, 768, 768, 3, True, True),       # M = 48: ragged last tile
+    (1, 16, 16, 384, 384, 3, True, True),     # batch 1
+    (1, 32, 32, 192, 192, 3, True, True),
+])
+def test_conv2d_split_k_reduced_inside_the_launch(dtype, case):
+    """afldm_conv_args.sync: the K slices of a tile are reduced by the GEMM launch itself (arrival counter, slabs
+    written through, reduce-scatter over the slices) instead of by k_splitk_reduce*.  Same arithmetic in the same
+    order: outputs bit-identical to the two-launch form, statistics equal after folding the splits, 30 repeats
+    identical (the hand-off must not depend on timing), and the counter words are zero again afterwards."""
+    import ctypes
+    from afldm_amd import _lib
+    ops = _ops()
+    B, H, W, Cin, Cout, KS, use_temb, use_res = case
+    g = torch.Generator().manual_seed(B * 7 + Cout)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dtype).cuda()
+    w = (torch.randn(Cout, KS, KS, Cin, generator=g) / (KS * Cin ** 0.5)).to(dtype).cuda()
+    bias = torch.randn(Cout, generator=g).cuda()
+    temb = torch.randn(B, Cout, generator=g).to(dtype).cuda() if use_temb else None
+    res = torch.randn(B, H, W, Cout, generator=g).to(dtype).cuda() if use_res else None
+
+    def run(fused):
+        y = torch.empty(B, H, W, Cout, dtype=dtype, device="cuda")
+        a = ops.conv_args(x, w, bias, temb=temb, temb_stride=Cout if use_temb else 0, residual=res, out=y)
+        if not fused:
+            a.sync, a.sync_bytes = None, 0
+        need = _lib.lib.afldm_conv2d_workspace(ctypes.byref(a))
+        ws = torch.empty(max(need, 4) // 4, dtype=torch.float32, device="cuda")
+        a.workspace, a.workspace_bytes = _lib.ptr(ws), need
+        S = _lib.lib.afldm_conv2d_stats_splits(ctypes.byref(a))
+        st = torch.zeros(B, S, Cout, 2, dtype=torch.float32, device="cuda")
+        a.stats_out = _lib.ptr(st)
+        ops.conv2d_launch(a)
+        return y, st, need
+
+    y0, st0, need = run(False)
+    if need == 0:
+        pytest.skip("the planner does not split K for this shape")
+    _lib.check(_lib.lib.afldm_conv2d_fused_splitk(1), "fused_splitk")
+    try:
+        ys = [run(True) for _ in range(30)]
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib.afldm_conv2d_fused_splitk(0)
+    for y1, st1, _ in ys:
+        assert torch.equal(y0, y1)
+        torch.testing.assert_close(st1.sum(1), st0.sum(1), rtol=1e-5, atol=1e-3)
+        assert torch.equal(st1, ys[0][1])
+    assert int(ops._sync_words(x.device).abs().sum()) == 0
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2).cpu(), w.float().permute(0, 3, 1, 2).cpu(), bias.cpu(), padding=KS // 2)
+    if use_temb:
+        ref = ref + temb.float().cpu()[:, :, None, None]
+    if use_res:
+        ref = ref + res.float().permute(0, 3, 1, 2).cpu()
+    close(back(ys[0][0]), ref, dtype, f"fused split-K {case}", bf16_rms=6e-3)
+
+
 H3_CASES = [
     # B, N (plane), Cin, Cout, temb, residual, variants (conv3h.hip ids)
     (2, 32, 192, 192, True, False, (41, 45, 46)),
