@@ -1571,6 +1571,10 @@ static const Variant kVariants[] = {
     {256, 192, 6, 3},  // 44  16x16 planes, one whole sample per tile
     {128, 192, 6, 3},  // 45  32x32 planes, 4 rows per tile, 8 + 4 waves
     {128, 192, 6, 3},  // 46  32x32 planes, 4 rows per tile, 4 + 4 waves
+    {256, 192, 6, 3},  // 47  = 41 on 32x32x16 MFMAs
+    {128, 192, 6, 3},  // 48  = 43 on 32x32x16 MFMAs
+    {256, 192, 6, 3},  // 49  = 44 on 32x32x16 MFMAs
+    {128, 192, 6, 3},  // 50  = 46 on 32x32x16 MFMAs
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -1634,10 +1638,10 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
   pl.splitk_auto = splitk_for(vid);
   // halo-patch kernel for the 3x3 convolutions of the 32x32 / 16x16 levels (conv3h.hip); support is checked by resolve_exec
   {
-    static const int s_h3 = getenv("AFLDM_CONV3H") ? atoi(getenv("AFLDM_CONV3H")) : 1;      // 0: off, 2: variant 43 at 16x16
+    static const int s_h3 = getenv("AFLDM_CONV3H") ? atoi(getenv("AFLDM_CONV3H")) : 1;      // 0: off, 2: variant 42 at 16x16
     if (s_h3 && a->KS == 3 && a->C2 == 0 && a->H == a->W && a->Cout % 192 == 0) {
       if (a->W == 32 && M >= 32768) vid = 41;
-      else if (a->W == 16 && M >= 8192) vid = s_h3 == 2 ? 43 : 42;
+      else if (a->W == 16 && M >= 8192) vid = s_h3 == 2 ? 42 : 43;      // 4 consumer waves (64x96) measured best at 16x16
     }
   }
   // in-situ tuning hook (tools/tune_insitu.py): AFLDM_CONV_OVERRIDE="M:Cout:KS:Ct=variant/splitk;..."

@@ -21,8 +21,10 @@
 // A ds_read_b128 is served in 16-lane groups made of 8 rows of lane group lg and 8 rows of lg ^ 1: bit 2 of the
 // position separates the two halves, and 4 rows of equal parity inside ANY run of 16 consecutive rows differ in
 // (q >> 1) & 3 - so the fragment reads are bank-conflict free for every tap shift of the patch (the swizzle of
-// k_igemm2, (q >> 1) & 7 on all three bits, is only conflict free for 16-aligned runs).  An LDS-DMA writes
-// lane-linearly, so the permutation is applied to the per-lane SOURCE chunk (guide rule 21).
+// k_igemm2, (q >> 1) & 7 on all three bits, is only conflict free for 16-aligned runs).  With 32x32x16 MFMAs a 16-lane
+// read group lies inside one 32-row fragment half (rows {0-3, 12-15, 20-27} + base, one chunk): there the plain
+// position c ^ ((q >> 1) & 7) is conflict free for every shift.  An LDS-DMA writes lane-linearly, so the permutation
+// is applied to the per-lane SOURCE chunk (guide rule 21).
 //
 // The accumulators start from the residual (loaded in fragment layout under the pipeline prologue).  Epilogue: the
 // fp32 tile leaves through the idle pipeline buffers 128 rows at a time as whole rows, 16 bytes per lane:
@@ -32,32 +34,72 @@
 
 namespace afldm {
 
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// MFMA flavour of the consumers.  MF = 16: v_mfma_f32_16x16x32_bf16 / 4 x 16x16x4_f32 (Mma<T>, common.hpp): lane
+// (i = l & 15, g = l >> 4) feeds chunk kc * 4 + g of row i; accumulator = 4 consecutive couts of one pixel.
+// MF = 32: v_mfma_f32_32x32x16_bf16 / 4 x 32x32x2_f32: lane (i = l & 31, g = l >> 5) feeds chunk 2 kk + g
+// (kk = 0..3) of row i; the accumulator (16 floats) holds couts 8 rq + 4 g + e (rq, e = 0..3) of pixel l & 31.
+// The 32x32 shape sustains ~15 % more matrix throughput on this chip (2382 vs 2075 TF in the guide's micro-benchmarks:
+// 32 instead of 2 x ~19 issue cycles for the same 16 K multiply-adds) and the K loop of this kernel sits on the
+// matrix pipe.
+template <typename T>
+struct Mma32;
+template <>
+struct Mma32<bf16> {
+  static __device__ __forceinline__ void mma(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  }
+};
+template <>
+struct Mma32<float> {
+  static __device__ __forceinline__ void mma(f32x16& acc, const f32x4& a, const f32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
+  }
+};
+
+// LDS position of chunk c of row q and its inverse (see the header): MF = 16 keeps bit 2 for the lane-group parity and
+// swizzles two bits, MF = 32 (the 16-lane read groups lie inside one 32-row half) swizzles all three.
+template <int MF>
+__device__ __forceinline__ int h_pos(int c, int q) {
+  if constexpr (MF == 16) return (((c & 1) << 2) | ((c >> 2) << 1) | ((c >> 1) & 1)) ^ ((q >> 1) & 3);
+  else return c ^ ((q >> 1) & 7);
+}
+template <int MF>
 __device__ __forceinline__ int h_chunk_at(int pos, int q) {   // source chunk that lives at position `pos` of row q
-  const int x = pos ^ ((q >> 1) & 3);
-  return ((x >> 1) & 1) * 4 + (x & 1) * 2 + (x >> 2);
+  if constexpr (MF == 16) {
+    const int x = pos ^ ((q >> 1) & 3);
+    return ((x >> 1) & 1) * 4 + (x & 1) * 2 + (x >> 2);
+  } else {
+    return pos ^ ((q >> 1) & 7);
+  }
 }
 
-template <typename T, int BM, int W_, int BN, int WGM, int WGN, int NPROD, int STAGES, int MINW>
+template <typename T, int BM, int W_, int BN, int WGM, int WGN, int NPROD, int STAGES, int MINW, int MF>
 __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP p) {
   typedef Mma<T> MM;
   typedef typename MM::Chunk Chunk;
   constexpr int NWC = WGM * WGN;
   constexpr int EPC = MM::EPC, KSTEP = 8 * EPC, ESZ = (int)sizeof(T);
-  constexpr int WMS = BM / WGM, WNS = BN / WGN, TM = WMS / 16, TN = WNS / 16;
+  constexpr int WMS = BM / WGM, WNS = BN / WGN, TM = WMS / MF, TN = WNS / MF;
   constexpr int ROWS = BM / W_, PW = W_ + 2, PR = ROWS + 2, NPQ = PR * PW, NPI = (NPQ + 7) / 8;
   constexpr int PATCH = NPI * 1024;
   constexpr int WI = BN / 8, WPW = WI / NPROD, PPW = (NPI + NPROD - 1) / NPROD;
   constexpr int W_STAGE = BN * 128;
   constexpr int LDS_TOTAL = 2 * PATCH + STAGES * W_STAGE;
   constexpr unsigned OOB = 0x80000000u;
-  static_assert(BM % W_ == 0 && WI % NPROD == 0 && WMS % 16 == 0 && WNS % 16 == 0, "tile shape");
+  static_assert(MF == 16 || MF == 32, "MFMA flavour");
+  static_assert(BM % W_ == 0 && WI % NPROD == 0 && WMS % MF == 0 && WNS % MF == 0, "tile shape");
   static_assert((STAGES - 2) * WPW + PPW < 64, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool is_producer = wave_all >= NWC;
-  const int li = lane & 15, lg = lane >> 4;
+  const int li = lane & (MF - 1), lg = lane / MF;       // fragment row / lane group of the consumers
 
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
@@ -81,7 +123,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
       if (j > NPI - 1) j = NPI - 1;
       pj[i] = j;
       const int q = 8 * j + (lane >> 3);
-      const int c = h_chunk_at(lane & 7, q);
+      const int c = h_chunk_at<MF>(lane & 7, q);
       const int pr = q / PW, pc = q - pr * PW;
       const int ih = oh0 + pr - 1;
       const bool ok = q < NPQ && pc >= 1 && pc <= W_ && ih >= 0 && ih < p.H;
@@ -91,7 +133,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
       const int r = 8 * (wave + NPROD * i) + (lane >> 3);      // weight row inside the BN slice
-      const int c = h_chunk_at(lane & 7, r);
+      const int c = h_chunk_at<MF>(lane & 7, r);
       woff[i] = ((unsigned)(n0 + r) * 9u * (unsigned)Ct + (unsigned)(c * EPC)) * ESZ;
     }
     // cursor of the next weight step to issue
@@ -145,37 +187,46 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
 
   // ------------------------------------------------------------------------------------------- consumers
   const int cw = wave_all, wm = cw / WGN, wn = cw - wm * WGN;
-  const int Pl = ((lg & 1) << 2) | (lg >> 1);                   // position bits of chunk (kc = 0, lg)
+  constexpr int NKK = MF == 16 ? 2 : 4;                          // fragment K steps inside a 128-byte row
+  constexpr int KXOR = MF == 16 ? 32 : 32;                       // K step kk of a fragment: byte address ^ (kk << 5)
+  constexpr int NACC = MF * MF / 64;                             // accumulator floats per lane and tile
+  constexpr int RQ = NACC / 4;                                   // cout quads per lane and tile
+  typedef __attribute__((ext_vector_type(NACC))) float AccT;
   int qb[TM];                                                    // patch pixel of (tile pixel, tap (0, 0))
 #pragma unroll
   for (int t = 0; t < TM; ++t) {
-    const int pix = wm * WMS + t * 16 + li;
+    const int pix = wm * WMS + t * MF + li;
     const int r = pix / W_, c = pix - r * W_;
     qb[t] = r * PW + c;
   }
-  const int a_off0 = (wn * WNS + li) * 128 + ((Pl ^ ((li >> 1) & 3)) << 4);
+  // fragment address of (row q, K step kk) = q * 128 + (h_pos(chunk(kk, lg), q) << 4) = (q * 128 + (h_pos(chunk(0, lg), q) << 4)) ^ (kk << 5)
+  // in both flavours (kk only enters position bit 1 for MF = 16 and bits 1..2 for MF = 32)
+  auto frag_off = [&](int q) { return q * 128 + (h_pos<MF>(lg, q) << 4); };
+  const int a_off0 = frag_off(wn * WNS + li);                    // + t * MF * 128 for weight tile t ((row >> 1) & 7 depends on li only)
 
-  // The accumulators START from the residual (fragment layout: lane (li, lg) of tile (tn, t) holds couts
-  // n0 + wn*WNS + 16 tn + 4 lg .. + 3 of pixel m0 + wm*WMS + 16 t + li): its load latency runs under the prologue of
-  // the LDS-DMA pipeline, when the consumers have nothing to do, instead of in the epilogue (one dependent global
-  // load per copied row was most of the fixed cost of a residual convolution); residual + sum of products, fp32.
-  f32x4 acc[TN][TM];
+  // The accumulators START from the residual (fragment layout): its load latency runs under the prologue of the
+  // LDS-DMA pipeline, when the consumers have nothing to do, instead of in the epilogue; residual + sum, fp32.
+  auto cout_of = [&](int tn, int rq) { return n0 + wn * WNS + tn * MF + (MF == 16 ? 4 * lg : 8 * rq + 4 * lg); };
+  AccT acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int e = 0; e < NACC; ++e) acc[a][b][e] = 0.f;
   if (p.residual) {
     const T* res = (const T*)p.residual;
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
-      for (int b = 0; b < TM; ++b) {
-        const T* src = res + (size_t)(m0 + wm * WMS + b * 16 + li) * p.res_ld + n0 + wn * WNS + a * 16 + 4 * lg;
-        float r0, r1, r2, r3;
-        load4<T>(src, r0, r1, r2, r3);
-        acc[a][b] = f32x4{r0, r1, r2, r3};
-      }
-  } else {
+      for (int b = 0; b < TM; ++b)
 #pragma unroll
-    for (int a = 0; a < TN; ++a)
-#pragma unroll
-      for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int rq = 0; rq < RQ; ++rq) {
+          const T* src = res + (size_t)(m0 + wm * WMS + b * MF + li) * p.res_ld + cout_of(a, rq);
+          float r0, r1, r2, r3;
+          load4<T>(src, r0, r1, r2, r3);
+          acc[a][b][4 * rq] = r0; acc[a][b][4 * rq + 1] = r1; acc[a][b][4 * rq + 2] = r2; acc[a][b][4 * rq + 3] = r3;
+        }
   }
 
   {
@@ -188,22 +239,33 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
         const int tapoff = kh * PW + kw;
         int boff[TM];
 #pragma unroll
-        for (int t = 0; t < TM; ++t) {
-          const int q = qb[t] + tapoff;
-          boff[t] = q * 128 + ((Pl ^ ((q >> 1) & 3)) << 4);
-        }
+        for (int t = 0; t < TM; ++t) boff[t] = frag_off(qb[t] + tapoff);
+        // hand-ordered fragment pipeline: the NKK x TN MFMA groups of the step (one weight fragment x TM pixel
+        // fragments each) run back to back; weight fragment i + AD is requested when group i starts, the pixel
+        // fragments of K step kk + 1 during the groups of kk.  (Left alone the compiler rotates two weight buffers
+        // with a distance of ONE group: every group then waits out an LDS round trip.)
+        constexpr int NG = NKK * TN, AD = 3;
+        Chunk af[NG], bf[NKK][TM];
+        auto lda = [&](int i) { return ld16<Chunk>(sW + ((a_off0 + (i % TN) * MF * 128) ^ ((i / TN) * KXOR))); };
 #pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
-          Chunk a[TN], b[TM];
+        for (int t = 0; t < TM; ++t) bf[0][t] = ld16<Chunk>(sP + boff[t]);
 #pragma unroll
-          for (int t = 0; t < TN; ++t) a[t] = ld16<Chunk>(sW + ((a_off0 + t * 2048) ^ (kc << 5)));
+        for (int i = 0; i < AD; ++i) af[i] = lda(i);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int t = 0; t < TM; ++t) b[t] = ld16<Chunk>(sP + (boff[t] ^ (kc << 5)));
+        for (int i = 0; i < NG; ++i) {
+          if (i + AD < NG) af[i + AD] = lda(i + AD);
+          if (i % TN == TN / 2 && i / TN + 1 < NKK) {
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
+            for (int t = 0; t < TM; ++t) bf[i / TN + 1][t] = ld16<Chunk>(sP + (boff[t] ^ ((i / TN + 1) * KXOR)));
+          }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) MM::mma(acc[tn][tm], a[tn], b[tm]);
-          if constexpr (NWC >= 8) __builtin_amdgcn_sched_barrier(0);
+          for (int tm = 0; tm < TM; ++tm) {
+            if constexpr (MF == 16) MM::mma(acc[i % TN][tm], af[i], bf[i / TN][tm]);
+            else Mma32<T>::mma(acc[i % TN][tm], af[i], bf[i / TN][tm]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       slot = slot + 1 == STAGES ? 0 : slot + 1;
@@ -264,8 +326,12 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
           for (int t = 0; t < TM; ++t) {
-            const int row = wml * WMS + t * 16 + li;
-            *reinterpret_cast<f32x4*>(sC + row * SROW + wn * WNS + tn * 16 + 4 * lg) = acc[tn][t];
+            const int row = wml * WMS + t * MF + li;
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) {
+              const f32x4 v = f32x4{acc[tn][t][4 * rq], acc[tn][t][4 * rq + 1], acc[tn][t][4 * rq + 2], acc[tn][t][4 * rq + 3]};
+              *reinterpret_cast<f32x4*>(sC + row * SROW + (cout_of(tn, rq) - n0)) = v;
+            }
             __builtin_amdgcn_sched_barrier(0);
           }
       }
@@ -321,16 +387,20 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
 
 // ----------------------------------------------------------------------------------------------- host side
 struct H3Variant {
-  int bm, w, wgm, wgn;
+  int bm, w, wgm, wgn, mf;
 };
 // ids kConv3hFirst + index
 static const H3Variant kH3[] = {
-    {256, 32, 4, 2},   // 41: 32x32 planes, 8 rows per tile; 8 consumer waves (64 x 96 each) + 4 producers
-    {128, 16, 2, 4},   // 42: 16x16 planes, 8 rows per tile; 8 consumers (64 x 48) + 4 producers
-    {128, 16, 2, 2},   // 43: 16x16 planes; 4 consumers (64 x 96) + 4 producers
-    {256, 16, 4, 2},   // 44: 16x16 planes, whole sample per tile
-    {128, 32, 2, 4},   // 45: 32x32 planes, 4 rows per tile
-    {128, 32, 2, 2},   // 46
+    {256, 32, 4, 2, 16},   // 41: 32x32 planes, 8 rows per tile; 8 consumer waves (64 x 96 each) + 4 producers
+    {128, 16, 2, 4, 16},   // 42: 16x16 planes, 8 rows per tile; 8 consumers (64 x 48) + 4 producers
+    {128, 16, 2, 2, 16},   // 43: 16x16 planes; 4 consumers (64 x 96) + 4 producers
+    {256, 16, 4, 2, 16},   // 44: 16x16 planes, whole sample per tile
+    {128, 32, 2, 4, 16},   // 45: 32x32 planes, 4 rows per tile
+    {128, 32, 2, 2, 16},   // 46
+    {256, 32, 4, 2, 32},   // 47: as 41 on 32x32x16 MFMAs
+    {128, 16, 2, 2, 32},   // 48: as 43 on 32x32x16 MFMAs
+    {256, 16, 4, 2, 32},   // 49: as 44 on 32x32x16 MFMAs
+    {128, 32, 2, 2, 32},   // 50: as 46 on 32x32x16 MFMAs
 };
 constexpr int kNumH3 = (int)(sizeof(kH3) / sizeof(kH3[0]));
 
@@ -347,7 +417,7 @@ bool conv3h_supported(int variant, int dtype_size, const ConvP& p) {
          (long long)p.Cout * 9 * p.C1 * dtype_size < (1ll << 31) && aligned16(p.y) && aligned16(p.x1) && aligned16(p.w);
 }
 
-template <typename T, int BM, int W_, int WGM, int WGN>
+template <typename T, int BM, int W_, int WGM, int WGN, int MF>
 static void launch_h3(const ConvP& p0, hipStream_t st) {
   constexpr int BN = 192, NPROD = 4, STAGES = 3;
   constexpr int NWC = WGM * WGN;
@@ -358,7 +428,7 @@ static void launch_h3(const ConvP& p0, hipStream_t st) {
   p.tiles_n = p.Cout / BN;
   p.splitk = 1;
   const int tiles = (p.M / BM) * p.tiles_n;
-  auto kern = k_conv3h<T, BM, W_, BN, WGM, WGN, NPROD, STAGES, MINW>;
+  auto kern = k_conv3h<T, BM, W_, BN, WGM, WGN, NPROD, STAGES, MINW, MF>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -370,12 +440,16 @@ static void launch_h3(const ConvP& p0, hipStream_t st) {
 template <typename T>
 static void launch_h3_variant(int k, const ConvP& p, hipStream_t st) {
   switch (k) {
-    case 0: launch_h3<T, 256, 32, 4, 2>(p, st); break;
-    case 1: launch_h3<T, 128, 16, 2, 4>(p, st); break;
-    case 2: launch_h3<T, 128, 16, 2, 2>(p, st); break;
-    case 3: launch_h3<T, 256, 16, 4, 2>(p, st); break;
-    case 4: launch_h3<T, 128, 32, 2, 4>(p, st); break;
-    case 5: launch_h3<T, 128, 32, 2, 2>(p, st); break;
+    case 0: launch_h3<T, 256, 32, 4, 2, 16>(p, st); break;
+    case 1: launch_h3<T, 128, 16, 2, 4, 16>(p, st); break;
+    case 2: launch_h3<T, 128, 16, 2, 2, 16>(p, st); break;
+    case 3: launch_h3<T, 256, 16, 4, 2, 16>(p, st); break;
+    case 4: launch_h3<T, 128, 32, 2, 4, 16>(p, st); break;
+    case 5: launch_h3<T, 128, 32, 2, 2, 16>(p, st); break;
+    case 6: launch_h3<T, 256, 32, 4, 2, 32>(p, st); break;
+    case 7: launch_h3<T, 128, 16, 2, 2, 32>(p, st); break;
+    case 8: launch_h3<T, 256, 16, 4, 2, 32>(p, st); break;
+    case 9: launch_h3<T, 128, 32, 2, 2, 32>(p, st); break;
   }
 }
 

@@ -11,13 +11,13 @@ import torch  # noqa: E402
 from afldm_amd import _lib, ops  # noqa: E402
 
 SHAPES = [
-    ("L32 192->192", 64, 32, 192, 192, (29, 41, 45, 46)),
-    ("L32 384->192", 64, 32, 384, 192, (29, 41, 45, 46)),
-    ("L32 576->192", 64, 32, 576, 192, (29, 41, 45, 46)),
-    ("L32 384->384", 64, 32, 384, 384, (29, 41, 45, 46)),
-    ("L16 384->384", 64, 16, 384, 384, (33, 42, 43, 44)),
-    ("L16 768->384", 64, 16, 768, 384, (33, 42, 43, 44)),
-    ("L16 192->384", 64, 16, 192, 384, (33, 42, 43, 44)),
+    ("L32 192->192", 64, 32, 192, 192, (29, 41, 47)),
+    ("L32 384->192", 64, 32, 384, 192, (29, 41, 47)),
+    ("L32 576->192", 64, 32, 576, 192, (29, 41, 47)),
+    ("L32 384->384", 64, 32, 384, 384, (29, 41, 47)),
+    ("L16 384->384", 64, 16, 384, 384, (33, 42, 43, 48, 49)),
+    ("L16 768->384", 64, 16, 768, 384, (33, 42, 43, 48, 49)),
+    ("L16 192->384", 64, 16, 192, 384, (33, 42, 43, 48, 49)),
 ]
 
 
