@@ -83,6 +83,7 @@ def _load():
         "afldm_ddim_step": ([vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, vp], c_int),
         "afldm_ddim_step_flat": ([vp, vp, vp, fp, fp, fp, fp, c_size_t, vp], c_int),
         "afldm_select_timestep": ([vp, vp, vp, ip, vp], c_int),
+        "afldm_select_step_row": ([vp, vp, vp, ip, vp, vp, c_size_t, vp], c_int),
     }
     for name, (argtypes, restype) in sigs.items():
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch

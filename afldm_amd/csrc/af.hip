@@ -447,6 +447,37 @@ __global__ void __launch_bounds__(256) k_af_act_kron(AfP<T> p) {
   const int Ct = p.C1 + p.C2, ctiles = Ct / 16, nitems = p.B * ctiles;
   const int cpg = p.gs.st1 ? Ct / p.G : 1;
 
+  // X tile of an item: [P px][16 c], unit = EPC pixels x EPC channels; lanes stride the units (the channel octet / quad
+  // of a lane is fixed: 64 % CQ == 0).  The loads of the FIRST item are issued before the 64 KB constant image is
+  // copied and before the GroupNorm partial sums are fetched, those of the next item while the current one is in its
+  // GEMMs: the three latencies used to follow one another in every launch (constants, statistics, tile).
+  constexpr int CQ = 16 / EPC, PQ = P / EPC, UNITS = CQ * PQ, UPL = (UNITS + 63) / 64;
+  const int ngroups = (nitems + 3) / 4;
+  Chunk xin[UPL][EPC];
+  auto item_of = [&](int grp, int& b, int& c0) {
+    const int item = grp * 4 + wave;
+    const bool live = item < nitems;
+    b = live ? item / ctiles : 0;
+    c0 = live ? (item - b * ctiles) * 16 : 0;
+    return live;
+  };
+  auto issue_x = [&](int grp) {
+    int b, c0;
+    if (grp >= ngroups || !item_of(grp, b, c0)) return;
+    const bool second = c0 >= p.C1;
+    const T* xsrc = second ? p.x2 : p.x1;
+    const int Cs = second ? p.C2 : p.C1, cs0 = second ? c0 - p.C1 : c0;
+#pragma unroll
+    for (int k = 0; k < UPL; ++k) {
+      const int u = lane + 64 * k;
+      if (u < UNITS) {
+        const int cq = u % CQ, pq = u / CQ;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) xin[k][e] = ld16<Chunk>(xsrc + ((size_t)b * P + pq * EPC + e) * Cs + cs0 + cq * EPC);
+      }
+    }
+  };
+  issue_x(blockIdx.x);
   {
     const Chunk* src = reinterpret_cast<const Chunk*>(p.packed);
     Chunk* dst = reinterpret_cast<Chunk*>(KU);
@@ -460,15 +491,9 @@ __global__ void __launch_bounds__(256) k_af_act_kron(AfP<T> p) {
   }
   __syncthreads();
 
-  const int ngroups = (nitems + 3) / 4;
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int item = grp * 4 + wave;
-    const bool live = item < nitems;
-    const int b = live ? item / ctiles : 0;
-    const int c0 = live ? (item - b * ctiles) * 16 : 0;
-    const bool second = c0 >= p.C1;
-    const T* xsrc = second ? p.x2 : p.x1;
-    const int Cs = second ? p.C2 : p.C1, cs0 = second ? c0 - p.C1 : c0;
+    int b, c0;
+    const bool live = item_of(grp, b, c0);
 
     // ---- GroupNorm scale/shift of channel c0 + li: lane group lg adds every 4th channel of its group
     float sc = 1.f, sh = 0.f;
@@ -479,10 +504,8 @@ __global__ void __launch_bounds__(256) k_af_act_kron(AfP<T> p) {
       sh = p.beta[c0 + li] - mean * sc;
     }
 
-    // ---- X tile: [P px][16 c] -> Xk[c][px] (pixels K-contiguous), GroupNorm applied.
-    // unit = EPC pixels x EPC channels; lanes stride the units (the channel octet/quad of a lane
-    // is fixed: 64 % CQ == 0), so its scale/shift are fetched with full-wave shuffles up front.
-    constexpr int CQ = 16 / EPC, PQ = P / EPC, UNITS = CQ * PQ;
+    // ---- X tile (already in registers) -> Xk[c][px] (pixels K-contiguous), GroupNorm applied; the scale / shift of a
+    // lane's channel octet are fetched with full-wave shuffles up front.
     float usc[EPC], ush[EPC];
 #pragma unroll
     for (int cc = 0; cc < EPC; ++cc) {
@@ -492,21 +515,22 @@ __global__ void __launch_bounds__(256) k_af_act_kron(AfP<T> p) {
     // (Xk / Ys are private to the wave and same-wave LDS operations are ordered: no workgroup barrier,
     //  the four waves drift apart and overlap their load / MFMA / store phases)
     if (live) {
-      for (int u = lane; u < UNITS; u += 64) {
-        const int cq = u % CQ, pq = u / CQ;
-        Chunk ch[EPC];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e)
-          ch[e] = ld16<Chunk>(xsrc + ((size_t)b * P + pq * EPC + e) * Cs + cs0 + cq * EPC);
+      for (int k = 0; k < UPL; ++k) {
+        const int u = lane + 64 * k;
+        if (u < UNITS) {
+          const int cq = u % CQ, pq = u / CQ;
 #pragma unroll
-        for (int cc = 0; cc < EPC; ++cc) {
-          Chunk o;
+          for (int cc = 0; cc < EPC; ++cc) {
+            Chunk o;
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) o[e] = from_f32<T>(to_f32(ch[e][cc]) * usc[cc] + ush[cc]);
-          st16<Chunk>(Xk + (cq * EPC + cc) * PK + pq * EPC, o);
+            for (int e = 0; e < EPC; ++e) o[e] = from_f32<T>(to_f32(xin[k][e][cc]) * usc[cc] + ush[cc]);
+            st16<Chunk>(Xk + (cq * EPC + cc) * PK + pq * EPC, o);
+          }
         }
       }
     }
+    issue_x(grp + (int)gridDim.x);      // the next item's tile travels during this item's GEMMs
 
     // ---- GEMM1 + SiLU
     Chunk xf[NKF1];

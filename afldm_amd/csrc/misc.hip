@@ -120,6 +120,27 @@ __global__ void k_select_timestep(const float* tvals, int* step_idx, float* t_ou
   t_out[0] = tvals[s];
 }
 
+// Step prologue of the sampling loop in ONE launch (single workgroup): advance the step counter, publish the
+// timestep value, and copy row `step` of a precomputed table (the 27 time_emb_proj outputs of that timestep:
+// time_proj -> linear_1 -> SiLU -> linear_2 -> SiLU -> all time_emb_proj layers depend on the timestep only, and a
+// sampler knows its timesteps in advance) into the buffer the convolutions read - instead of seven launches per step.
+__global__ void __launch_bounds__(1024) k_select_step_row(const float* tvals, int* step_idx, float* t_out, int pre_advance,
+                                                          const uint4* table, uint4* row_out, int row_chunks) {
+  __shared__ int s_step;
+  if (threadIdx.x == 0) {
+    int s = *step_idx;
+    if (pre_advance) {
+      s += 1;
+      *step_idx = s;
+    }
+    t_out[0] = tvals[s];
+    s_step = s;
+  }
+  __syncthreads();
+  const uint4* src = table + (size_t)s_step * row_chunks;
+  for (int i = threadIdx.x; i < row_chunks; i += 1024) row_out[i] = src[i];
+}
+
 // Masked equivariance metrics in ONE pass (reference shift_utils/metrics.py:5-20): per sample
 // out[b] = { sum ((a - b) m)^2, sum m, max(a m), min(a m), max(b m), min(b m) }.  One workgroup per sample,
 // fixed summation order (strided per-thread partials, xor-shuffle tree, 4 wave partials in order).
@@ -264,6 +285,16 @@ extern "C" int afldm_ddim_step(const float* x, const void* eps, float* x_prev, c
              "afldm_ddim_step");
   if (advance) k_advance<<<1, 1, 0, st>>>(step_idx);
   return check_launch("afldm_ddim_step");
+}
+
+extern "C" int afldm_select_step_row(const float* tvals, int* step_idx, float* t_out, int pre_advance, const void* table,
+                                     void* row_out, size_t row_bytes, afldm_stream_t stream) {
+  AFLDM_REQUIRE(tvals && step_idx && t_out && table && row_out, AFLDM_ENULL, "afldm_select_step_row: NULL pointer");
+  AFLDM_REQUIRE(row_bytes > 0 && row_bytes % 16 == 0 && aligned16(table) && aligned16(row_out), AFLDM_EALIGN,
+                "afldm_select_step_row: rows must be whole 16-byte chunks");
+  k_select_step_row<<<1, 1024, 0, (hipStream_t)stream>>>(tvals, step_idx, t_out, pre_advance, (const uint4*)table,
+                                                          (uint4*)row_out, (int)(row_bytes / 16));
+  return check_launch("afldm_select_step_row");
 }
 
 extern "C" int afldm_select_timestep(const float* tvals, int* step_idx, float* t_out, int pre_advance,

@@ -6,7 +6,9 @@ The reference loop costs, per step, ~1100 dependent kernel launches from Python 
 memory — the timestep table, the DDIM coefficient table and a step counter the update kernel
 increments itself — so a replay needs no host value and no synchronisation:
 
-    step++; t <- t_table[step]                    (afldm_select_timestep, counter starts at -1)
+    step++; t <- t_table[step]; temb <- table[step] (afldm_select_step_row, counter starts at -1: the time-embedding
+                                                   MLP and the 27 time_emb_proj layers depend on the timestep only and
+                                                   are tabulated once per schedule)
     x_nhwc <- NCHW fp32 latents                   (afldm_nchw_to_nhwc)
     eps    <- UNet(x_nhwc, t)                     (~450 HIP kernels, all from libafldm_hip.so)
     lat    <- DDIM(lat, eps, coef[step])          (afldm_ddim_step, in place)
@@ -19,7 +21,7 @@ from . import ops
 
 
 class DenoiseEngine:
-    def __init__(self, unet, scheduler, batch_size, num_inference_steps=50, use_graph=True, steps_per_graph=5):
+    def __init__(self, unet, scheduler, batch_size, num_inference_steps=50, use_graph=True, steps_per_graph=5, branches=1):
         if unet.device.type != "cuda":
             raise RuntimeError("DenoiseEngine needs the UNet on an MI355X ('cuda') device; there is no CPU path")
         self.unet, self.scheduler = unet, scheduler
@@ -41,14 +43,41 @@ class DenoiseEngine:
         self.steps_per_graph = max(1, int(os.environ.get("AFLDM_STEPS_PER_GRAPH", steps_per_graph)))
         self.use_graph = use_graph
         self.kernels_per_step = None
+        # everything of the UNet that depends on the timestep only (time_proj -> time_embedding -> SiLU -> the 27
+        # time_emb_proj layers) is tabulated once for the schedule: [steps, sum Cout]; a step copies its row
+        self.temb_table = torch.cat([unet.temb_projection(t) for t in self.timesteps], 0).contiguous()
+        self.temb_row = torch.empty_like(self.temb_table[:1])
+        self.temb_slices = unet.temb_slices(self.temb_row)
+        nb = int(os.environ.get("AFLDM_BRANCHES", branches))
+        self.branches = nb if nb > 1 and batch_size % nb == 0 else 1
+        self._side = [torch.cuda.Stream() for _ in range(self.branches - 1)]
 
     # one denoise step, entirely stream-ordered
     def _step(self):
         # the step counter starts at -1 and is advanced by the first kernel of the step
-        ops.select_timestep(self.t_table, self.step_idx, self.t_cur, pre_advance=True)
-        ops.to_nhwc(self.lat, self.unet.dtype, out=self.x_nhwc)
-        eps = self.unet.forward_nhwc(self.x_nhwc, self.t_cur)
-        ops.ddim_step(self.lat, eps, self.coef, self.step_idx, advance=False, out=self.lat)
+        ops.select_step_row(self.t_table, self.step_idx, self.t_cur, self.temb_table, self.temb_row, pre_advance=True)
+        nb = self.branches
+        if nb <= 1:
+            self._substep(self.lat, self.x_nhwc)
+            return
+        # The batch as `nb` independent sub-batches on parallel streams (parallel branches of the captured graph):
+        # samples are independent, so the kernels of one branch fill the gaps the other leaves - prologues / epilogues
+        # of the large convolutions (one tile per CU: nothing inside a launch overlaps them) and the latency-bound
+        # launches of the 8x8 .. 2x2 levels.
+        main = torch.cuda.current_stream()
+        per = self.B // nb
+        for i, s in enumerate(self._side):
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                self._substep(self.lat[(i + 1) * per:(i + 2) * per], self.x_nhwc[(i + 1) * per:(i + 2) * per])
+        self._substep(self.lat[:per], self.x_nhwc[:per])
+        for s in self._side:
+            main.wait_stream(s)
+
+    def _substep(self, lat, x_nhwc):
+        ops.to_nhwc(lat, self.unet.dtype, out=x_nhwc)
+        eps = self.unet.forward_nhwc(x_nhwc, self.t_cur, temb_slices=self.temb_slices)
+        ops.ddim_step(lat, eps, self.coef, self.step_idx, advance=False, out=lat)
 
     def _capture(self):
         keep = self.lat.clone()

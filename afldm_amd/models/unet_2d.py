@@ -173,16 +173,28 @@ class UNet2DModel(nn.Module):
         emb = self.time_embedding(t_emb)                                   # [rows, temb_dim]
         w, b, offs, total = self._temb_weights(dtype)
         proj = ops.conv2d(ops.silu(emb), w, b)                            # [rows, sum Cout]
-        stride = 0 if t.numel() == 1 else total
-        rs = list(self._resnets_in_order())
-        slices = [(proj.view(-1)[o:] if stride == 0 else proj[:, o:], stride) for o, r in zip(offs, rs)]
-        return slices, emb
+        return self.temb_slices(proj, t.numel() > 1), emb
+
+    def temb_slices(self, proj, per_sample=False):
+        """per-resnet (view into `proj` [rows, sum Cout], row stride) pairs."""
+        _, _, offs, total = self._temb_weights(self.dtype)
+        stride = total if per_sample else 0
+        return [(proj.view(-1)[o:] if stride == 0 else proj[:, o:], stride) for o in offs]
+
+    def temb_projection(self, timestep):
+        """[1, sum Cout] time_emb_proj outputs of one shared timestep (what DenoiseEngine tabulates per step)."""
+        dev, dtype = self.device, self.dtype
+        t = torch.full((1,), float(timestep), dtype=torch.float32, device=dev)
+        emb = self.time_embedding(self.time_proj(t, dtype))
+        w, b, _, _ = self._temb_weights(dtype)
+        return ops.conv2d(ops.silu(emb), w, b)
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def forward_nhwc(self, x, timestep):
-        """x: NHWC [B, H, W, in_channels] in the model dtype -> NHWC [B, H, W, out_channels]."""
-        slices, _ = self.time_embed(timestep, x.shape[0])
+    def forward_nhwc(self, x, timestep, temb_slices=None):
+        """x: NHWC [B, H, W, in_channels] in the model dtype -> NHWC [B, H, W, out_channels].
+        temb_slices: the per-resnet time_emb_proj slices when the caller already has them (DenoiseEngine's table)."""
+        slices = temb_slices if temb_slices is not None else self.time_embed(timestep, x.shape[0])[0]
         it = iter(slices)
 
         def take(n):

@@ -684,3 +684,12 @@ def select_timestep(tvals, step_idx, t_out, pre_advance=False):
     check(lib.afldm_select_timestep(ptr(tvals), ptr(step_idx), ptr(t_out), int(pre_advance), stream_ptr()),
           "select_timestep")
     return t_out
+
+
+def select_step_row(tvals, step_idx, t_out, table, row_out, pre_advance=False):
+    """afldm_select_step_row: select_timestep + row_out <- table[step] in one launch."""
+    assert table.is_contiguous() and row_out.is_contiguous() and table[0].numel() == row_out.numel()
+    nbytes = row_out.numel() * row_out.element_size()
+    check(lib.afldm_select_step_row(ptr(tvals), ptr(step_idx), ptr(t_out), int(pre_advance), ptr(table), ptr(row_out),
+                                    nbytes, stream_ptr()), "select_step_row")
+    return t_out

@@ -271,6 +271,12 @@ int afldm_ddim_step_flat(const float* x, const float* eps, float* x_prev, float 
  * launch behind afldm_ddim_step). */
 int afldm_select_timestep(const float* tvals, int* step_idx, float* t_out, int pre_advance,
                           afldm_stream_t stream);
+/* The same plus a table row: row_out[0 .. row_bytes) = table[step * row_bytes ..] (row_bytes % 16 == 0), one
+ * launch.  A sampler knows its timesteps up front, so everything that depends on the timestep only - time_proj ->
+ * TimestepEmbedding -> SiLU -> every ResnetBlock2D.time_emb_proj (diffusers UNet2DModel.forward) - is a table with
+ * one row per step; the step then starts with this launch instead of seven. */
+int afldm_select_step_row(const float* tvals, int* step_idx, float* t_out, int pre_advance, const void* table,
+                          void* row_out, size_t row_bytes, afldm_stream_t stream);
 
 /* ---- masked equivariance metrics (shift_utils/metrics.py:5-20) ------------------------------
  * One pass over a, b [B][n] (dtype) and mask [B][n] fp32: out[b] = { sum ((a - b) mask)^2, sum mask,

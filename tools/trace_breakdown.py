@@ -7,15 +7,18 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_select_timestep" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "k_select_timestep" in r["Kernel_Name"] or "k_select_step_row" in r["Kernel_Name"]]
 step = rows[idx[-2]:idx[-1]]
 
 
 def short(n):
+    if "k_conv3h" in n:
+        m = re.search(r"Li(\d+)ELi(\d+)ELi192ELi(\d+)ELi(\d+)E", n) or re.search(r"<\w+, (\d+), (\d+), 192, (\d+), (\d+)", n)
+        return f"conv3h_{m.group(1)}w{m.group(2)}c{int(m.group(3)) * int(m.group(4))}"
     if "k_igemm3" in n:
         return "igemm3_128x192p"
     if "k_igemm" in n:
-        m = re.search(r"Li(\d+)ELi(\d+)ELi\d+ELi\d+ELi\d+E(?:Li(\d+)E)?", n)
+        m = re.search(r"Li(\d+)ELi(\d+)ELi\d+ELi\d+ELi\d+E(?:Li(\d+)E)?", n) or re.search(r"<\w+, (\d+), (\d+), \d+, \d+, \d+(?:, (\d+))?", n)
         return f"igemm{'2' if 'igemm2' in n else ''}_{m.group(1)}x{m.group(2)}" + (f"s{m.group(3)}" if m.group(3) else "")
     for k in ["k_attn", "gn_partial", "gn_apply", "af_act_mfma", "af_act_kron", "af_act_small", "splitk", "axis_contract",
               "cin4", "small_cout", "silu", "ddim", "nchw", "timestep", "select", "advance"]:

@@ -6,7 +6,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_select_timestep" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "k_select_timestep" in r["Kernel_Name"] or "k_select_step_row" in r["Kernel_Name"]]
 step = rows[idx[-2]:idx[-1]]
 prev_end = None
 for r in step:
