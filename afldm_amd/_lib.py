@@ -79,6 +79,7 @@ def _load():
         "afldm_conv2d_stats_splits": ([POINTER(ConvArgs)], c_int),
         "afldm_conv2d_tune": ([ip, ip], c_int),
         "afldm_conv2d_fused_splitk": ([ip], c_int),
+        "afldm_conv2d_variant": ([POINTER(ConvArgs)], c_int),
         "afldm_attention": ([vp, ip, vp, ip, vp, vp, ip, ip, ip, ip, ip, ip, ip, fp, ip, vp], c_int),
         "afldm_ddim_step": ([vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, vp], c_int),
         "afldm_ddim_step_flat": ([vp, vp, vp, fp, fp, fp, fp, c_size_t, vp], c_int),

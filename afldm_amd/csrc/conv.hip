@@ -1575,6 +1575,11 @@ static const Variant kVariants[] = {
     {128, 192, 6, 3},  // 48  = 43 on 32x32x16 MFMAs
     {256, 192, 6, 3},  // 49  = 44 on 32x32x16 MFMAs
     {128, 192, 6, 3},  // 50  = 46 on 32x32x16 MFMAs
+    {64, 96, 6, 3},    // 51  halo-patch, 8x8 planes: one sample x 96 couts per tile, 3 taps per K step, no split-K
+    {64, 96, 6, 3},    // 52  4x4 planes: four samples x 96 couts per tile, split-K over the channel blocks
+    {64, 96, 6, 3},    // 53  = 51
+    {128, 96, 6, 3},   // 54  16x16 planes, 8 rows x 96 couts (small batches)
+    {128, 96, 6, 3},   // 55  32x32 planes, 4 rows x 96 couts (small batches)
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -1615,7 +1620,16 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
     const int bm_ = kVariants[v].bm, bn_ = kVariants[v].bn;
     const long long tiles = ((M + bm_ - 1) / bm_) * ((a->Cout + bn_ - 1) / bn_);
     int sk = 1;
-    if (kVariants[v].ver == 6) return 1;      // halo-patch kernel: no split-K
+    if (kVariants[v].ver == 6) {
+      // halo-patch kernel: the small-tile variants (51+) may split the CHANNEL BLOCKS over up to 4 slices when the
+      // tiles alone leave most CUs idle; the slice count must divide the number of 128-byte channel blocks
+      if (v < 51) return 1;
+      const int ncb = Ct / (2 * elems_per_row);
+      int z = 1;
+      for (int c = 2; c <= 4; ++c)
+        if (ncb % c == 0 && tiles * c <= 320) z = c;
+      return z;
+    }
     if (kVariants[v].ver == 4 && kVariants[v].stages == 3 && bn_ == 192) {
       // one 8-wave workgroup per CU: aim at 256 workgroups (measured best: 64 tiles -> 4, 128 tiles -> 2)
       sk = (int)((256 + tiles / 2) / tiles);
@@ -1638,10 +1652,21 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
   pl.splitk_auto = splitk_for(vid);
   // halo-patch kernel for the 3x3 convolutions of the 32x32 / 16x16 levels (conv3h.hip); support is checked by resolve_exec
   {
-    static const int s_h3 = getenv("AFLDM_CONV3H") ? atoi(getenv("AFLDM_CONV3H")) : 1;      // 0: off, 2: variant 42 at 16x16
+    static const int s_h3 = getenv("AFLDM_CONV3H") ? atoi(getenv("AFLDM_CONV3H")) : 4;      // 0: off, 1: 32x32 / 16x16 only, 2: + variant 42 at 16x16, 3: + 8x8 / 4x4, 4: + small batches
     if (s_h3 && a->KS == 3 && a->C2 == 0 && a->H == a->W && a->Cout % 192 == 0) {
-      if (a->W == 32 && M >= 32768) vid = 41;
-      else if (a->W == 16 && M >= 8192) vid = s_h3 == 2 ? 42 : 43;      // 4 consumer waves (64x96) measured best at 16x16
+      // tile by plane size; the large tiles only while they still give every CU a workgroup
+      const long long t256 = (M / 256) * (a->Cout / 192), t128 = (M / 128) * (a->Cout / 192);
+      if (a->W == 32 && t256 >= 192) vid = 41;
+      else if (a->W == 32 && t128 >= 192 && s_h3 >= 4) vid = 46;
+      else if (a->W == 16 && t128 >= 192) vid = s_h3 == 2 ? 42 : 43;      // 4 consumer waves (64x96) measured best at 16x16
+      else if (s_h3 >= 3 && a->W == 8 && M >= 2048 && a->Cout % 96 == 0) vid = 51;
+      else if (s_h3 >= 3 && a->W == 4 && M >= 1024 && a->Cout % 96 == 0) vid = 52;
+      else if (s_h3 >= 4 && a->Cout % 96 == 0) {      // small batches: the 96-cout tiles with split channel blocks
+        if (a->W == 32 && M >= 1024) vid = 55;
+        else if (a->W == 16 && M >= 256) vid = 54;
+        else if (a->W == 8 && M >= 64) vid = 51;
+        else if (a->W == 4 && M >= 64) vid = 52;
+      }
     }
   }
   // in-situ tuning hook (tools/tune_insitu.py): AFLDM_CONV_OVERRIDE="M:Cout:KS:Ct=variant/splitk;..."
@@ -1830,6 +1855,7 @@ static Exec resolve_exec(const afldm_conv_args* a) {
     q.C1 = a->C1; q.C2 = a->C2; q.H = a->H; q.W = a->W; q.Cout = a->Cout; q.KS = a->KS; q.M = (int)M;
     q.out_mode = a->out_mode; q.y_ld = a->y_ld; q.res_ld = a->res_ld; q.temb_stride = a->temb_stride;
     q.temb_mod = a->temb_mod > 0 ? a->temb_mod : a->Cout;
+    q.splitk = e.splitk;               // (after the workspace check: a shape that needs its slices cannot run without them)
     if (!conv3h_supported(e.vid, (int)sizeof(T), q)) {       // not this kernel's shape: the automatic choice
       e.vid = e.pl.cfg_auto;
       e.splitk = e.pl.splitk_auto;
@@ -1837,8 +1863,6 @@ static Exec resolve_exec(const afldm_conv_args* a) {
         const size_t need = (size_t)e.splitk * M * a->Cout * sizeof(float);
         if (!a->workspace || a->workspace_bytes < need) e.splitk = 1;
       }
-    } else {
-      e.splitk = 1;
     }
   }
   if (kVariants[e.vid].ver >= 2 && kVariants[e.vid].ver != 6 && !v2_ok) e.vid = kVariants[e.vid].bm == 128 ? (kVariants[e.vid].bn >= 128 ? 0 : 1) : 3;
@@ -2074,6 +2098,13 @@ extern "C" int afldm_conv2d_tune(int variant, int splitk) {
 extern "C" int afldm_conv2d_fused_splitk(int enable) {
   g_fused_splitk = enable ? 1 : 0;
   return AFLDM_OK;
+}
+
+extern "C" int afldm_conv2d_variant(const afldm_conv_args* a) {
+  if (!a || (a->dtype != AFLDM_F32 && a->dtype != AFLDM_BF16)) return -1;
+  const Exec e = a->dtype == AFLDM_F32 ? resolve_exec<float>(a) : resolve_exec<bf16>(a);
+  if (e.pl.kind != 0) return -1 - e.pl.kind;
+  return e.vid | (e.splitk << 8) | (e.fused << 16);
 }
 
 extern "C" int afldm_conv2d_stats_splits(const afldm_conv_args* a) {

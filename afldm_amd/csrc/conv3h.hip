@@ -78,21 +78,29 @@ __device__ __forceinline__ int h_chunk_at(int pos, int q) {   // source chunk th
   }
 }
 
-template <typename T, int BM, int W_, int BN, int WGM, int WGN, int NPROD, int STAGES, int MINW, int MF>
+// TPS: filter taps per K step (1, or 3 = one filter row): the small-plane variants (64 x 96 tiles over the 8x8 / 4x4
+// levels, one MFMA wave per SIMD) do 3 taps between two barriers so that a step still carries 36 MFMAs per wave.
+// Tiles may hold several whole samples (BM >= H * W: NSEG segments of SEG = H rows, each with its own halo rows) and
+// the channel blocks may be split over blockIdx.z (fp32 slabs, reduced by k_splitk_reduce*, conv.hip).
+template <typename T, int BM, int W_, int BN, int WGM, int WGN, int NPROD, int STAGES, int MINW, int MF, int TPS>
 __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP p) {
   typedef Mma<T> MM;
   typedef typename MM::Chunk Chunk;
   constexpr int NWC = WGM * WGN;
   constexpr int EPC = MM::EPC, KSTEP = 8 * EPC, ESZ = (int)sizeof(T);
   constexpr int WMS = BM / WGM, WNS = BN / WGN, TM = WMS / MF, TN = WNS / MF;
-  constexpr int ROWS = BM / W_, PW = W_ + 2, PR = ROWS + 2, NPQ = PR * PW, NPI = (NPQ + 7) / 8;
+  constexpr int ROWS = BM / W_, SEG = ROWS < W_ ? ROWS : W_, NSEG = ROWS / SEG;      // planes are square: H == W_
+  constexpr int PW = W_ + 2, PR = NSEG * (SEG + 2), NPQ = PR * PW, NPI = (NPQ + 7) / 8;
   constexpr int PATCH = NPI * 1024;
-  constexpr int WI = BN / 8, WPW = WI / NPROD, PPW = (NPI + NPROD - 1) / NPROD;
-  constexpr int W_STAGE = BN * 128;
+  constexpr int SPC = 9 / TPS;                                   // K steps per channel block
+  constexpr int WIT = BN / 8;                                    // weight instructions per tap
+  constexpr int WI = TPS * WIT, WPW = WI / NPROD, PPW = (NPI + NPROD - 1) / NPROD;
+  constexpr int W_TAP = BN * 128, W_STAGE = TPS * W_TAP;
   constexpr int LDS_TOTAL = 2 * PATCH + STAGES * W_STAGE;
   constexpr unsigned OOB = 0x80000000u;
   static_assert(MF == 16 || MF == 32, "MFMA flavour");
-  static_assert(BM % W_ == 0 && WI % NPROD == 0 && WMS % MF == 0 && WNS % MF == 0, "tile shape");
+  static_assert(TPS == 1 || TPS == 3, "taps per step");
+  static_assert(BM % W_ == 0 && ROWS % SEG == 0 && WI % NPROD == 0 && WMS % MF == 0 && WNS % MF == 0, "tile shape");
   static_assert((STAGES - 2) * WPW + PPW < 64, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -104,10 +112,13 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int Ct = p.C1, HW = p.H * W_;
-  const int ncb = Ct / KSTEP, G = ncb * 9;
+  const int Ct = p.C1, HW = W_ * W_;
+  const int ncb = Ct / KSTEP;
+  const int ks = blockIdx.z;
+  const int cb_lo = (ncb * ks) / p.splitk, cb_hi = (ncb * (ks + 1)) / p.splitk;   // this slice's channel blocks
+  const int G = (cb_hi - cb_lo) * SPC;
   const int b_tile = m0 / HW;
-  const int oh0 = (m0 - b_tile * HW) / W_;
+  const int oh0 = NSEG == 1 ? (m0 - b_tile * HW) / W_ : 0;      // first image row of the (single) segment
 
   if (is_producer) {
     const int wave = wave_all - NWC;
@@ -125,36 +136,38 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
       const int q = 8 * j + (lane >> 3);
       const int c = h_chunk_at<MF>(lane & 7, q);
       const int pr = q / PW, pc = q - pr * PW;
-      const int ih = oh0 + pr - 1;
-      const bool ok = q < NPQ && pc >= 1 && pc <= W_ && ih >= 0 && ih < p.H;
-      const int pixel = m0 + (pr - 1) * W_ + (pc - 1);
+      const int sg = pr / (SEG + 2), jj = pr - sg * (SEG + 2);            // segment (one sample's rows) and row inside it
+      const int ih = oh0 + jj - 1;
+      const bool ok = q < NPQ && pc >= 1 && pc <= W_ && ih >= 0 && ih < W_;
+      const int pixel = m0 + (sg * SEG + jj - 1) * W_ + (pc - 1);
       poff[i] = ok ? ((unsigned)pixel * (unsigned)Ct + (unsigned)(c * EPC)) * ESZ : OOB;
     }
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
-      const int r = 8 * (wave + NPROD * i) + (lane >> 3);      // weight row inside the BN slice
+      const int j = wave + NPROD * i;                            // instruction inside the stage: (tap in step, row group)
+      const int tis = j / WIT, r = 8 * (j - tis * WIT) + (lane >> 3);
       const int c = h_chunk_at<MF>(lane & 7, r);
-      woff[i] = ((unsigned)(n0 + r) * 9u * (unsigned)Ct + (unsigned)(c * EPC)) * ESZ;
+      woff[i] = (((unsigned)(n0 + r) * 9u + (unsigned)tis) * (unsigned)Ct + (unsigned)(c * EPC)) * ESZ;
     }
     // cursor of the next weight step to issue
-    int is_g = 0, is_tap = 0, is_cb = 0, is_slot = 0;
+    int is_g = 0, is_st = 0, is_cb = cb_lo, is_slot = 0;
     auto issue_weights = [&]() {
       char* sbase = smem + 2 * PATCH + is_slot * W_STAGE;
-      const unsigned so = is_g < G ? (unsigned)((is_tap * Ct + is_cb * KSTEP) * ESZ) : OOB;
+      const unsigned so = is_g < G ? (unsigned)((is_st * TPS * Ct + is_cb * KSTEP) * ESZ) : OOB;
 #pragma unroll
       for (int i = 0; i < WPW; ++i) {
         lds_ptr_t dst = (lds_ptr_t)(sbase + (wave + NPROD * i) * 1024);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, dst, 16, (int)woff[i], (int)so, 0, 0);
       }
       ++is_g;
-      if (++is_tap == 9) {
-        is_tap = 0;
+      if (++is_st == SPC) {
+        is_st = 0;
         ++is_cb;
       }
       is_slot = is_slot + 1 == STAGES ? 0 : is_slot + 1;
     };
     auto issue_patch = [&](int cb) {
-      char* sbase = smem + (cb & 1) * PATCH;
+      char* sbase = smem + ((cb - cb_lo) & 1) * PATCH;
       const unsigned so = (unsigned)(cb * KSTEP * ESZ);
 #pragma unroll
       for (int i = 0; i < PPW; ++i) {
@@ -162,22 +175,26 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, dst, 16, (int)poff[i], (int)so, 0, 0);
       }
     };
-    issue_patch(0);
+    issue_patch(cb_lo);
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s) issue_weights();
-    int tap = 0, cb = 0;
+    int st = 0, cb = cb_lo, since = STAGES;                      // K steps since the last patch issue (in the loop)
     for (int g = 0; g < G; ++g) {
-      // in flight behind the weights of step g: the weights of steps g+1 .. g+STAGES-2, and - during taps
-      // 1 .. STAGES-1 of a channel block - the next block's patch (issued at tap 0, behind step g+STAGES-1's weights)
-      if (tap >= 1 && tap <= STAGES - 1 && cb + 1 < ncb) wait_vmcnt<(STAGES - 2) * WPW + PPW>();
+      // in flight behind the weights of step g: the weights of steps g+1 .. g+STAGES-2, and - for the STAGES-1 steps
+      // after a patch issue - that patch (issued behind step g+STAGES-1's weights of its iteration)
+      if (since <= STAGES - 1) wait_vmcnt<(STAGES - 2) * WPW + PPW>();
       else wait_vmcnt<(STAGES - 2) * WPW>();
       __builtin_amdgcn_s_barrier();
+      ++since;
       if (!(p.dbg & 1)) {
         issue_weights();
-        if (tap == 0 && cb + 1 < ncb) issue_patch(cb + 1);
+        if (st == 0 && cb + 1 < cb_hi) {
+          issue_patch(cb + 1);
+          since = 1;
+        }
       }
-      if (++tap == 9) {
-        tap = 0;
+      if (++st == SPC) {
+        st = 0;
         ++cb;
       }
     }
@@ -188,7 +205,6 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
   // ------------------------------------------------------------------------------------------- consumers
   const int cw = wave_all, wm = cw / WGN, wn = cw - wm * WGN;
   constexpr int NKK = MF == 16 ? 2 : 4;                          // fragment K steps inside a 128-byte row
-  constexpr int KXOR = MF == 16 ? 32 : 32;                       // K step kk of a fragment: byte address ^ (kk << 5)
   constexpr int NACC = MF * MF / 64;                             // accumulator floats per lane and tile
   constexpr int RQ = NACC / 4;                                   // cout quads per lane and tile
   typedef __attribute__((ext_vector_type(NACC))) float AccT;
@@ -197,15 +213,16 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
   for (int t = 0; t < TM; ++t) {
     const int pix = wm * WMS + t * MF + li;
     const int r = pix / W_, c = pix - r * W_;
-    qb[t] = r * PW + c;
+    const int sg = r / SEG, rr = r - sg * SEG;
+    qb[t] = (sg * (SEG + 2) + rr) * PW + c;
   }
-  // fragment address of (row q, K step kk) = q * 128 + (h_pos(chunk(kk, lg), q) << 4) = (q * 128 + (h_pos(chunk(0, lg), q) << 4)) ^ (kk << 5)
-  // in both flavours (kk only enters position bit 1 for MF = 16 and bits 1..2 for MF = 32)
+  // fragment address of (row q, K step kk) = (q * 128 + (h_pos(chunk(0, lg), q) << 4)) ^ (kk << 5) in both flavours
   auto frag_off = [&](int q) { return q * 128 + (h_pos<MF>(lg, q) << 4); };
   const int a_off0 = frag_off(wn * WNS + li);                    // + t * MF * 128 for weight tile t ((row >> 1) & 7 depends on li only)
 
   // The accumulators START from the residual (fragment layout): its load latency runs under the prologue of the
   // LDS-DMA pipeline, when the consumers have nothing to do, instead of in the epilogue; residual + sum, fp32.
+  // (split-K: the slabs carry plain partial sums, the reduction kernel adds the epilogue terms)
   auto cout_of = [&](int tn, int rq) { return n0 + wn * WNS + tn * MF + (MF == 16 ? 4 * lg : 8 * rq + 4 * lg); };
   AccT acc[TN][TM];
 #pragma unroll
@@ -214,7 +231,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
     for (int b = 0; b < TM; ++b)
 #pragma unroll
       for (int e = 0; e < NACC; ++e) acc[a][b][e] = 0.f;
-  if (p.residual) {
+  if (p.residual && p.splitk == 1) {
     const T* res = (const T*)p.residual;
 #pragma unroll
     for (int a = 0; a < TN; ++a)
@@ -230,34 +247,45 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
   }
 
   {
-    int slot = 0, tap = 0, kh = 0, kw = 0, pbuf = 0;
+    int slot = 0, st = 0, pbuf = 0;
     for (int g = 0; g < G; ++g) {
       __builtin_amdgcn_s_barrier();
       if (!(p.dbg & 2)) {
         const char* sP = smem + pbuf * PATCH;
         const char* sW = smem + 2 * PATCH + slot * W_STAGE;
-        const int tapoff = kh * PW + kw;
-        int boff[TM];
+        int boff[TPS][TM];
 #pragma unroll
-        for (int t = 0; t < TM; ++t) boff[t] = frag_off(qb[t] + tapoff);
-        // hand-ordered fragment pipeline: the NKK x TN MFMA groups of the step (one weight fragment x TM pixel
-        // fragments each) run back to back; weight fragment i + AD is requested when group i starts, the pixel
-        // fragments of K step kk + 1 during the groups of kk.  (Left alone the compiler rotates two weight buffers
-        // with a distance of ONE group: every group then waits out an LDS round trip.)
-        constexpr int NG = NKK * TN, AD = 3;
-        Chunk af[NG], bf[NKK][TM];
-        auto lda = [&](int i) { return ld16<Chunk>(sW + ((a_off0 + (i % TN) * MF * 128) ^ ((i / TN) * KXOR))); };
+        for (int ti = 0; ti < TPS; ++ti) {
+          const int tap = st * TPS + ti;                         // TPS == 3: kh = st, kw = ti
+          const int tapoff = (tap / 3) * PW + (tap - (tap / 3) * 3);
 #pragma unroll
-        for (int t = 0; t < TM; ++t) bf[0][t] = ld16<Chunk>(sP + boff[t]);
+          for (int t = 0; t < TM; ++t) boff[ti][t] = frag_off(qb[t] + tapoff);
+        }
+        // hand-ordered fragment pipeline over the step's TPS x NKK phases of TN MFMA groups (one weight fragment x TM
+        // pixel fragments each): weight fragment i + AD is requested when group i starts, the pixel fragments of the
+        // next phase in the middle of the current one.  (Left alone the compiler rotates two weight buffers with a
+        // distance of ONE group: every group then waits out an LDS round trip.)
+        constexpr int NPH = TPS * NKK, NG = NPH * TN, AD = 3;
+        Chunk af[NG], bf[NPH][TM];
+        auto lda = [&](int i) {
+          const int ph = i / TN, ti = ph / NKK, kk = ph - ti * NKK;
+          return ld16<Chunk>(sW + ti * W_TAP + ((a_off0 + (i - ph * TN) * MF * 128) ^ (kk << 5)));
+        };
+        auto ldb = [&](int ph, int t) {
+          const int ti = ph / NKK, kk = ph - ti * NKK;
+          return ld16<Chunk>(sP + (boff[ti][t] ^ (kk << 5)));
+        };
+#pragma unroll
+        for (int t = 0; t < TM; ++t) bf[0][t] = ldb(0, t);
 #pragma unroll
         for (int i = 0; i < AD; ++i) af[i] = lda(i);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
           if (i + AD < NG) af[i + AD] = lda(i + AD);
-          if (i % TN == TN / 2 && i / TN + 1 < NKK) {
+          if (i % TN == TN / 2 && i / TN + 1 < NPH) {
 #pragma unroll
-            for (int t = 0; t < TM; ++t) bf[i / TN + 1][t] = ld16<Chunk>(sP + (boff[t] ^ ((i / TN + 1) * KXOR)));
+            for (int t = 0; t < TM; ++t) bf[i / TN + 1][t] = ldb(i / TN + 1, t);
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -269,13 +297,8 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
         }
       }
       slot = slot + 1 == STAGES ? 0 : slot + 1;
-      if (++kw == 3) {
-        kw = 0;
-        ++kh;
-      }
-      if (++tap == 9) {
-        tap = 0;
-        kh = 0;
+      if (++st == SPC) {
+        st = 0;
         pbuf ^= 1;
       }
     }
@@ -303,7 +326,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
     float bvec[EO], ss1[EO], ss2[EO];
 #pragma unroll
     for (int e = 0; e < EO; ++e) bvec[e] = ss1[e] = ss2[e] = 0.f;
-    if (active) {
+    if (active && p.splitk == 1) {
       if (p.bias) {
 #pragma unroll
         for (int q = 0; q < EO / 4; ++q) {
@@ -336,6 +359,17 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
           }
       }
       __syncthreads();
+      if (p.splitk > 1) {
+        // split-K slab: fp32 rows, 16 bytes per lane
+        constexpr int QPR = BN / 4;
+#pragma unroll 1
+        for (int i = etid; i < PROWS * QPR; i += NTC) {
+          const int row = i / QPR, q = i - row * QPR;
+          const f32x4 a = *reinterpret_cast<const f32x4*>(sC + row * SROW + 4 * q);
+          *reinterpret_cast<f32x4*>(p.ws + ((size_t)ks * p.M + m0 + ps * PROWS + row) * p.Cout + n0 + 4 * q) = a;
+        }
+        continue;
+      }
       if (active) {
 #pragma unroll 2
         for (int row = tr; row < PROWS; row += RPI) {
@@ -361,7 +395,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
         }
       }
     }
-    if (p.stats_out) {
+    if (p.stats_out && p.splitk == 1) {
       // per-channel sums of this tile's BM rows (one split of one sample): the RPI row-interleaved partials of a
       // column are added in a fixed order through LDS
       float* sR = sC;   // [RPI][BN][2]
@@ -387,22 +421,35 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
 
 // ----------------------------------------------------------------------------------------------- host side
 struct H3Variant {
-  int bm, w, wgm, wgn, mf;
+  int bm, w, bn, wgm, wgn, mf, tps;
 };
 // ids kConv3hFirst + index
 static const H3Variant kH3[] = {
-    {256, 32, 4, 2, 16},   // 41: 32x32 planes, 8 rows per tile; 8 consumer waves (64 x 96 each) + 4 producers
-    {128, 16, 2, 4, 16},   // 42: 16x16 planes, 8 rows per tile; 8 consumers (64 x 48) + 4 producers
-    {128, 16, 2, 2, 16},   // 43: 16x16 planes; 4 consumers (64 x 96) + 4 producers
-    {256, 16, 4, 2, 16},   // 44: 16x16 planes, whole sample per tile
-    {128, 32, 2, 4, 16},   // 45: 32x32 planes, 4 rows per tile
-    {128, 32, 2, 2, 16},   // 46
-    {256, 32, 4, 2, 32},   // 47: as 41 on 32x32x16 MFMAs
-    {128, 16, 2, 2, 32},   // 48: as 43 on 32x32x16 MFMAs
-    {256, 16, 4, 2, 32},   // 49: as 44 on 32x32x16 MFMAs
-    {128, 32, 2, 2, 32},   // 50: as 46 on 32x32x16 MFMAs
+    {256, 32, 192, 4, 2, 16, 1},   // 41: 32x32 planes, 8 rows per tile; 8 consumer waves (64 x 96 each) + 4 producers
+    {128, 16, 192, 2, 4, 16, 1},   // 42: 16x16 planes, 8 rows per tile; 8 consumers (64 x 48) + 4 producers
+    {128, 16, 192, 2, 2, 16, 1},   // 43: 16x16 planes; 4 consumers (64 x 96) + 4 producers
+    {256, 16, 192, 4, 2, 16, 1},   // 44: 16x16 planes, whole sample per tile
+    {128, 32, 192, 2, 4, 16, 1},   // 45: 32x32 planes, 4 rows per tile
+    {128, 32, 192, 2, 2, 16, 1},   // 46
+    {256, 32, 192, 4, 2, 32, 1},   // 47: as 41 on 32x32x16 MFMAs
+    {128, 16, 192, 2, 2, 32, 1},   // 48: as 43 on 32x32x16 MFMAs
+    {256, 16, 192, 4, 2, 32, 1},   // 49: as 44 on 32x32x16 MFMAs
+    {128, 32, 192, 2, 2, 32, 1},   // 50: as 46 on 32x32x16 MFMAs
+    {64, 8, 96, 2, 2, 16, 3},      // 51: 8x8 planes, one sample x 96 couts per tile, 3 taps per step, no split-K
+    {64, 4, 96, 2, 2, 16, 3},      // 52: 4x4 planes, four samples x 96 couts per tile, 3 taps per step, split-K 2
+    {64, 8, 96, 2, 2, 16, 3},      // 53: (= 51; a 192-cout tile with 3 taps per step does not fit the LDS)
+    {128, 16, 96, 2, 2, 16, 3},    // 54: 16x16 planes, 8 rows x 96 couts, 3 taps per step (small batches)
+    {128, 32, 96, 2, 2, 16, 3},    // 55: 32x32 planes, 4 rows x 96 couts (small batches)
 };
 constexpr int kNumH3 = (int)(sizeof(kH3) / sizeof(kH3[0]));
+
+int conv3h_tile(int variant, int* bm, int* bn) {
+  const int k = variant - kConv3hFirst;
+  if (k < 0 || k >= kNumH3) return 0;
+  *bm = kH3[k].bm;
+  *bn = kH3[k].bn;
+  return 1;
+}
 
 bool conv3h_supported(int variant, int dtype_size, const ConvP& p) {
   const int k = variant - kConv3hFirst;
@@ -411,45 +458,54 @@ bool conv3h_supported(int variant, int dtype_size, const ConvP& p) {
   const int kstep = 128 / dtype_size;
   const int eo = 16 / dtype_size;
   const int HW = p.H * p.W;
-  return p.KS == 3 && p.C2 == 0 && p.W == v.w && p.H == p.W && HW % v.bm == 0 && p.M % v.bm == 0 && p.Cout % 192 == 0 &&
-         p.C1 % kstep == 0 && p.out_mode == 0 && !p.y2 && p.y_ld % eo == 0 && (!p.residual || p.res_ld % eo == 0) &&
-         (!p.temb || (p.temb_stride % eo == 0 && p.temb_mod % eo == 0)) && (long long)p.M * p.C1 * dtype_size < (1ll << 31) &&
-         (long long)p.Cout * 9 * p.C1 * dtype_size < (1ll << 31) && aligned16(p.y) && aligned16(p.x1) && aligned16(p.w);
+  const int z = p.splitk > 0 ? p.splitk : 1;
+  const bool tile_ok = HW % v.bm == 0 || (v.bm % HW == 0 && z > 1);    // several samples per tile: only as split-K slabs
+  return p.KS == 3 && p.C2 == 0 && p.W == v.w && p.H == p.W && tile_ok && p.M % v.bm == 0 && p.Cout % v.bn == 0 &&
+         p.C1 % kstep == 0 && (p.C1 / kstep) % z == 0 && p.out_mode == 0 && !p.y2 && p.y_ld % eo == 0 &&
+         (!p.residual || p.res_ld % eo == 0) && (!p.temb || (p.temb_stride % eo == 0 && p.temb_mod % eo == 0)) &&
+         (long long)p.M * p.C1 * dtype_size < (1ll << 31) && (long long)p.Cout * 9 * p.C1 * dtype_size < (1ll << 31) &&
+         p.Cout % 4 == 0 && aligned16(p.y) && aligned16(p.x1) && aligned16(p.w);
 }
 
-template <typename T, int BM, int W_, int WGM, int WGN, int MF>
+template <typename T, int BM, int W_, int BN, int WGM, int WGN, int MF, int TPS>
 static void launch_h3(const ConvP& p0, hipStream_t st) {
-  constexpr int BN = 192, NPROD = 4, STAGES = 3;
+  constexpr int NPROD = 4, STAGES = 3;
   constexpr int NWC = WGM * WGN;
   constexpr int MINW = (NWC + NPROD + 3) / 4;
-  constexpr int NPI = ((BM / W_ + 2) * (W_ + 2) + 7) / 8;
-  constexpr int lds = 2 * NPI * 1024 + STAGES * BN * 128;
+  constexpr int ROWS = BM / W_, SEG = ROWS < W_ ? ROWS : W_, NSEG = ROWS / SEG;
+  constexpr int NPI = (NSEG * (SEG + 2) * (W_ + 2) + 7) / 8;
+  constexpr int lds = 2 * NPI * 1024 + STAGES * TPS * BN * 128;
   ConvP p = p0;
   p.tiles_n = p.Cout / BN;
-  p.splitk = 1;
+  if (p.splitk < 1) p.splitk = 1;
   const int tiles = (p.M / BM) * p.tiles_n;
-  auto kern = k_conv3h<T, BM, W_, BN, WGM, WGN, NPROD, STAGES, MINW, MF>;
+  auto kern = k_conv3h<T, BM, W_, BN, WGM, WGN, NPROD, STAGES, MINW, MF, TPS>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  kern<<<tiles, (NWC + NPROD) * 64, lds, st>>>(p);
+  kern<<<dim3(tiles, 1, p.splitk), (NWC + NPROD) * 64, lds, st>>>(p);
 }
 
 template <typename T>
 static void launch_h3_variant(int k, const ConvP& p, hipStream_t st) {
   switch (k) {
-    case 0: launch_h3<T, 256, 32, 4, 2, 16>(p, st); break;
-    case 1: launch_h3<T, 128, 16, 2, 4, 16>(p, st); break;
-    case 2: launch_h3<T, 128, 16, 2, 2, 16>(p, st); break;
-    case 3: launch_h3<T, 256, 16, 4, 2, 16>(p, st); break;
-    case 4: launch_h3<T, 128, 32, 2, 4, 16>(p, st); break;
-    case 5: launch_h3<T, 128, 32, 2, 2, 16>(p, st); break;
-    case 6: launch_h3<T, 256, 32, 4, 2, 32>(p, st); break;
-    case 7: launch_h3<T, 128, 16, 2, 2, 32>(p, st); break;
-    case 8: launch_h3<T, 256, 16, 4, 2, 32>(p, st); break;
-    case 9: launch_h3<T, 128, 32, 2, 2, 32>(p, st); break;
+    case 0: launch_h3<T, 256, 32, 192, 4, 2, 16, 1>(p, st); break;
+    case 1: launch_h3<T, 128, 16, 192, 2, 4, 16, 1>(p, st); break;
+    case 2: launch_h3<T, 128, 16, 192, 2, 2, 16, 1>(p, st); break;
+    case 3: launch_h3<T, 256, 16, 192, 4, 2, 16, 1>(p, st); break;
+    case 4: launch_h3<T, 128, 32, 192, 2, 4, 16, 1>(p, st); break;
+    case 5: launch_h3<T, 128, 32, 192, 2, 2, 16, 1>(p, st); break;
+    case 6: launch_h3<T, 256, 32, 192, 4, 2, 32, 1>(p, st); break;
+    case 7: launch_h3<T, 128, 16, 192, 2, 2, 32, 1>(p, st); break;
+    case 8: launch_h3<T, 256, 16, 192, 4, 2, 32, 1>(p, st); break;
+    case 9: launch_h3<T, 128, 32, 192, 2, 2, 32, 1>(p, st); break;
+    case 10: launch_h3<T, 64, 8, 96, 2, 2, 16, 3>(p, st); break;
+    case 11: launch_h3<T, 64, 4, 96, 2, 2, 16, 3>(p, st); break;
+    case 12: launch_h3<T, 64, 8, 96, 2, 2, 16, 3>(p, st); break;
+    case 13: launch_h3<T, 128, 16, 96, 2, 2, 16, 3>(p, st); break;
+    case 14: launch_h3<T, 128, 32, 96, 2, 2, 16, 3>(p, st); break;
   }
 }
 

@@ -43,7 +43,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // halo-patch 3x3 convolution (conv3h.hip): variant ids >= kConv3hFirst of the conv variant table
 constexpr int kConv3hFirst = 41;
-bool conv3h_supported(int variant, int dtype_size, const ConvP& p);
+bool conv3h_supported(int variant, int dtype_size, const ConvP& p);      // p.splitk = the planned K slices
+int conv3h_tile(int variant, int* bm, int* bn);
 void conv3h_launch(int variant, int dtype_size, const ConvP& p, hipStream_t st);
 
 }  // namespace afldm

@@ -235,6 +235,9 @@ int afldm_conv2d_tune(int variant, int splitk);
 /* Enable (1) / disable (0, the default) the in-kernel split-K reduction for calls that pass `sync` words: measured
  * slower than the two-launch form on MI355X, kept as a tested option. */
 int afldm_conv2d_fused_splitk(int enable);
+/* How afldm_conv2d will run this problem (tests / tuning tools): GEMM tile variant | split-K slices << 8 | in-kernel
+ * reduction << 16; < 0 for the direct (non-GEMM) kernels. */
+int afldm_conv2d_variant(const afldm_conv_args* args);
 /* bytes of split-K workspace afldm_conv2d may use for this problem (0 if none). */
 size_t afldm_conv2d_workspace(const afldm_conv_args* args);
 /* split count S of the statistics afldm_conv2d writes to stats_out for this problem (> 0). */

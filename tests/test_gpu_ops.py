@@ -302,7 +302,7 @@ def test_conv2d_every_gemm_variant(dtype):
                 close(back(y), ref, dtype, f"conv variant {v} splitk {sk}", bf16_rms=6e-3)
     finally:
         _lib.lib.afldm_conv2d_tune(-1, -1)
-    assert nvar >= 50
+    assert nvar >= 55
 
 
 @pytest.mark.parametrize("case", [
@@ -415,6 +415,12 @@ H3_CASES = [
     (2, 32, 64, 384, True, True, (41, 45, 46, 47, 50)),
     (3, 16, 384, 384, True, True, (42, 43, 44, 48, 49)),
     (5, 16, 128, 192, False, False, (42, 43, 44, 48, 49)),
+    (5, 8, 384, 384, True, True, (51,)),          # small-plane variants: one 8x8 sample per tile, 3 taps per step
+    (3, 8, 768, 96, False, True, (51,)),
+    (8, 4, 768, 768, True, True, (52,)),             # four 4x4 samples per tile, channel blocks split over 2-4 slices
+    (4, 4, 256, 96, False, False, (52,)),
+    (2, 16, 384, 96, True, True, (54,)),
+    (2, 32, 192, 288, True, True, (55,)),
 ]
 
 
@@ -443,11 +449,18 @@ def test_conv3x3_halo_patch_variants(dtype, case):
     rh = nhwc(res, dtype) if use_res else None
     try:
         for v in variants:
-            _lib.check(_lib.lib.afldm_conv2d_tune(v, 1), "tune")
+            _lib.check(_lib.lib.afldm_conv2d_tune(v, -1), "tune")
             ys = [ops.conv2d(xh, wp, b.cuda(), temb=th, temb_stride=Cout if use_temb else 0, residual=rh, want_stats=True)
                   for _ in range(2)]
-            bm = 256 if v in (41, 44, 47, 49) else 128
-            assert ys[0].gn_partial.shape == (B, N * N // bm, Cout, 2), (v, ys[0].gn_partial.shape)     # the halo kernel ran
+            import ctypes
+            probe = ops.conv_args(xh, wp, b.cuda(), temb=th, temb_stride=Cout if use_temb else 0, residual=rh, out=ys[0])
+            probe.workspace, probe.workspace_bytes = _lib.ptr(torch.empty(1 << 24, device="cuda")), 1 << 26
+            code = _lib.lib.afldm_conv2d_variant(ctypes.byref(probe))
+            assert code & 255 == v, "the halo variant did not run this shape"
+            split = (code >> 8) & 255
+            bm = 256 if v in (41, 44, 47, 49) else 64 if v in (51, 52, 53) else 128
+            if split == 1:    # (with K slices the statistics come from the reduction kernel)
+                assert ys[0].gn_partial.shape == (B, N * N // bm, Cout, 2), (v, ys[0].gn_partial.shape)     # the halo kernel ran
             close(back(ys[0]), ref, dtype, f"conv3h variant {v} {case}", bf16_rms=6e-3)
             assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0].gn_partial, ys[1].gn_partial)
             yv = ys[0].float()
