@@ -768,9 +768,9 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
         // rows of a thread: every RPI-th one; CONSECUTIVE ones when the tile spans several whole samples and
         // statistics are wanted (p.stats_multi), so that all rows of a thread lie in one sample
         constexpr int RPT = PROWS / RPI;
-        const int row_first = p.stats_multi ? (etid / CPR) * RPT : etid / CPR;
-        const int row_step = p.stats_multi ? 1 : RPI;
-        const int row_end = p.stats_multi ? row_first + RPT : PROWS;
+        const int row_first = p.stats_multi == 1 ? (etid / CPR) * RPT : etid / CPR;
+        const int row_step = p.stats_multi == 1 ? 1 : RPI;
+        const int row_end = p.stats_multi == 1 ? row_first + RPT : PROWS;
 #pragma unroll 1
         for (int row = row_first; row < row_end; row += row_step) {
           const int mt = row / (TMP * 16), rr = row - mt * (TMP * 16);
@@ -806,7 +806,15 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
 #pragma unroll
             for (int e = 0; e < EO; ++e) o[e] = from_f32<T>(v[e]);
             st16<Chunk>((T*)p.y + (size_t)m * p.y_ld + n, o);
-            if (p.stats_out) {
+            if (p.stats_out && p.stats_multi == 2) {
+              // H * W == 1 (a dense layer over a flattened plane): every row is a sample of its own, its "sums" are the
+              // values themselves (S = 1)
+#pragma unroll
+              for (int e = 0; e < EO; e += 2) {
+                const float v0 = to_f32(o[e]), v1 = to_f32(o[e + 1]);
+                *reinterpret_cast<f32x4*>(p.stats_out + ((size_t)m * p.Cout + n + e) * 2) = f32x4{v0, v0 * v0, v1, v1 * v1};
+              }
+            } else if (p.stats_out) {
 #pragma unroll
               for (int e = 0; e < EO; ++e) {
                 const float vr = to_f32(o[e]);      // statistics of what the consumer will read
@@ -868,7 +876,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
       if (p.sync) splitk_fused_reduce<T, BM, BN, NTC>(p, m0, n0, ks, tile, etid, sC);
       return;
     }
-    if (p.stats_out) {
+    if (p.stats_out && p.stats_multi != 2) {
       // per-channel sums of this tile (BM rows of ONE sample: the host only asks when H*W % BM == 0):
       // the RPI row-interleaved partials of a column are added in a fixed order through LDS
       float* sR = sC;   // [RPI][BN][2]
@@ -880,7 +888,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
           *reinterpret_cast<f32x2*>(sR + ((tr * BN) + ch * EO + e) * 2) = f32x2{ss1[e], ss2[e]};
       }
       __syncthreads();
-      if (p.stats_multi) {
+      if (p.stats_multi == 1) {
         // the tile holds BM / HW whole samples (S = 1): row lane tr owns rows tr * RPT .. + RPT - 1
         constexpr int RPT = PROWS / RPI;
         const int ns = BM / HW, lanes_per_sample = HW / RPT;
@@ -1580,6 +1588,7 @@ static const Variant kVariants[] = {
     {64, 96, 6, 3},    // 53  = 51
     {128, 96, 6, 3},   // 54  16x16 planes, 8 rows x 96 couts (small batches)
     {128, 96, 6, 3},   // 55  32x32 planes, 4 rows x 96 couts (small batches)
+    {64, 32, 4, 12},   // 56  64x32 tiles, 12 stages (a skinny GEMM's K step costs DMA latency / ring depth): dense layers over <= 64 rows (the 2x2 level at batch 64) WITHOUT split-K
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -1620,6 +1629,7 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
     const int bm_ = kVariants[v].bm, bn_ = kVariants[v].bn;
     const long long tiles = ((M + bm_ - 1) / bm_) * ((a->Cout + bn_ - 1) / bn_);
     int sk = 1;
+    if (v == 56) return 1;
     if (kVariants[v].ver == 6) {
       // halo-patch kernel: the small-tile variants (51+) may split the CHANNEL BLOCKS over up to 4 slices when the
       // tiles alone leave most CUs idle; the slice count must divide the number of 128-byte channel blocks
@@ -1668,6 +1678,14 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
         else if (a->W == 4 && M >= 64) vid = 52;
       }
     }
+  }
+  {
+    // a dense layer over <= 64 rows (the 3x3 convolutions of the 2x2 level in their flattened form at batch 64) on 96+
+    // 64x32 tiles that walk the whole K themselves (no slabs, no reduction launch): MEASURED SLOWER - 28.7 us kernel-only
+    // against 11.1 + 4.3 us for four slices of 64x64 tiles (a K step of this skinny tile costs ~0.6 us whatever the
+    // ring depth: 4 and 12 stages measure the same), 5.39 vs 5.26 ms/step.  Off unless AFLDM_DENSE_NOSPLIT is set.
+    static const bool off = getenv("AFLDM_DENSE_NOSPLIT") == nullptr;
+    if (!off && a->KS == 1 && a->H * a->W == 1 && M <= 64 && a->Cout >= 2048 && a->Cout % 32 == 0) vid = 56;
   }
   // in-situ tuning hook (tools/tune_insitu.py): AFLDM_CONV_OVERRIDE="M:Cout:KS:Ct=variant/splitk;..."
   int ov_sk = -1;
@@ -1758,6 +1776,10 @@ static bool igemm3_ok(const afldm_conv_args* a) {
 
 template <typename T>
 static bool launch_variant(int id, const ConvP& p, hipStream_t st) {
+  if (id == 56) {
+    launch_igemm2<T, 64, 32, 2, 2, 12, 2, 0, true>(p, st);
+    return true;
+  }
   if (id >= kConv3hFirst) {
     conv3h_launch(id, (int)sizeof(T), p, st);
     return true;
@@ -1932,6 +1954,11 @@ static int stats_mode(const afldm_conv_args* a, const Exec& e, int* S) {
     *S = HW / kVariants[e.vid].bm;
     return ST_EPILOGUE;
   }
+  if (e.pl.kind == 0 && e.splitk == 1 && kVariants[e.vid].ver >= 2 && kVariants[e.vid].ver <= 4 && HW == 1 && vec16 &&
+      !getenv("AFLDM_CONV_NOSTAGE")) {
+    *S = 1;           // H * W == 1: a row is a sample, written straight from the epilogue (stats_multi 2)
+    return ST_EPILOGUE;
+  }
   if (cin4_mfma_ok<T>(a)) {
     *S = HW / CIN4_BM;
     return ST_EPILOGUE;
@@ -2026,7 +2053,7 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
     p.splitk = ex.splitk;
     if (smode == ST_EPILOGUE) {
       p.stats_out = a->stats_out;
-      p.stats_multi = (a->H * a->W) < kVariants[ex.vid].bm ? 1 : 0;
+      p.stats_multi = (a->H * a->W) == 1 ? 2 : (a->H * a->W) < kVariants[ex.vid].bm ? 1 : 0;
     }
     p.sync = ex.fused ? a->sync : nullptr;
     if (ex.fused && smode == ST_FUSED) p.stats_out = a->stats_out;

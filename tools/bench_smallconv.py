@@ -26,7 +26,10 @@ def main():
     dt = torch.bfloat16
     iters = int(os.environ.get("ITERS", 30))
     forced = os.environ.get("FORCE")      # "variant/splitk"
+    only = [t for t in os.environ.get("ONLY", "").split(",") if t]
     for name, B, N, Cin, Cout, KS in SHAPES:
+        if only and not any(name.startswith(t) for t in only):
+            continue
         x = torch.randn(B, N, N, Cin, device="cuda").to(dt)
         w = (torch.randn(Cout, KS, KS, Cin, device="cuda") / (KS * Cin ** 0.5)).to(dt)
         bias = torch.randn(Cout, device="cuda")
