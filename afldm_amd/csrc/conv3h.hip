@@ -220,8 +220,10 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
   auto frag_off = [&](int q) { return q * 128 + (h_pos<MF>(lg, q) << 4); };
   const int a_off0 = frag_off(wn * WNS + li);                    // + t * MF * 128 for weight tile t ((row >> 1) & 7 depends on li only)
 
-  // The accumulators START from the residual (fragment layout): its load latency runs under the prologue of the
-  // LDS-DMA pipeline, when the consumers have nothing to do, instead of in the epilogue; residual + sum, fp32.
+  // The residual enters through the ACCUMULATORS (fragment layout), a few tiles per K step during the first NRS
+  // steps: requested at the top of step s, added at the top of step s + 1 - its latency runs under MFMA work instead
+  // of in the epilogue (one dependent global load per copied row was most of the fixed cost of a residual
+  // convolution) or in front of the first step.  residual + sum of products, fp32.
   // (split-K: the slabs carry plain partial sums, the reduction kernel adds the epilogue terms)
   auto cout_of = [&](int tn, int rq) { return n0 + wn * WNS + tn * MF + (MF == 16 ? 4 * lg : 8 * rq + 4 * lg); };
   AccT acc[TN][TM];
@@ -231,7 +233,16 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
     for (int b = 0; b < TM; ++b)
 #pragma unroll
       for (int e = 0; e < NACC; ++e) acc[a][b][e] = 0.f;
-  if (p.residual && p.splitk == 1) {
+  constexpr int NRT = TN * TM * RQ;                              // residual quads per lane
+  constexpr int NRS = TPS == 1 ? 8 : 3;                          // steps they are spread over (G >= 9 / 3)
+  constexpr int RCH = (NRT + NRS - 1) / NRS;
+  typedef __attribute__((ext_vector_type(4))) T Quad;
+  Quad rv[RCH];
+  const bool use_res = p.residual && p.splitk == 1 && !(p.dbg & 16);
+  // (fp32 on the 8 + 4 wave tiles: 16-byte residual quads do not fit next to 96 accumulators at 3 waves per SIMD -
+  //  there the accumulators simply start from the residual, loaded in front of the first step)
+  constexpr bool RSPREAD = !(sizeof(T) == 4 && NWC >= 8);
+  if (!RSPREAD && use_res) {
     const T* res = (const T*)p.residual;
 #pragma unroll
     for (int a = 0; a < TN; ++a)
@@ -239,17 +250,78 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
       for (int b = 0; b < TM; ++b)
 #pragma unroll
         for (int rq = 0; rq < RQ; ++rq) {
-          const T* src = res + (size_t)(m0 + wm * WMS + b * MF + li) * p.res_ld + cout_of(a, rq);
           float r0, r1, r2, r3;
-          load4<T>(src, r0, r1, r2, r3);
+          load4<T>(res + (size_t)(m0 + wm * WMS + b * MF + li) * p.res_ld + cout_of(a, rq), r0, r1, r2, r3);
           acc[a][b][4 * rq] = r0; acc[a][b][4 * rq + 1] = r1; acc[a][b][4 * rq + 2] = r2; acc[a][b][4 * rq + 3] = r3;
         }
   }
+  auto res_issue = [&](int chunk) {
+    const T* res = (const T*)p.residual;
+#pragma unroll
+    for (int k = 0; k < RCH; ++k) {
+      const int idx = chunk * RCH + k;
+      if (idx < NRT) {
+        const int a = idx / (TM * RQ), b = (idx / RQ) % TM, rq = idx % RQ;
+        rv[k] = *reinterpret_cast<const Quad*>(res + (size_t)(m0 + wm * WMS + b * MF + li) * p.res_ld + cout_of(a, rq));
+      }
+    }
+  };
+  auto res_add = [&](int chunk) {
+#pragma unroll
+    for (int k = 0; k < RCH; ++k) {
+      const int idx = chunk * RCH + k;
+      if (idx < NRT) {
+        const int a = idx / (TM * RQ), b = (idx / RQ) % TM, rq = idx % RQ;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[a][b][4 * rq + e] += to_f32(rv[k][e]);
+      }
+    }
+  };
 
   {
     int slot = 0, st = 0, pbuf = 0;
-    for (int g = 0; g < G; ++g) {
-      __builtin_amdgcn_s_barrier();
+    auto step_end = [&]() {
+      slot = slot + 1 == STAGES ? 0 : slot + 1;
+      if (++st == SPC) {
+        st = 0;
+        pbuf ^= 1;
+      }
+    };
+    // plain form of a K step (fragments of one phase, then its MFMAs; the compiler's own schedule): used for the
+    // first NRS steps of a residual convolution, where the residual chunks need the registers the hand-ordered
+    // pipeline below spends on fragments in flight
+    auto k_step_plain = [&]() {
+      if (!(p.dbg & 2)) {
+        const char* sP = smem + pbuf * PATCH;
+        const char* sW = smem + 2 * PATCH + slot * W_STAGE;
+#pragma unroll
+        for (int ti = 0; ti < TPS; ++ti) {
+          const int tap = st * TPS + ti;
+          const int tapoff = (tap / 3) * PW + (tap - (tap / 3) * 3);
+          int bo[TM];
+#pragma unroll
+          for (int t = 0; t < TM; ++t) bo[t] = frag_off(qb[t] + tapoff);
+#pragma unroll
+          for (int kk = 0; kk < NKK; ++kk) {
+            Chunk a[TN], b[TM];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) a[t] = ld16<Chunk>(sW + ti * W_TAP + ((a_off0 + t * MF * 128) ^ (kk << 5)));
+#pragma unroll
+            for (int t = 0; t < TM; ++t) b[t] = ld16<Chunk>(sP + (bo[t] ^ (kk << 5)));
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+              for (int tm = 0; tm < TM; ++tm) {
+                if constexpr (MF == 16) MM::mma(acc[tn][tm], a[tn], b[tm]);
+                else Mma32<T>::mma(acc[tn][tm], a[tn], b[tm]);
+              }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      step_end();
+    };
+    auto k_step = [&]() {
       if (!(p.dbg & 2)) {
         const char* sP = smem + pbuf * PATCH;
         const char* sW = smem + 2 * PATCH + slot * W_STAGE;
@@ -296,15 +368,105 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      slot = slot + 1 == STAGES ? 0 : slot + 1;
-      if (++st == SPC) {
-        st = 0;
-        pbuf ^= 1;
+      step_end();
+    };
+    int g = 0;
+    if (RSPREAD && use_res) {     // (wave-uniform) the first NRS steps, peeled: static accumulator indices for the residual chunks
+#pragma unroll
+      for (int c = 0; c < NRS; ++c) {
+        __builtin_amdgcn_s_barrier();
+        if (c > 0) res_add(c - 1);
+        res_issue(c);
+        k_step_plain();
       }
+      res_add(NRS - 1);
+      g = NRS;
+    }
+    for (; g < G; ++g) {
+      __builtin_amdgcn_s_barrier();
+      k_step();
     }
   }
 
   // ------------------------------------------------------------------------------------------- epilogue
+  if (p.dbg & 8) return;       // (timing decomposition only)
+  if constexpr (ESZ == 2) {
+    if (p.splitk == 1) {
+      // bf16, whole K in this workgroup: (residual + sum) + (bias + temb) is rounded in the accumulator layout and the
+      // tile is staged in bf16 - ONE pass for all BM rows (half the LDS bytes of an fp32 tile, two barriers fewer),
+      // then leaves as whole rows, 16 bytes per lane; per-channel GroupNorm partial sums of the stored values
+      // accumulated by the thread that owns the column (fixed order, no atomics).
+      constexpr int NTC = NWC * 64, EO = 8, CPR = BN / EO, RPI = NTC / CPR, OROW = BN + 8;
+      static_assert(1024 + BM * OROW * 2 <= LDS_TOTAL && BN * 4 <= 1024 && RPI * BN * 8 <= LDS_TOTAL, "staging tile");
+      float* sB = reinterpret_cast<float*>(smem);        // [BN] bias + time embedding of this tile (one sample)
+      T* sO = reinterpret_cast<T*>(smem + 1024);         // [BM][OROW]
+      const T* temb = (const T*)p.temb;
+      const int etid = cw * 64 + lane;
+      __syncthreads();                                    // pipeline buffers idle
+      for (int c = etid; c < BN; c += NTC) {
+        float v = p.bias ? p.bias[n0 + c] : 0.f;
+        if (temb) v += to_f32(temb[(size_t)b_tile * p.temb_stride + (n0 + c) % p.temb_mod]);
+        sB[c] = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) {
+          const int cl = cout_of(tn, rq) - n0;
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(sB + cl);
+#pragma unroll
+          for (int t = 0; t < TM; ++t) {
+            Quad o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(acc[tn][t][4 * rq + e] + b4[e]);
+            *reinterpret_cast<Quad*>(sO + (wm * WMS + t * MF + li) * OROW + cl) = o;
+          }
+        }
+      __syncthreads();
+      const bool active = etid < RPI * CPR;
+      const int ch = etid % CPR, tr = etid / CPR;
+      const int n = n0 + ch * EO;
+      float ss1[EO], ss2[EO];
+#pragma unroll
+      for (int e = 0; e < EO; ++e) ss1[e] = ss2[e] = 0.f;
+      if (active) {
+#pragma unroll 4
+        for (int row = tr; row < BM; row += RPI) {
+          const Chunk o = ld16<Chunk>(sO + row * OROW + ch * EO);
+          if (!(p.dbg & 4)) st16<Chunk>((T*)p.y + (size_t)(m0 + row) * p.y_ld + n, o);
+          if (p.stats_out) {
+#pragma unroll
+            for (int e = 0; e < EO; ++e) {
+              const float vr = to_f32(o[e]);
+              ss1[e] += vr;
+              ss2[e] = fmaf(vr, vr, ss2[e]);
+            }
+          }
+        }
+      }
+      if (p.stats_out) {
+        float* sR = reinterpret_cast<float*>(smem);       // [RPI][BN][2]
+        __syncthreads();
+        if (active) {
+#pragma unroll
+          for (int e = 0; e < EO; ++e) *reinterpret_cast<f32x2*>(sR + ((tr * BN) + ch * EO + e) * 2) = f32x2{ss1[e], ss2[e]};
+        }
+        __syncthreads();
+        for (int c = etid; c < BN; c += NTC) {
+          float a1 = 0.f, a2 = 0.f;
+          for (int r = 0; r < RPI; ++r) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(sR + ((r * BN) + c) * 2);
+            a1 += v[0];
+            a2 += v[1];
+          }
+          const int sp = (m0 - b_tile * HW) / BM;
+          *reinterpret_cast<f32x2*>(p.stats_out + (((size_t)b_tile * p.stats_S + sp) * p.Cout + n0 + c) * 2) = f32x2{a1, a2};
+        }
+      }
+      return;
+    }
+  }
   {
     constexpr int SROW = BN + 8;                       // fp32 row stride: conflict-free 16-byte writes
     constexpr int PROWS = BM < 128 ? BM : 128;         // rows staged per pass
@@ -383,7 +545,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
           Chunk o;
 #pragma unroll
           for (int e = 0; e < EO; ++e) o[e] = from_f32<T>(v[e] + bvec[e]);       // (residual + sum) + (bias + temb)
-          st16<Chunk>((T*)p.y + (size_t)m * p.y_ld + n, o);
+          if (!(p.dbg & 4)) st16<Chunk>((T*)p.y + (size_t)m * p.y_ld + n, o);
           if (p.stats_out) {
 #pragma unroll
             for (int e = 0; e < EO; ++e) {
