@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
       for (int i = tid; i < N * N * CPP; i += NT) {
         const int pix = i / CPP, q = i - pix * CPP;
         const int h = pix / N, w = pix - h * N;
-        st16<Chunk>(p.y + ((size_t)b * N * N + pix) * Ct + c0 + q * EPC, ld16<Chunk>(Ys + h * YRP + w * CH + q * EPC));
+        st16_out<Chunk>(p.y + ((size_t)b * N * N + pix) * Ct + c0 + q * EPC, ld16<Chunk>(Ys + h * YRP + w * CH + q * EPC));
       }
     }
   }  // persistent item loop

@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnP<T> p) {
       for (int td = 0; td < ND; ++td) {
         const int dch = 16 * td + 4 * lg;
         if (dch + 3 < p.d)
-          store4<T>(op + dch, oacc[u][td][0] * inv, oacc[u][td][1] * inv, oacc[u][td][2] * inv, oacc[u][td][3] * inv);
+          store4_out<T>(op + dch, oacc[u][td][0] * inv, oacc[u][td][1] * inv, oacc[u][td][2] * inv, oacc[u][td][3] * inv);
       }
     }
   }

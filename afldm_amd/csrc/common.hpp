@@ -114,6 +114,23 @@ __device__ __forceinline__ void st16(void* p, const V& v) {
   *reinterpret_cast<V*>(p) = v;
 }
 
+// 16-byte store of a kernel's OUTPUT tensor.  With AFLDM_WT (a per-source build switch) it is a write-through (sc1)
+// store: the line goes to memory as the kernel runs instead of staying dirty in the XCD's L2 until the end-of-kernel
+// release writes it back in front of the next launch (cdna_hip_programming.md Guideline 16 / microarch "publish-large").
+#ifndef AFLDM_WT
+#define AFLDM_WT 0
+#endif
+template <typename V>
+__device__ __forceinline__ void st16_out(void* p, const V& v) {
+#if AFLDM_WT
+  typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+  const u4 d = __builtin_bit_cast(u4, v);
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+#else
+  *reinterpret_cast<V*>(p) = v;
+#endif
+}
+
 // Pack 4 fp32 values as 4 consecutive T elements and store (8 B for bf16, 16 B for fp32).
 template <typename T>
 __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
@@ -127,6 +144,24 @@ __device__ __forceinline__ void store4<bf16>(bf16* p, float a, float b, float c,
   v[0] = (bf16)a; v[1] = (bf16)b; v[2] = (bf16)c; v[3] = (bf16)d;
   *reinterpret_cast<bf16x4*>(p) = v;
 }
+// store4 for a kernel's output tensor (see st16_out)
+template <typename T>
+__device__ __forceinline__ void store4_out(T* p, float a, float b, float c, float d) {
+#if AFLDM_WT
+  if constexpr (sizeof(T) == 2) {
+    bf16x4 v;
+    v[0] = (bf16)a; v[1] = (bf16)b; v[2] = (bf16)c; v[3] = (bf16)d;
+    typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+    const u2 dd = __builtin_bit_cast(u2, v);
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(dd) : "memory");
+  } else {
+    st16_out<f32x4>(p, f32x4{a, b, c, d});
+  }
+#else
+  store4<T>(p, a, b, c, d);
+#endif
+}
+
 template <typename T>
 __device__ __forceinline__ void load4(const T* p, float& a, float& b, float& c, float& d);
 template <>

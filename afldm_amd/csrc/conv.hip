@@ -805,7 +805,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
             Chunk o;
 #pragma unroll
             for (int e = 0; e < EO; ++e) o[e] = from_f32<T>(v[e]);
-            st16<Chunk>((T*)p.y + (size_t)m * p.y_ld + n, o);
+            st16_out<Chunk>((T*)p.y + (size_t)m * p.y_ld + n, o);
             if (p.stats_out && p.stats_multi == 2) {
               // H * W == 1 (a dense layer over a flattened plane): every row is a sample of its own, its "sums" are the
               // values themselves (S = 1)
@@ -1589,6 +1589,7 @@ static const Variant kVariants[] = {
     {128, 96, 6, 3},   // 54  16x16 planes, 8 rows x 96 couts (small batches)
     {128, 96, 6, 3},   // 55  32x32 planes, 4 rows x 96 couts (small batches)
     {64, 32, 4, 12},   // 56  64x32 tiles, 12 stages (a skinny GEMM's K step costs DMA latency / ring depth): dense layers over <= 64 rows (the 2x2 level at batch 64) WITHOUT split-K
+    {256, 192, 6, 2},  // 57  = 41 with a 2-deep weight ring (lookahead experiment)
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 

@@ -434,7 +434,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
 #pragma unroll 4
         for (int row = tr; row < BM; row += RPI) {
           const Chunk o = ld16<Chunk>(sO + row * OROW + ch * EO);
-          if (!(p.dbg & 4)) st16<Chunk>((T*)p.y + (size_t)(m0 + row) * p.y_ld + n, o);
+          if (!(p.dbg & 4)) st16_out<Chunk>((T*)p.y + (size_t)(m0 + row) * p.y_ld + n, o);      // write-through (build.py: AFLDM_WT)
           if (p.stats_out) {
 #pragma unroll
             for (int e = 0; e < EO; ++e) {
@@ -545,7 +545,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
           Chunk o;
 #pragma unroll
           for (int e = 0; e < EO; ++e) o[e] = from_f32<T>(v[e] + bvec[e]);       // (residual + sum) + (bias + temb)
-          if (!(p.dbg & 4)) st16<Chunk>((T*)p.y + (size_t)m * p.y_ld + n, o);
+          if (!(p.dbg & 4)) st16_out<Chunk>((T*)p.y + (size_t)m * p.y_ld + n, o);
           if (p.stats_out) {
 #pragma unroll
             for (int e = 0; e < EO; ++e) {
@@ -602,6 +602,8 @@ static const H3Variant kH3[] = {
     {64, 8, 96, 2, 2, 16, 3},      // 53: (= 51; a 192-cout tile with 3 taps per step does not fit the LDS)
     {128, 16, 96, 2, 2, 16, 3},    // 54: 16x16 planes, 8 rows x 96 couts, 3 taps per step (small batches)
     {128, 32, 96, 2, 2, 16, 3},    // 55: 32x32 planes, 4 rows x 96 couts (small batches)
+    {0, 0, 0, 0, 0, 0, 0},         // 56: (implicit-GEMM variant, conv.hip)
+    {256, 32, 192, 4, 2, 16, 1},   // 57: as 41 with a 2-deep weight ring (lookahead experiment)
 };
 constexpr int kNumH3 = (int)(sizeof(kH3) / sizeof(kH3[0]));
 
@@ -617,6 +619,7 @@ bool conv3h_supported(int variant, int dtype_size, const ConvP& p) {
   const int k = variant - kConv3hFirst;
   if (k < 0 || k >= kNumH3) return false;
   const H3Variant& v = kH3[k];
+  if (v.bm == 0) return false;
   const int kstep = 128 / dtype_size;
   const int eo = 16 / dtype_size;
   const int HW = p.H * p.W;
@@ -629,9 +632,9 @@ bool conv3h_supported(int variant, int dtype_size, const ConvP& p) {
          p.Cout % 4 == 0 && aligned16(p.y) && aligned16(p.x1) && aligned16(p.w);
 }
 
-template <typename T, int BM, int W_, int BN, int WGM, int WGN, int MF, int TPS>
+template <typename T, int BM, int W_, int BN, int WGM, int WGN, int MF, int TPS, int STAGES = 3>
 static void launch_h3(const ConvP& p0, hipStream_t st) {
-  constexpr int NPROD = 4, STAGES = 3;
+  constexpr int NPROD = 4;
   constexpr int NWC = WGM * WGN;
   constexpr int MINW = (NWC + NPROD + 3) / 4;
   constexpr int ROWS = BM / W_, SEG = ROWS < W_ ? ROWS : W_, NSEG = ROWS / SEG;
@@ -668,6 +671,8 @@ static void launch_h3_variant(int k, const ConvP& p, hipStream_t st) {
     case 12: launch_h3<T, 64, 8, 96, 2, 2, 16, 3>(p, st); break;
     case 13: launch_h3<T, 128, 16, 96, 2, 2, 16, 3>(p, st); break;
     case 14: launch_h3<T, 128, 32, 96, 2, 2, 16, 3>(p, st); break;
+    case 15: break;                                                   // (id 56 is an implicit-GEMM variant, conv.hip)
+    case 16: launch_h3<T, 256, 32, 192, 4, 2, 16, 1, 2>(p, st); break;  // 57: as 41 with a 2-deep weight ring (lookahead experiment)
   }
 }
 

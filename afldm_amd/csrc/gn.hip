@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(256) k_gn_apply(const T* __restrict__ x1, int 
             if (act == 1) f = silu_f(f);
             o[e] = from_f32<T>(f);
           }
-          st16<Chunk>(dst + (size_t)(row + u * rl) * C, o);
+          st16_out<Chunk>(dst + (size_t)(row + u * rl) * C, o);
         }
       }
       for (; row < r1; row += rl) {
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(256) k_gn_apply(const T* __restrict__ x1, int 
           if (act == 1) f = silu_f(f);
           o[e] = from_f32<T>(f);
         }
-        st16<Chunk>(dst + (size_t)row * C, o);
+        st16_out<Chunk>(dst + (size_t)row * C, o);
       }
     }
     return;

@@ -179,7 +179,7 @@ __global__ void __launch_bounds__((NWC + NPROD) * 64, MINW) k_lin_wreg(LinP p) {
 #pragma unroll 2
       for (int it = 0; it < NPW * CPR / 64; ++it) {
         const int idx = lane + 64 * it, row = idx / CPR, c = idx - row * CPR;
-        st16<Chunk>(p.y2 + ((size_t)bsm * cv + (n0w - p.split_n + row)) * p.HW + tok0 + c * 8,
+        st16_out<Chunk>(p.y2 + ((size_t)bsm * cv + (n0w - p.split_n + row)) * p.HW + tok0 + c * 8,
                     ld16<Chunk>(ws + row * CF::TROW + c * 8));
       }
     } else {
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__((NWC + NPROD) * 64, MINW) k_lin_wreg(LinP p) {
 #pragma unroll 2
       for (int it = 0; it < BM * CPR / 64; ++it) {
         const int idx = lane + 64 * it, row = idx / CPR, c = idx - row * CPR;
-        st16<Chunk>(p.y + (size_t)(m0 + row) * p.y_ld + n0w + c * 8, ld16<Chunk>(ws + row * CF::SROW + c * 8));
+        st16_out<Chunk>(p.y + (size_t)(m0 + row) * p.y_ld + n0w + c * 8, ld16<Chunk>(ws + row * CF::SROW + c * 8));
       }
     }
     __builtin_amdgcn_wave_barrier();

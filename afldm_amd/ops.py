@@ -33,7 +33,7 @@ class Profiler:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for kind, flops, nbytes, e0, e1 in self.records:
+        for kind, flops, nbytes, e0, e1, _ in self.records:
             d = agg.setdefault(kind, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
@@ -50,12 +50,14 @@ def _begin():
     return e
 
 
-def _end(tok, kind, flops=0.0, nbytes=0.0):
+def _end(tok, kind, flops=0.0, nbytes=0.0, replay=None):
+    """replay: a callable that re-issues exactly this launch on the same buffers (bench.py replays a family's launches
+    back to back from a captured graph to time the kernels without the host's launch gaps)."""
     if tok is None:
         return
     e = torch.cuda.Event(enable_timing=True)
     e.record()
-    _PROFILE.records.append((kind, float(flops), float(nbytes), tok, e))
+    _PROFILE.records.append((kind, float(flops), float(nbytes), tok, e, replay))
 
 
 def _dev(t, name="tensor"):
@@ -600,8 +602,10 @@ def conv2d(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, o
         es = x1.element_size()
         kind = "conv3x3" if a.KS == 3 else ("conv1x1" if a.H * a.W > 1 and x1.ndim == 4 else "linear")
         # algorithmic bytes: input + weights + output (+ the residual read), as tools/replay_conv3x3.py counts them
+        keep = (a, st, out, workspace)
         _end(tok, kind, 2.0 * M * a.Cout * a.KS * a.KS * Ct,
-             (M * Ct + a.Cout * a.KS * a.KS * Ct + M * a.Cout * (2 if residual is not None else 1)) * es)
+             (M * Ct + a.Cout * a.KS * a.KS * Ct + M * a.Cout * (2 if residual is not None else 1)) * es,
+             replay=lambda keep=keep: conv2d_launch(keep[0]))
     return out
 
 

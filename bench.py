@@ -71,6 +71,32 @@ def roofline_pass(unet, batch, dtype):
                       gbs=round(d["bytes"] / d["ms"] / 1e6, 1) if d["ms"] > 0 else 0.0)
     dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
     name, d = dom
+    # The eager pass brackets every launch with events on the launch stream, but the host needs 10-20 us of Python per
+    # launch: short kernels (the 8x8 .. 2x2 levels) are timed together with the gap in front of them.  For the dominant
+    # family the SAME launches - same argument blocks, same buffers holding the step's real activations - are therefore
+    # also captured back to back into one HIP graph and timed with events around its replay: kernel time including the
+    # boundaries between the family's own launches, no host gaps.  This replay time is what `achieved` is computed from.
+    replay = None
+    calls = [r for r in prof.records if r[0] == name and r[5] is not None]
+    if calls and len(calls) == d["launches"]:
+        calls = calls[:len(calls) // 3]                      # the launches of ONE step
+        for r in calls:
+            r[5]()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for r in calls:
+                r[5]()
+        ts = []
+        for _ in range(7):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        replay = dict(ms=median(ts[2:]), launches=len(calls), flops=sum(r[1] for r in calls), bytes=sum(r[2] for r in calls))
+        del g
     # HBM bytes per launch of the dominant family from the PMC counters (FETCH_SIZE / WRITE_SIZE in separate
     # rocprofv3 passes, gfx950 x2 read correction): a PMC pass cannot run inside the timed process, so it is
     # collected by profiles/run_pmc_conv3x3.sh over a replay of exactly this family's launches and committed
@@ -93,10 +119,16 @@ def roofline_pass(unet, batch, dtype):
         or name.startswith("af_act_N16")
     if mfma_bound:
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
-        achieved = d["flops"] / d["ms"] / 1e9
+        eager = d["flops"] / d["ms"] / 1e9
+        achieved = replay["flops"] / replay["ms"] / 1e9 if replay else eager
+        fam_ms = replay["ms"] if replay else d["ms"] / 3
+        n = replay["launches"] if replay else d["launches"] // 3
         roof = dict(kernel=name, bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
                     frac=round(achieved / peak, 4), traffic=traffic, traffic_note=traffic_note,
-                    launches_per_step=d["launches"] // 3, avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
+                    launches_per_step=n, avg_launch_us=round(1e3 * fam_ms / n, 2), family_ms_per_step=round(fam_ms, 4),
+                    timing="HIP events around a graph replay of the family's launches of one step (no host gaps)" if replay
+                    else "HIP events around each eager launch",
+                    eager_achieved=round(eager, 2), eager_family_ms_per_step=round(d["ms"] / 3, 4),
                     flops_per_launch=d["flops"] / d["launches"], algorithmic_bytes_per_launch=round(d["bytes"] / d["launches"]))
     else:
         achieved = d["bytes"] / d["ms"] / 1e6

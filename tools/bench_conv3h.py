@@ -23,6 +23,7 @@ SHAPES = [
 
 def main():
     dt = torch.bfloat16
+    cold = torch.zeros(300 << 20, dtype=torch.float32, device="cuda") if os.environ.get("COLD") else None
     rounds = int(os.environ.get("ROUNDS", 5))
     iters = int(os.environ.get("ITERS", 20))
     only = [t for t in os.environ.get("SHAPES", "").split(",") if t]
@@ -55,6 +56,8 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(iters):
+                    if cold is not None:
+                        cold.add_(1.0)              # 1.2 GB read + written: evicts the L2s and the Infinity Cache
                     fn()
                 e1.record()
                 torch.cuda.synchronize()

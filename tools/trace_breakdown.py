@@ -13,8 +13,8 @@ step = rows[idx[-2]:idx[-1]]
 
 def short(n):
     if "k_conv3h" in n:
-        m = re.search(r"Li(\d+)ELi(\d+)ELi192ELi(\d+)ELi(\d+)E", n) or re.search(r"<\w+, (\d+), (\d+), 192, (\d+), (\d+)", n)
-        return f"conv3h_{m.group(1)}w{m.group(2)}c{int(m.group(3)) * int(m.group(4))}"
+        m = re.search(r"Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", n) or re.search(r"<\w+, (\d+), (\d+), (\d+), (\d+), (\d+)", n)
+        return f"conv3h_{m.group(1)}x{m.group(3)}w{m.group(2)}c{int(m.group(4)) * int(m.group(5))}"
     if "k_igemm3" in n:
         return "igemm3_128x192p"
     if "k_igemm" in n:
