@@ -1634,7 +1634,7 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
     if (kVariants[v].ver == 6) {
       // halo-patch kernel: the small-tile variants (51+) may split the CHANNEL BLOCKS over up to 4 slices when the
       // tiles alone leave most CUs idle; the slice count must divide the number of 128-byte channel blocks
-      if (v < 51) return 1;
+      if (v < 51 || v == 57) return 1;
       const int ncb = Ct / (2 * elems_per_row);
       int z = 1;
       for (int c = 2; c <= 4; ++c)

@@ -17,7 +17,8 @@
 //
 // LDS image: one 128-byte row per patch pixel / weight row holding the 8 16-byte chunks (chunk c = kc * 4 + lg:
 // MFMA K-chunk kc, lane group lg) of the channel block at position
-//       pos(c, q) = ((lg & 1) << 2 | kc << 1 | lg >> 1)  ^  ((q >> 1) & 3)            q = row index
+//       pos(c, q) = ((lg & 1) << 2 | kc << 1 | lg >> 1)  ^  sw(q),   sw(q) = (q >> 1) & 3,   q = row index
+//       (patches of 8x8 / 4x4 planes: sw from the patch coordinates, see h_sw_patch)
 // A ds_read_b128 is served in 16-lane groups made of 8 rows of lane group lg and 8 rows of lg ^ 1: bit 2 of the
 // position separates the two halves, and 4 rows of equal parity inside ANY run of 16 consecutive rows differ in
 // (q >> 1) & 3 - so the fragment reads are bank-conflict free for every tap shift of the patch (the swizzle of
@@ -31,6 +32,8 @@
 // (residual + sum) + (bias + temb) in fp32, one rounding, per-channel GroupNorm partial sums of the stored values
 // accumulated by the thread that owns the column (fixed order, no atomics).
 #include "conv_common.hpp"
+
+#include <type_traits>
 
 namespace afldm {
 
@@ -63,18 +66,38 @@ struct Mma32<float> {
 
 // LDS position of chunk c of row q and its inverse (see the header): MF = 16 keeps bit 2 for the lane-group parity and
 // swizzles two bits, MF = 32 (the 16-lane read groups lie inside one 32-row half) swizzles all three.
+// The row's swizzle bits sw: (q >> 1) & 3 (& 7 for MF = 32) of the row index for the weight rows and for patches of
+// planes 16+ wide, where 16 consecutive tile pixels are 16 consecutive patch pixels.  On the 8x8 / 4x4 planes a
+// fragment's 16 pixels span 2 / 4 image rows (patch rows are W + 2 pixels apart) and that rule put two of every 8
+// equal-lane-group rows on the same banks - every patch read of those variants took two LDS cycles.  There the bits
+// come from the patch COORDINATES (pr, pc): column pair (pc >> 1) & 3 on 8-wide planes (the 8 pixels of one lane
+// group in a read group are columns c .. c+3 of one row and c+4 .. c+7 of the next); column pair and row parity on
+// 4-wide planes (rows a, a+3 or a+1, a+2) - conflict free for all nine tap shifts (checked by enumeration).
 template <int MF>
-__device__ __forceinline__ int h_pos(int c, int q) {
-  if constexpr (MF == 16) return (((c & 1) << 2) | ((c >> 2) << 1) | ((c >> 1) & 1)) ^ ((q >> 1) & 3);
-  else return c ^ ((q >> 1) & 7);
+__device__ __forceinline__ int h_sw_rows(int q) {
+  return MF == 16 ? (q >> 1) & 3 : (q >> 1) & 7;
+}
+template <int MF, int W_>
+__device__ __forceinline__ int h_sw_patch(int q) {
+  if constexpr (MF == 16 && W_ <= 8) {
+    const int pr = q / (W_ + 2), pc = q - pr * (W_ + 2);
+    return W_ == 8 ? (pc >> 1) & 3 : (((pc >> 1) & 1) | ((pr & 1) << 1));
+  } else {
+    return h_sw_rows<MF>(q);
+  }
 }
 template <int MF>
-__device__ __forceinline__ int h_chunk_at(int pos, int q) {   // source chunk that lives at position `pos` of row q
+__device__ __forceinline__ int h_pos(int c, int sw) {
+  if constexpr (MF == 16) return (((c & 1) << 2) | ((c >> 2) << 1) | ((c >> 1) & 1)) ^ sw;
+  else return c ^ sw;
+}
+template <int MF>
+__device__ __forceinline__ int h_chunk_at(int pos, int sw) {   // source chunk that lives at position `pos` of a row with swizzle bits sw
   if constexpr (MF == 16) {
-    const int x = pos ^ ((q >> 1) & 3);
+    const int x = pos ^ sw;
     return ((x >> 1) & 1) * 4 + (x & 1) * 2 + (x >> 2);
   } else {
-    return pos ^ ((q >> 1) & 7);
+    return pos ^ sw;
   }
 }
 
@@ -109,8 +132,24 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
   const bool is_producer = wave_all >= NWC;
   const int li = lane & (MF - 1), lg = lane / MF;       // fragment row / lane group of the consumers
 
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
+  // Tile order.  Default: each XCD (private L2) takes a contiguous run of tiles, n fastest - it reads 1/8 of the
+  // pixels and ALL the weights.  p.xcd_gn > 0: the 8 XCDs form a (8 / gn) x gn grid over (m tiles, n tiles), so an
+  // XCD reads gn / 8 of the weights and 1 / (8 / gn) of the pixels - the 4x4 level's 10-21 MB of weights were
+  // fetched 8 times otherwise (launch_h3 picks gn from the byte counts).  Same time in the step (those fetches hit
+  // the MALL), a third less fabric traffic for the family.
+  int tile_m, tile_n;
+  if (p.xcd_gn > 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int gn = p.xcd_gn, tn_per = p.tiles_n / gn, tm_per = (gridDim.x / p.tiles_n) / (8 / gn);
+    const int xm = xcd / gn, xn = xcd - xm * gn;
+    const int lm = j / tn_per, ln = j - lm * tn_per;
+    tile_m = xm * tm_per + lm;
+    tile_n = xn * tn_per + ln;
+  } else {
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    tile_m = tile / p.tiles_n;
+    tile_n = tile - tile_m * p.tiles_n;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int Ct = p.C1, HW = W_ * W_;
   const int ncb = Ct / KSTEP;
@@ -134,7 +173,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
       if (j > NPI - 1) j = NPI - 1;
       pj[i] = j;
       const int q = 8 * j + (lane >> 3);
-      const int c = h_chunk_at<MF>(lane & 7, q);
+      const int c = h_chunk_at<MF>(lane & 7, h_sw_patch<MF, W_>(q));
       const int pr = q / PW, pc = q - pr * PW;
       const int sg = pr / (SEG + 2), jj = pr - sg * (SEG + 2);            // segment (one sample's rows) and row inside it
       const int ih = oh0 + jj - 1;
@@ -146,7 +185,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
     for (int i = 0; i < WPW; ++i) {
       const int j = wave + NPROD * i;                            // instruction inside the stage: (tap in step, row group)
       const int tis = j / WIT, r = 8 * (j - tis * WIT) + (lane >> 3);
-      const int c = h_chunk_at<MF>(lane & 7, r);
+      const int c = h_chunk_at<MF>(lane & 7, h_sw_rows<MF>(r));
       woff[i] = (((unsigned)(n0 + r) * 9u + (unsigned)tis) * (unsigned)Ct + (unsigned)(c * EPC)) * ESZ;
     }
     // cursor of the next weight step to issue
@@ -217,8 +256,8 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
     qb[t] = (sg * (SEG + 2) + rr) * PW + c;
   }
   // fragment address of (row q, K step kk) = (q * 128 + (h_pos(chunk(0, lg), q) << 4)) ^ (kk << 5) in both flavours
-  auto frag_off = [&](int q) { return q * 128 + (h_pos<MF>(lg, q) << 4); };
-  const int a_off0 = frag_off(wn * WNS + li);                    // + t * MF * 128 for weight tile t ((row >> 1) & 7 depends on li only)
+  auto frag_off = [&](int q) { return q * 128 + (h_pos<MF>(lg, h_sw_patch<MF, W_>(q)) << 4); };                      // patch rows
+  const int a_off0 = (wn * WNS + li) * 128 + (h_pos<MF>(lg, h_sw_rows<MF>(wn * WNS + li)) << 4);                    // + t * MF * 128 for weight tile t ((row >> 1) & 7 depends on li only)
 
   // The residual enters through the ACCUMULATORS (fragment layout), a few tiles per K step during the first NRS
   // steps: requested at the top of step s, added at the top of step s + 1 - its latency runs under MFMA work instead
@@ -278,6 +317,16 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
     }
   };
 
+  // TPS == 3 (the small tiles): the fragment offsets of all nine taps are computed ONCE (9 x TM registers) and the
+  // step loop is unrolled over the three filter rows; computed per step (as the TPS == 1 tiles do) they were ~85 VALU
+  // instructions in front of every step's first LDS read.
+  int btab[TPS == 3 ? 9 : 1][TM];
+  if constexpr (TPS == 3) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int t = 0; t < TM; ++t) btab[tap][t] = frag_off(qb[t] + (tap / 3) * PW + (tap - (tap / 3) * 3));
+  }
   {
     int slot = 0, st = 0, pbuf = 0;
     auto step_end = [&]() {
@@ -290,7 +339,8 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
     // plain form of a K step (fragments of one phase, then its MFMAs; the compiler's own schedule): used for the
     // first NRS steps of a residual convolution, where the residual chunks need the registers the hand-ordered
     // pipeline below spends on fragments in flight
-    auto k_step_plain = [&]() {
+    auto k_step_plain = [&](auto ST) {                 // ST: the step's index inside its channel block when static (TPS == 3), else -1
+      constexpr int sst = decltype(ST)::value;
       if (!(p.dbg & 2)) {
         const char* sP = smem + pbuf * PATCH;
         const char* sW = smem + 2 * PATCH + slot * W_STAGE;
@@ -300,7 +350,10 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
           const int tapoff = (tap / 3) * PW + (tap - (tap / 3) * 3);
           int bo[TM];
 #pragma unroll
-          for (int t = 0; t < TM; ++t) bo[t] = frag_off(qb[t] + tapoff);
+          for (int t = 0; t < TM; ++t) {
+            if constexpr (sst >= 0) bo[t] = btab[sst * TPS + ti][t];
+            else bo[t] = frag_off(qb[t] + tapoff);
+          }
 #pragma unroll
           for (int kk = 0; kk < NKK; ++kk) {
             Chunk a[TN], b[TM];
@@ -321,7 +374,8 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
       }
       step_end();
     };
-    auto k_step = [&]() {
+    auto k_step = [&](auto ST) {
+      constexpr int sst = decltype(ST)::value;
       if (!(p.dbg & 2)) {
         const char* sP = smem + pbuf * PATCH;
         const char* sW = smem + 2 * PATCH + slot * W_STAGE;
@@ -331,7 +385,10 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
           const int tap = st * TPS + ti;                         // TPS == 3: kh = st, kw = ti
           const int tapoff = (tap / 3) * PW + (tap - (tap / 3) * 3);
 #pragma unroll
-          for (int t = 0; t < TM; ++t) boff[ti][t] = frag_off(qb[t] + tapoff);
+          for (int t = 0; t < TM; ++t) {
+            if constexpr (sst >= 0) boff[ti][t] = btab[sst * TPS + ti][t];
+            else boff[ti][t] = frag_off(qb[t] + tapoff);
+          }
         }
         // hand-ordered fragment pipeline over the step's TPS x NKK phases of TN MFMA groups (one weight fragment x TM
         // pixel fragments each): weight fragment i + AD is requested when group i starts, the pixel fragments of the
@@ -341,10 +398,16 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
         Chunk af[NG], bf[NPH][TM];
         auto lda = [&](int i) {
           const int ph = i / TN, ti = ph / NKK, kk = ph - ti * NKK;
+#ifdef AFLDM_H3_NOLOAD                                                // (timing decomposition build: MFMAs without fragment reads)
+          return Chunk{};
+#endif
           return ld16<Chunk>(sW + ti * W_TAP + ((a_off0 + (i - ph * TN) * MF * 128) ^ (kk << 5)));
         };
         auto ldb = [&](int ph, int t) {
           const int ti = ph / NKK, kk = ph - ti * NKK;
+#ifdef AFLDM_H3_NOLOAD
+          return Chunk{};
+#endif
           return ld16<Chunk>(sP + (boff[ti][t] ^ (kk << 5)));
         };
 #pragma unroll
@@ -362,6 +425,10 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int tm = 0; tm < TM; ++tm) {
+#ifdef AFLDM_H3_NOMMA                                                 // (timing decomposition build: fragment reads without MFMAs)
+            asm volatile("" ::"v"(af[i]), "v"(bf[i / TN][tm]));
+            continue;
+#endif
             if constexpr (MF == 16) MM::mma(acc[i % TN][tm], af[i], bf[i / TN][tm]);
             else Mma32<T>::mma(acc[i % TN][tm], af[i], bf[i / TN][tm]);
           }
@@ -370,21 +437,46 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
       }
       step_end();
     };
+    typedef std::integral_constant<int, -1> RT;
     int g = 0;
     if (RSPREAD && use_res) {     // (wave-uniform) the first NRS steps, peeled: static accumulator indices for the residual chunks
-#pragma unroll
-      for (int c = 0; c < NRS; ++c) {
+      auto peeled = [&](auto C) {
+        constexpr int c = decltype(C)::value;
         __builtin_amdgcn_s_barrier();
         if (c > 0) res_add(c - 1);
         res_issue(c);
-        k_step_plain();
+        if constexpr (TPS == 3) k_step_plain(C);      // NRS == SPC == 3: step c of the first channel block
+        else k_step_plain(RT{});
+      };
+      static_assert(TPS == 1 || NRS == SPC, "peeled steps = one channel block");
+      peeled(std::integral_constant<int, 0>{});
+      peeled(std::integral_constant<int, 1>{});
+      peeled(std::integral_constant<int, 2>{});
+      if constexpr (NRS > 3) {
+        peeled(std::integral_constant<int, 3>{});
+        peeled(std::integral_constant<int, 4>{});
+        peeled(std::integral_constant<int, 5>{});
+        peeled(std::integral_constant<int, 6>{});
+        peeled(std::integral_constant<int, 7>{});
       }
+      static_assert(NRS == 3 || NRS == 8, "peeled steps");
       res_add(NRS - 1);
       g = NRS;
     }
-    for (; g < G; ++g) {
-      __builtin_amdgcn_s_barrier();
-      k_step();
+    if constexpr (TPS == 3) {
+      for (; g < G; g += 3) {                            // G - g is a multiple of SPC = 3
+        __builtin_amdgcn_s_barrier();
+        k_step(std::integral_constant<int, 0>{});
+        __builtin_amdgcn_s_barrier();
+        k_step(std::integral_constant<int, 1>{});
+        __builtin_amdgcn_s_barrier();
+        k_step(std::integral_constant<int, 2>{});
+      }
+    } else {
+      for (; g < G; ++g) {
+        __builtin_amdgcn_s_barrier();
+        k_step(RT{});
+      }
     }
   }
 
@@ -640,10 +732,25 @@ static void launch_h3(const ConvP& p0, hipStream_t st) {
   constexpr int ROWS = BM / W_, SEG = ROWS < W_ ? ROWS : W_, NSEG = ROWS / SEG;
   constexpr int NPI = (NSEG * (SEG + 2) * (W_ + 2) + 7) / 8;
   constexpr int lds = 2 * NPI * 1024 + STAGES * TPS * BN * 128;
+  static_assert(lds <= 160 * 1024, "LDS");
   ConvP p = p0;
   p.tiles_n = p.Cout / BN;
   if (p.splitk < 1) p.splitk = 1;
-  const int tiles = (p.M / BM) * p.tiles_n;
+  const int tiles_m = p.M / BM, tiles = tiles_m * p.tiles_n;
+  {
+    // XCD grid (see the kernel): bytes fetched beyond the L2s ~ pixels * gn + weights * (8 / gn)
+    static const int s_gn = getenv("AFLDM_CONV3H_GN") ? atoi(getenv("AFLDM_CONV3H_GN")) : -1;
+    const double xb = (double)p.M * p.C1, wb = 9.0 * p.Cout * p.C1;
+    int best = 0;
+    double best_cost = xb + 8.0 * wb;
+    for (int gn = 2; gn <= 8; gn *= 2) {
+      if (tiles % 8 || p.tiles_n % gn || tiles_m % (8 / gn)) continue;
+      const double c = xb * gn + wb * (8 / gn);
+      if (c < 0.9 * best_cost) best = gn, best_cost = c;
+    }
+    if (s_gn >= 0) best = (s_gn == 0 || (tiles % 8 == 0 && p.tiles_n % s_gn == 0 && 8 % s_gn == 0 && tiles_m % (8 / s_gn) == 0)) ? s_gn : 0;
+    p.xcd_gn = best;
+  }
   auto kern = k_conv3h<T, BM, W_, BN, WGM, WGN, NPROD, STAGES, MINW, MF, TPS>;
   static bool attr_set = false;
   if (!attr_set) {

@@ -31,6 +31,7 @@ struct ConvP {
   int m_fast;     // tile order of the LDS-DMA kernel: 1 = tile_m fastest (weights outweigh pixels)
   int stage_ok;   // leading dimensions / splits allow the LDS-staged 16-byte epilogue
   int dbg;      // AFLDM_CONV_DBG (timing decomposition only): bit 0 skip the LDS-DMA, bit 1 skip the MFMA phase
+  int xcd_gn;    // conv3h tile order: the XCDs as a (8 / xcd_gn) x xcd_gn grid over (m, n) tiles; 0 = contiguous runs, n fastest
   unsigned* sync;   // in-kernel split-K reduction: 2 zero-initialised words per output tile (arrivals, departures), or NULL
 };
 

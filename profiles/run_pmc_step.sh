@@ -5,7 +5,7 @@
 TAG=${1:-r01}
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 OUT=gpurun_out/pmc_step_$TAG; rm -rf $OUT; mkdir -p $OUT
-CMD="python bench.py --no-graph --steps 4 --warmup 2 --no-cpu-baseline --no-roofline"
+CMD="python bench.py --no-graph --steps 4 --warmup 2 --regions 1 --no-cpu-baseline --no-roofline --no-extras"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o fetch -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o write -- $CMD > $OUT/write.log 2>&1
 python - "$OUT" "$TAG" <<'PY'
@@ -14,7 +14,7 @@ out, tag = sys.argv[1], sys.argv[2]
 
 
 def fam(n):
-    for k in ("k_igemm3", "k_igemm2", "k_igemm", "k_lin_wreg", "k_attn", "k_af_act_plane", "k_af_act_kron", "k_af_act_small",
+    for k in ("k_conv3h", "k_igemm3", "k_igemm2", "k_igemm", "k_lin_wreg", "k_attn", "k_af_act_plane", "k_af_act_kron", "k_af_act_small",
               "k_resample_plane", "k_axis_contract", "k_splitk", "k_gn_apply", "k_gn_partial", "k_conv_cin4", "k_conv_small"):
         if k in n:
             return k
@@ -27,7 +27,7 @@ for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     f = glob.glob(out + "/**/" + name + "_counter_collection.csv", recursive=True)[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == ctr]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    marks = [i for i, r in enumerate(rows) if "k_select_timestep" in r["Kernel_Name"]]
+    marks = [i for i, r in enumerate(rows) if ("k_select_step_row" in r["Kernel_Name"] or "k_select_timestep" in r["Kernel_Name"])]
     lo, hi = marks[2], marks[-1]           # steady state: from the third step's first kernel to the last step's
     nsteps = len(marks) - 3
     for r in rows[lo:hi]:

@@ -417,7 +417,7 @@ H3_CASES = [
     (5, 16, 128, 192, False, False, (42, 43, 44, 48, 49)),
     (5, 8, 384, 384, True, True, (51,)),          # small-plane variants: one 8x8 sample per tile, 3 taps per step
     (3, 8, 768, 96, False, True, (51,)),
-    (8, 4, 768, 768, True, True, (52,)),             # four 4x4 samples per tile, channel blocks split over 2-4 slices
+    (8, 4, 768, 768, True, True, (52,)),           # four 4x4 samples per tile, channel blocks split over 2-4 slices
     (4, 4, 256, 96, False, False, (52,)),
     (2, 16, 384, 96, True, True, (54,)),
     (2, 32, 192, 288, True, True, (55,)),
