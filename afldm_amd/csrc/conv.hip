@@ -1667,12 +1667,13 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
     if (s_h3 && a->KS == 3 && a->C2 == 0 && a->H == a->W && a->Cout % 192 == 0) {
       // tile by plane size; the large tiles only while they still give every CU a workgroup
       const long long t256 = (M / 256) * (a->Cout / 192), t128 = (M / 128) * (a->Cout / 192);
+      const bool bf = elems_per_row == 32;      // (64-byte row pieces: 32 bf16 / 16 fp32)
       if (a->W == 32 && t256 >= 192) vid = 41;
-      else if (a->W == 32 && t128 >= 192 && s_h3 >= 4) vid = 46;
+      else if (a->W == 32 && t128 >= 192 && s_h3 >= 4 && bf) vid = 46;
       else if (a->W == 16 && t128 >= 192) vid = s_h3 == 2 ? 42 : 43;      // 4 consumer waves (64x96) measured best at 16x16
       else if (s_h3 >= 3 && a->W == 8 && M >= 2048 && a->Cout % 96 == 0) vid = 51;
       else if (s_h3 >= 3 && a->W == 4 && M >= 1024 && a->Cout % 96 == 0) vid = 52;
-      else if (s_h3 >= 4 && a->Cout % 96 == 0) {      // small batches: the 96-cout tiles with split channel blocks
+      else if (s_h3 >= 4 && bf && a->Cout % 96 == 0) {      // small batches (bf16; fp32 measured slower: 4.99 vs 4.38 ms/step at batch 1): the 96-cout tiles with split channel blocks
         if (a->W == 32 && M >= 1024) vid = 55;
         else if (a->W == 16 && M >= 256) vid = 54;
         else if (a->W == 8 && M >= 64) vid = 51;

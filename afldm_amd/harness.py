@@ -33,10 +33,16 @@ def vae_decode(vae, x):
 
 @torch.no_grad()
 def shift_ldm(pipeline, num_inference_steps=50, num_shift_steps=16, output_path="results/shift_ldm.gif",
-              input_path=None, generator=None, rank=0, world=1, batch_offsets=True):
+              input_path=None, generator=None, rank=0, world=1, batch_offsets=True, reference_exact=False):
     """batch_offsets: the LOAD passes of this rank's offsets run as ONE batch (samples are independent; the
     cross-frame K/V of the stored pass is shared by the whole batch) instead of the reference's one B = 1
-    sampler run per offset (shift_ldm_ffhq.py:124-151) - 50 UNet evaluations instead of 50 per offset."""
+    sampler run per offset (shift_ldm_ffhq.py:124-151) - 50 UNet evaluations instead of 50 per offset.
+
+    Deviations from the reference flow, switched off by reference_exact=True:
+    * `input_path`: the image is resized to sample_size * VAE ratio (256) so that its latent has the UNet's
+      sample_size; the reference resizes to (sample_size, sample_size) = 32 x 32 BEFORE the VAE
+      (shift_ldm_ffhq.py:110-113), i.e. inverts a 4 x 4 latent.
+    * the initial noise is drawn on the CPU (device independent) instead of on the GPU (:118-122)."""
     device = pipeline.device
     vae, unet, scheduler = pipeline.vae, pipeline.unet, pipeline.scheduler
     pipeline.set_progress_bar_config(disable=True)
@@ -59,15 +65,18 @@ def shift_ldm(pipeline, num_inference_steps=50, num_shift_steps=16, output_path=
 
     try:
         if input_path is not None:
-            size = unet.config.sample_size * ratio
+            size = unet.config.sample_size * (1 if reference_exact else ratio)
             tensor = vae_encode(vae, image_to_tensor(input_path, (size, size)).to(device))
             scheduler.set_timesteps(num_inference_steps, device=device)
             init_latent = pipeline.ddim_inversion(tensor, bar=False)
         else:
             # CPU-side draw (seedable, device independent) — the reference draws on the GPU
             # (shift_ldm_ffhq.py:118-122), which is not reproducible across devices
-            init_latent = randn_tensor((1, unet.config.in_channels, unet.config.sample_size, unet.config.sample_size),
-                                       generator=generator).to(device)
+            shape = (1, unet.config.in_channels, unet.config.sample_size, unet.config.sample_size)
+            if reference_exact:
+                init_latent = randn_tensor(shape, device=device, generator=generator)
+            else:
+                init_latent = randn_tensor(shape, generator=generator).to(device)
         attn_state.reset()
         denoised = denoise(init_latent)
         attn_state.to_load()

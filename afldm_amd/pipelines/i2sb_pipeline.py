@@ -13,12 +13,15 @@ class I2SBLDMPipeline(MyLDMPipeline):
 
     @torch.no_grad()
     def __call__(self, images, generator=None, is_ode=False, num_inference_steps=50, output_type="pil",
-                 return_dict=True, **kwargs):
+                 return_dict=True, reference_exact=False, **kwargs):
         """images: [B, 3, H, W] tensor in [-1, 1] (the reference's VaeImageProcessor.preprocess leaves
-        such tensors unchanged)."""
+        such tensors unchanged).  The posterior sample of the start latent is drawn from `generator` (seeded runs are
+        reproducible); the reference calls latent_dist.sample() without it (i2sb_pipeline.py) - reference_exact=True
+        does the same."""
         if self.vae is None:
             raise NotImplementedError("I2SBLDMPipeline needs a VAE to encode the degraded image")
-        start = self.vae.encode(images.to(device=self.device, dtype=self.unet.dtype)).latent_dist.sample(generator)
+        start = self.vae.encode(images.to(device=self.device, dtype=self.unet.dtype)).latent_dist.sample(
+            None if reference_exact else generator)
         latents = self._bridge(start * self.vae.config.scaling_factor, num_inference_steps, is_ode, generator)
         return self._deliver(latents, output_type, return_dict)
 
