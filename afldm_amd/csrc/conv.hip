@@ -1918,6 +1918,9 @@ static Exec resolve_exec(const afldm_conv_args* a) {
 // weights-in-registers kernel for the short-K attention projections (lin.hip)
 int lin_wreg_bm(const afldm_conv_args* a);
 int lin_wreg_launch(const afldm_conv_args* a, hipStream_t st);
+// operands-straight-to-registers kernel for 1x1 convolutions / dense layers over few rows (skinny.hip)
+int skinny_stats_splits(const afldm_conv_args* a);      // 0: does not apply; else the statistics splits of its output
+int skinny_launch(const afldm_conv_args* a, hipStream_t st);
 
 // conv_in on MFMA (k_conv_cin4_mfma): bf16, Cin = 4, 3x3, whole 128-pixel blocks inside one sample
 template <typename T>
@@ -1938,6 +1941,10 @@ static int stats_mode(const afldm_conv_args* a, const Exec& e, int* S) {
                     a->Cout % 4 == 0;
   const bool vec16 = a->y_ld % eo == 0 && (!a->residual || a->res_ld % eo == 0) && (!a->temb || a->temb_stride % eo == 0) &&
                      a->Cout % eo == 0;
+  if (const int sk = skinny_stats_splits(a)) {
+    *S = sk;
+    return ST_EPILOGUE;
+  }
   if (e.pl.kind == 0 && e.splitk > 1 && e.fused) {
     const int rw = kVariants[e.vid].bm / e.splitk;
     *S = rw >= HW ? 1 : HW / rw;
@@ -2020,6 +2027,7 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
   if (a->stats_out) smode = stats_mode<T>(a, ex, &p.stats_S);
   int rc = AFLDM_OK;
   if (lin_wreg_bm(a)) return lin_wreg_launch(a, st);
+  if (skinny_stats_splits(a)) return skinny_launch(a, st);
   if (pl.kind == 1 && cin4_mfma_ok<T>(a)) {
     if (smode == ST_EPILOGUE) p.stats_out = a->stats_out;
     const int lds = CIN4_BM * (a->Cout + 8) * 2 + 4 * a->Cout * 2 * (int)sizeof(float);
@@ -2132,6 +2140,7 @@ extern "C" int afldm_conv2d_fused_splitk(int enable) {
 extern "C" int afldm_conv2d_variant(const afldm_conv_args* a) {
   if (!a || (a->dtype != AFLDM_F32 && a->dtype != AFLDM_BF16)) return -1;
   const Exec e = a->dtype == AFLDM_F32 ? resolve_exec<float>(a) : resolve_exec<bf16>(a);
+  if (skinny_stats_splits(a)) return -16;        // skinny.hip
   if (e.pl.kind != 0) return -1 - e.pl.kind;
   return e.vid | (e.splitk << 8) | (e.fused << 16);
 }
@@ -2146,7 +2155,7 @@ extern "C" int afldm_conv2d_stats_splits(const afldm_conv_args* a) {
 
 extern "C" size_t afldm_conv2d_workspace(const afldm_conv_args* a) {
   if (!a || (a->dtype != AFLDM_F32 && a->dtype != AFLDM_BF16)) return 0;
-  if (lin_wreg_bm(a)) return 0;
+  if (lin_wreg_bm(a) || skinny_stats_splits(a)) return 0;
   Plan pl = make_plan(a, a->dtype == AFLDM_F32 ? 16 : 32);
   if (pl.kind != 0 || pl.splitk <= 1) return 0;
   return (size_t)pl.splitk * a->B * a->H * a->W * a->Cout * sizeof(float);

@@ -519,6 +519,56 @@ def test_conv2d_emits_groupnorm_statistics(dtype, case):
     assert (fused.float() - alone.float()).abs().max() <= (1e-5 if dtype == torch.float32 else 2e-2)
 
 
+SKINNY_CASES = [
+    # B, H, W, C1, C2, Cout, residual, temb       (1x1 convolutions / dense layers over few rows: skinny.hip)
+    (16, 1, 1, 3072, 0, 3072, True, True),     # a 2x2-level 3x3 convolution in its dense form (batch 16)
+    (1, 1, 1, 768, 0, 768, False, False),      # one row
+    (8, 2, 2, 768, 768, 768, True, False),     # two inputs (virtual concat), 8 samples of 4 pixels in one 64-row block
+    (5, 4, 4, 256, 0, 96, True, True),         # 80 rows: a ragged second block, 4 samples per block
+    (1, 8, 8, 384, 0, 384, True, False),       # one 8x8 sample = one block
+    (3, 8, 8, 384, 0, 416, False, True),       # three blocks; bf16: K = 384 = 4 slices of 3 steps, 13 blocks of 32 couts
+    (2, 16, 16, 256, 0, 64, True, True),       # H*W = 256: four statistic splits per sample
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", SKINNY_CASES)
+def test_conv1x1_few_rows_operands_straight_to_registers(dtype, case):
+    """skinny.hip (M <= 1024 rows, K a multiple of 8 MFMA steps: one launch, no LDS staging, no split-K slabs) against
+    F.conv2d in fp32 on the same (rounded) inputs, with bias, time embedding, residual, two-pointer input and the
+    attached GroupNorm statistics; bit-identical across reruns; the kernel really ran."""
+    import ctypes
+    from afldm_amd import _lib
+    ops = _ops()
+    B, H, W, C1, C2, Cout, use_res, use_temb = case
+    g = torch.Generator().manual_seed(C1 + Cout + B)
+    x = rnd(dtype, torch.randn(B, C1 + C2, H, W, generator=g))
+    w = rnd(dtype, torch.randn(Cout, C1 + C2, 1, 1, generator=g) / (C1 + C2) ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    temb = rnd(dtype, torch.randn(B, Cout, generator=g)) if use_temb else None
+    res = rnd(dtype, torch.randn(B, Cout, H, W, generator=g)) if use_res else None
+    ref = F.conv2d(x, w, b)
+    if use_temb:
+        ref = ref + temb[:, :, None, None]
+    if use_res:
+        ref = ref + res
+    kw = dict(x2=nhwc(x[:, C1:], dtype) if C2 else None, temb=temb.to(device="cuda", dtype=dtype) if use_temb else None,
+              temb_stride=Cout if use_temb else 0, residual=nhwc(res, dtype) if use_res else None)
+    x1, wp, bias = nhwc(x[:, :C1], dtype), ops.pack_weight(w.cuda(), dtype), b.cuda()
+    probe = ops.conv_args(x1, wp, bias, kw["x2"], kw["temb"], kw["temb_stride"], kw["residual"],
+                          torch.empty(B, H, W, Cout, device="cuda", dtype=dtype))
+    assert _lib.lib.afldm_conv2d_variant(ctypes.byref(probe)) == -16, "the skinny kernel does not take this shape"
+    ys = [ops.conv2d(x1, wp, bias, want_stats=True, **kw) for _ in range(2)]
+    close(back(ys[0]), ref, dtype, f"skinny {case}", bf16_rms=6e-3)
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0].gn_partial, ys[1].gn_partial)
+    assert ys[0].gn_partial.shape == (B, max(1, H * W // 64), Cout, 2)
+    yv = ys[0].float()
+    got = ys[0].gn_partial.double().sum(1).cpu()
+    s1, s2 = yv.sum((1, 2)).cpu(), (yv * yv).sum((1, 2)).cpu()
+    assert (got[..., 0] - s1).abs().max() <= 1e-4 * (1 + s1.abs().max())
+    assert (got[..., 1] - s2).abs().max() <= 1e-4 * (1 + s2.abs().max())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("C1,C2,Cout", [(64, 0, 64), (96, 32, 48)])
 def test_conv3x3_on_2x2_plane_runs_as_one_dense_layer(dtype, C1, C2, Cout):
