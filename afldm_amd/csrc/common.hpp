@@ -209,7 +209,20 @@ __device__ __forceinline__ void gn_channel_sums(const GnStats& s, int b, int c, 
   const float* st = second ? s.st2 : s.st1;
   const int Cs = second ? s.C2 : s.C1, S = second ? s.S2 : s.S1, cc = second ? c - s.C1 : c;
   const float* q = st + ((size_t)b * S * Cs + cc) * 2;
-  for (int i = 0; i < S; ++i) {
+  // eight independent loads in flight, then the adds in split order (a rolled loop waited out one load latency per
+  // split: the prologue of every GroupNorm consumer at small batch)
+  int i = 0;
+  for (; i + 8 <= S; i += 8) {
+    f32x2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x2*>(q + (size_t)(i + u) * Cs * 2);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      s1 += (double)v[u][0];
+      s2 += (double)v[u][1];
+    }
+  }
+  for (; i < S; ++i) {
     const f32x2 v = *reinterpret_cast<const f32x2*>(q + (size_t)i * Cs * 2);
     s1 += (double)v[0];
     s2 += (double)v[1];
