@@ -265,20 +265,59 @@ __device__ __forceinline__ void gn_group_sums_wave(const GnStats& s, int b, int 
   }
 }
 
-// Per-lane GroupNorm (mean, rstd) for a wave whose lanes each own one (sample b, group g) key
-// (`live` = the lane has one): the distinct keys are visited one at a time, wave-cooperatively.
+// Per-lane GroupNorm (mean, rstd) for a wave whose lanes each own one (sample b, group g) key (`live` = the lane has
+// one; ALL 64 lanes must call).  Up to four distinct keys are resolved per round: the keys are numbered with ballots,
+// quarter q of the wave (16 lanes) walks the cpg x S partials of key q (channel-major, fixed order) and folds them
+// with xor-shuffles inside the quarter - one load round trip per round instead of one per key (a wave of the N = 2
+// activation spans 3-4 groups).
 __device__ __forceinline__ void gn_wave_keys(const GnStats& s, bool live, int b, int g, int cpg, double n, float eps,
                                              int lane, float& mean, float& rstd) {
   bool done = !live;
   mean = 0.f;
   rstd = 1.f;
+  const int smax = s.S1 > s.S2 ? s.S1 : s.S2;
   while (__any(!done)) {
-    const int leader = __ffsll((unsigned long long)__ballot(!done)) - 1;
-    const int kb = __shfl(b, leader, 64), kg = __shfl(g, leader, 64);
-    double s1, s2;
-    gn_group_sums_wave(s, kb, kg, cpg, lane, s1, s2);
-    if (!done && b == kb && g == kg) {
-      gn_mean_rstd(s1, s2, n, eps, mean, rstd);
+    int slot = -1, nk = 0, kb[4], kg[4];                    // this lane's key number in the round, keys of the round
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned long long open = __ballot(!done && slot < 0);
+      kb[k] = 0;
+      kg[k] = 0;
+      if (open) {                                           // (wave-uniform)
+        const int leader = __ffsll(open) - 1;
+        kb[k] = __shfl(b, leader, 64);
+        kg[k] = __shfl(g, leader, 64);
+        if (!done && slot < 0 && b == kb[k] && g == kg[k]) slot = k;
+        nk = k + 1;
+      }
+    }
+    const int q = lane >> 4, ql = lane & 15;
+    const int qb = q == 0 ? kb[0] : q == 1 ? kb[1] : q == 2 ? kb[2] : kb[3];
+    const int qg = q == 0 ? kg[0] : q == 1 ? kg[1] : q == 2 ? kg[2] : kg[3];
+    double s1 = 0.0, s2 = 0.0;
+    if (q < nk) {
+      for (int j = ql; j < cpg * smax; j += 16) {
+        const int c = qg * cpg + j / smax, sp = j - (j / smax) * smax;
+        const bool second = c >= s.C1;
+        const int S = second ? s.S2 : s.S1;
+        if (sp < S) {
+          const float* st = second ? s.st2 : s.st1;
+          const int Cs = second ? s.C2 : s.C1, cc = second ? c - s.C1 : c;
+          const f32x2 v = *reinterpret_cast<const f32x2*>(st + (((size_t)qb * S + sp) * Cs + cc) * 2);
+          s1 += (double)v[0];
+          s2 += (double)v[1];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {                       // (xor < 16: stays inside the quarter)
+      s1 += __shfl_xor(s1, o, 64);
+      s2 += __shfl_xor(s2, o, 64);
+    }
+    const int src = (slot < 0 ? 0 : slot) * 16;
+    const double t1 = __shfl(s1, src, 64), t2 = __shfl(s2, src, 64);
+    if (slot >= 0) {
+      gn_mean_rstd(t1, t2, n, eps, mean, rstd);
       done = true;
     }
   }
