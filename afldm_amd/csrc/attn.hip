@@ -433,14 +433,22 @@ static int attn_launch(const void* q, int ldq, const void* k, int ldk, const voi
   p.scale_log2e = scale * 1.4426950408889634f;
   // 8 waves (256 queries share every staged chunk) once a (batch, head) has that many queries,
   // 4 waves below; a wave always owns 32 queries
-  const int waves = Tq >= 256 ? 8 : 4;
+  // (and 2 / 1 waves for the 8x8 / 4x4 planes: a 4-wave workgroup of the 4x4 level was one wave of 16 queries and
+  //  three idle ones)
+  static const bool small_ok = !(getenv("AFLDM_ATTN_NO_SMALL") && atoi(getenv("AFLDM_ATTN_NO_SMALL")) != 0);
+  // only with >= 1024 workgroups: with few of them (small batch) four waves stage the K / V chunks faster
+  // (same box, ms/step: batch 64 5.499 -> 5.473; batch 8 2.543 -> 2.562, batch 1 2.295 -> 2.308 without this limit)
+  const bool many = (long long)B * heads >= 1024;
+  const int waves = Tq >= 256 ? 8 : (Tq > 64 || !small_ok || !many) ? 4 : Tq > 32 ? 2 : 1;
   p.qblocks = (Tq + 32 * waves - 1) / (32 * waves);
   const int grid = B * heads * p.qblocks;
   constexpr int KPF = Mma<T>::KPF;
   const int nkf = d / KPF + 1, nd = d / 16 + 1;    // + 1: room for the -m_run channel / the row of ones
   const bool ragged = Tk % KC != 0;
   const bool ok = waves == 8 ? (ragged ? attn_launch_nw<T, 8, true>(p, nd, nkf, grid, st) : attn_launch_nw<T, 8, false>(p, nd, nkf, grid, st))
-                             : (ragged ? attn_launch_nw<T, 4, true>(p, nd, nkf, grid, st) : attn_launch_nw<T, 4, false>(p, nd, nkf, grid, st));
+                  : waves == 4 ? (ragged ? attn_launch_nw<T, 4, true>(p, nd, nkf, grid, st) : attn_launch_nw<T, 4, false>(p, nd, nkf, grid, st))
+                  : waves == 2 ? (ragged ? attn_launch_nw<T, 2, true>(p, nd, nkf, grid, st) : attn_launch_nw<T, 2, false>(p, nd, nkf, grid, st))
+                               : (ragged ? attn_launch_nw<T, 1, true>(p, nd, nkf, grid, st) : attn_launch_nw<T, 1, false>(p, nd, nkf, grid, st));
   if (!ok) {
     set_error("afldm_attention: unsupported head_dim %d", d);
     return AFLDM_ESHAPE;
