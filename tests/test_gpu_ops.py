@@ -656,7 +656,8 @@ def test_conv2d_errors_are_reported_not_fatal():
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,Bk,heads,T,d", [(2, 2, 8, 1024, 24), (3, 1, 16, 256, 24), (2, 2, 16, 64, 24),
-                                            (4, 2, 32, 16, 24), (2, 1, 32, 4, 24), (2, 2, 4, 64, 16)])
+                                            (4, 2, 32, 16, 24), (2, 1, 32, 4, 24), (2, 2, 4, 64, 16),
+                                            (64, 64, 16, 64, 24), (32, 16, 32, 16, 24), (40, 40, 32, 4, 24)])   # >= 1024 (batch, head) pairs: 2- / 1-wave workgroups
 def test_attention(dtype, B, Bk, heads, T, d):
     ops = _ops()
     g = torch.Generator().manual_seed(6)
