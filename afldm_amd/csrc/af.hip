@@ -606,7 +606,10 @@ __global__ void __launch_bounds__(256) k_af_act_small(AfP<T> p) {
       }
     // hp stays a run-time loop: X/Y are indexed statically (registers), the matrix rows with a
     // wave-uniform run-time offset (scalar loads), which keeps N = 8 inside the VGPR budget.
-#pragma unroll 1
+    // (N = 2: fully unrolled - all 16 coefficients arrive in one batch of scalar loads instead of one dependent batch
+    //  per row of the upsampled plane)
+    constexpr int HP_UNROLL = N == 2 ? 4 : 1;
+#pragma unroll HP_UNROLL
     for (int hp = 0; hp < H2; ++hp) {
       float t1[N];
 #pragma unroll
