@@ -34,12 +34,15 @@ struct SkP {
 
 constexpr int SK_WAVES = 8, SK_ROWS = 64, SK_MT = SK_ROWS / 16, SK_U = 4;
 
-template <typename T>
+// MTT: row tiles a workgroup can hold (4, or 1 for launches of <= 16 rows); U: K steps per register group - the
+// one-tile form fetches 12 steps at once (a 3072-wide K slice of 384 = ONE load round trip instead of two or three;
+// at batch 1 a dense layer is launch + load latency and little else).
+template <typename T, int MTT, int U>
 __global__ void __launch_bounds__(SK_WAVES * 64) k_skinny(SkP p) {
   typedef Mma<T> MM;
   typedef typename MM::Chunk Chunk;
   constexpr int EPC = MM::EPC, KPF = MM::KPF;
-  __shared__ f32x4 sAcc[SK_WAVES][SK_MT][64];
+  __shared__ f32x4 sAcc[SK_WAVES][MTT][64];
   __shared__ float sOut[SK_WAVES / 2][SK_ROWS][16 + 1];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, lg = lane >> 4;
@@ -55,23 +58,23 @@ __global__ void __launch_bounds__(SK_WAVES * 64) k_skinny(SkP p) {
   const int ldx = second ? p.K - p.C1 : p.C1;
   const int kx = (second ? kbase - p.C1 : kbase) + lg * EPC;
   const T* wrow = (const T*)p.w + (size_t)(n0 + li) * p.K + kbase + lg * EPC;
-  const T* xrow[SK_MT];
+  const T* xrow[MTT];
 #pragma unroll
-  for (int mt = 0; mt < SK_MT; ++mt) {
+  for (int mt = 0; mt < MTT; ++mt) {
     int row = m0 + mt * 16 + li;
     row = row < p.M ? row : p.M - 1;                      // rows past the end repeat the last one (never stored)
     xrow[mt] = xs + (size_t)row * ldx + kx;
   }
-  f32x4 acc[SK_MT];
+  f32x4 acc[MTT];
 #pragma unroll
-  for (int mt = 0; mt < SK_MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mt = 0; mt < MTT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int mtn = (p.M - m0 + 15) / 16;                  // row tiles that exist in this block (wave-uniform): absent ones cost no loads
 
-  // groups of SK_U K steps, double buffered in registers: the loads of group g + 1 are issued before group g's MFMAs
-  Chunk a[2][SK_U], b[2][SK_U][SK_MT];
+  // groups of U K steps, double buffered in registers: the loads of group g + 1 are issued before group g's MFMAs
+  Chunk a[2][U], b[2][U][MTT];
   auto load_group = [&](int buf, int ks0) {
 #pragma unroll
-    for (int u = 0; u < SK_U; ++u) {
+    for (int u = 0; u < U; ++u) {
       if (ks0 + u < nks) {                                // (wave-uniform)
         const int off = (ks0 + u) * KPF;
 #if defined(AFLDM_SK_NOW)                                 // (timing decomposition builds: no weight / no x loads; garbage results)
@@ -80,7 +83,7 @@ __global__ void __launch_bounds__(SK_WAVES * 64) k_skinny(SkP p) {
         a[buf][u] = ld16<Chunk>(wrow + off);
 #endif
 #pragma unroll
-        for (int mt = 0; mt < SK_MT; ++mt) {
+        for (int mt = 0; mt < MTT; ++mt) {
           if (mt < mtn) {
 #if defined(AFLDM_SK_NOX)
             b[buf][u][mt] = a[buf][u];
@@ -94,29 +97,29 @@ __global__ void __launch_bounds__(SK_WAVES * 64) k_skinny(SkP p) {
   };
   auto mma_group = [&](int buf, int ks0) {
 #pragma unroll
-    for (int u = 0; u < SK_U; ++u) {
+    for (int u = 0; u < U; ++u) {
       if (ks0 + u < nks) {
 #pragma unroll
-        for (int mt = 0; mt < SK_MT; ++mt)
+        for (int mt = 0; mt < MTT; ++mt)
           if (mt < mtn) MM::mma(acc[mt], a[buf][u], b[buf][u][mt]);
       }
     }
   };
   load_group(0, 0);
-  for (int ks0 = 0; ks0 < nks; ks0 += 2 * SK_U) {
-    load_group(1, ks0 + SK_U);
+  for (int ks0 = 0; ks0 < nks; ks0 += 2 * U) {
+    load_group(1, ks0 + U);
     mma_group(0, ks0);
-    load_group(0, ks0 + 2 * SK_U);
-    mma_group(1, ks0 + SK_U);
+    load_group(0, ks0 + 2 * U);
+    mma_group(1, ks0 + U);
   }
 
   // the K slices meet in LDS (fragment layout, 16 bytes per lane: conflict free)
 #pragma unroll
-  for (int mt = 0; mt < SK_MT; ++mt) sAcc[wave][mt][lane] = acc[mt];
+  for (int mt = 0; mt < MTT; ++mt) sAcc[wave][mt][lane] = acc[mt];
   __syncthreads();
   const bool want_stats = p.stats != nullptr;
-  for (int pi = wave; pi < NT * SK_MT; pi += SK_WAVES) {  // (cout tile, row tile) pairs, fixed summation order
-    const int nt = pi / SK_MT, mt = pi - nt * SK_MT;
+  for (int pi = wave; pi < NT * MTT; pi += SK_WAVES) {  // (cout tile, row tile) pairs, fixed summation order
+    const int nt = pi / MTT, mt = pi - nt * MTT;
     f32x4 v = sAcc[nt * NS][mt][lane];
     for (int s = 1; s < NS; ++s) v += sAcc[nt * NS + s][mt][lane];
     const int row = m0 + mt * 16 + li, n = nblk + nt * 16 + 4 * lg;
@@ -221,8 +224,13 @@ int skinny_launch(const afldm_conv_args* a, hipStream_t st) {
   p.stats_S = skinny_stats_splits(a);
   p.ns = skinny_slices(a);
   const dim3 grid(p.N / (16 * (SK_WAVES / p.ns)), (p.M + SK_ROWS - 1) / SK_ROWS);
-  if (a->dtype == AFLDM_F32) k_skinny<float><<<grid, SK_WAVES * 64, 0, st>>>(p);
-  else k_skinny<bf16><<<grid, SK_WAVES * 64, 0, st>>>(p);
+  if (p.M <= 16) {
+    if (a->dtype == AFLDM_F32) k_skinny<float, 1, 12><<<grid, SK_WAVES * 64, 0, st>>>(p);
+    else k_skinny<bf16, 1, 12><<<grid, SK_WAVES * 64, 0, st>>>(p);
+  } else {
+    if (a->dtype == AFLDM_F32) k_skinny<float, SK_MT, SK_U><<<grid, SK_WAVES * 64, 0, st>>>(p);
+    else k_skinny<bf16, SK_MT, SK_U><<<grid, SK_WAVES * 64, 0, st>>>(p);
+  }
   return check_launch("afldm_conv2d(skinny)");
 }
 
