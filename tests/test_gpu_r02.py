@@ -181,6 +181,37 @@ def test_full_af_vae_batch128_c4():
         assert p16 > 20.0 and p16 >= p32 - 3.0
 
 
+def test_i2sb_per_gpu_share_of_c5():
+    """BASELINE configs[4] (C5) as one GPU sees it: 32 samples (256 sharded over 8) through the 99 UNet evaluations of
+    the 100-step I2SB bridge (is_ode, as scripts/shift_ldm_sr.py runs it) on the FFHQ-size AF-UNet.  The oracle cannot
+    run this size in test time (its first three evaluations are pinned by test_ffhq_three_step_trajectories); here:
+    finite results, bit-identical reruns, and sample independence - the first two samples of the batch-32 fp32 run
+    equal a batch-2 run of the same latents (different tile / split-K plans per batch size) to 1e-3."""
+    from afldm_amd.pipelines.i2sb_pipeline import I2SBLDMPipeline
+    from afldm_amd.schedulers.i2sb import I2SBScheduler
+    from afldm_amd.configs import FFHQ_DDIM_CONFIG
+    cfg = {k: v for k, v in FFHQ_DDIM_CONFIG.items() if k != "set_alpha_to_one"}
+    start = torch.randn(32, 4, 32, 32, generator=torch.Generator().manual_seed(99))
+    outs = {}
+    for dtype in (torch.bfloat16, torch.float32):
+        unet, _, _ = build_unet("ffhq", dtype)
+        pipe = I2SBLDMPipeline(None, unet, I2SBScheduler.from_config(cfg))
+        pipe.set_progress_bar_config(disable=True)
+        x = start.cuda().to(dtype)
+        a = pipe._bridge(x, 100, True, None)
+        assert a.shape == (32, 4, 32, 32) and torch.isfinite(a.float()).all()
+        if dtype == torch.bfloat16:
+            assert torch.equal(a, pipe._bridge(x, 100, True, None))
+        else:
+            two = pipe._bridge(x[:2], 100, True, None)
+            assert rel_rms(a[:2].float(), two.float().cpu()) <= 1e-3
+        outs[dtype] = a.float().cpu()
+        del unet, pipe
+    r = rel_rms(outs[torch.bfloat16], outs[torch.float32])
+    print(f"[C5] 99-evaluation I2SB bridge, batch 32: bf16 vs fp32 rel-RMS {r:.3e}")
+    assert r <= 0.15
+
+
 # ------------------------------------------------------------------------------------------------ item 9
 def test_ffhq_equivariance_bf16_vs_fp32():
     """The property the model exists for, in the BENCHMARKED precision at FFHQ size: the masked latent-space
