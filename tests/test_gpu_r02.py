@@ -181,6 +181,28 @@ def test_full_af_vae_batch128_c4():
         assert p16 > 20.0 and p16 >= p32 - 3.0
 
 
+def test_ddim_per_gpu_share_of_c3():
+    """BASELINE configs[2] (C3) as one GPU sees it: its 64-sample shard of the batch-512 run through all 50 DDIM steps
+    on the FFHQ-size AF-UNet (bf16, graph-replayed engine = the bench workload run to completion).  Finite latents,
+    bit-identical reruns, and sample independence: the shard's first two samples against a batch-2 engine on the same
+    noise (other tile / split-K / kernel choices per batch size), in fp32 to 1e-3 and in bf16 to 5e-2."""
+    from afldm_amd.engine import DenoiseEngine
+    from afldm_amd.schedulers.ddim import ffhq_ddim_scheduler
+    noise = torch.randn(64, 4, 32, 32, generator=torch.Generator().manual_seed(512))
+    for dtype, tol in ((torch.bfloat16, 5e-2), (torch.float32, 1e-3)):
+        unet, _, _ = build_unet("ffhq", dtype)
+        big = DenoiseEngine(unet, ffhq_ddim_scheduler(), 64, 50, use_graph=True)
+        a = big.run(noise)
+        assert a.shape == (64, 4, 32, 32) and torch.isfinite(a).all()
+        if dtype == torch.bfloat16:
+            assert torch.equal(a, big.run(noise))
+        two = DenoiseEngine(unet, ffhq_ddim_scheduler(), 2, 50, use_graph=True).run(noise[:2])
+        r = rel_rms(a[:2], two.cpu())
+        print(f"[C3] 50-step DDIM, batch 64 vs batch 2, {dtype}: rel-RMS {r:.3e}")
+        assert r <= tol, (dtype, r)
+        del big, unet
+
+
 def test_i2sb_per_gpu_share_of_c5():
     """BASELINE configs[4] (C5) as one GPU sees it: 32 samples (256 sharded over 8) through the 99 UNet evaluations of
     the 100-step I2SB bridge (is_ode, as scripts/shift_ldm_sr.py runs it) on the FFHQ-size AF-UNet.  The oracle cannot
