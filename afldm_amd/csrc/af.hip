@@ -608,7 +608,7 @@ __global__ void __launch_bounds__(256) k_af_act_small(AfP<T> p) {
     // wave-uniform run-time offset (scalar loads), which keeps N = 8 inside the VGPR budget.
     // (N = 2: fully unrolled - all 16 coefficients arrive in one batch of scalar loads instead of one dependent batch
     //  per row of the upsampled plane)
-    constexpr int HP_UNROLL = N == 2 ? 4 : 1;
+    constexpr int HP_UNROLL = N == 2 ? 4 : N == 4 ? 8 : 1;
 #pragma unroll HP_UNROLL
     for (int hp = 0; hp < H2; ++hp) {
       float t1[N];
@@ -988,13 +988,18 @@ static int af_act_dispatch(const void* x1, int C1, const void* x2, int C2, const
   p.eps = eps;
   p.x1 = (const T*)x1; p.x2 = (const T*)x2; p.gs = gs; p.gamma = gamma; p.beta = beta;
   p.U = U; p.D = D; p.y = (T*)y; p.C1 = C1; p.C2 = C2; p.G = G; p.B = B;
+  // bit mask 4 / 8: plane sizes run on the VALU kernel instead of the Kronecker MFMA kernel.  N = 4 (default): one thread
+  // per plane with the loop over the upsampled rows fully unrolled (all 64 coefficients in SGPRs) beats the MFMA form,
+  // whose workgroups each stage a 64 KB constant image: 5.251 -> 5.229 ms/step (same box).  N = 8 needs 256 coefficients
+  // per row step and stays on MFMA (VALU: 5.25 -> 5.51).
+  static const int s_small = getenv("AFLDM_AF_SMALL_N") ? atoi(getenv("AFLDM_AF_SMALL_N")) : 4;
   switch (N) {
     case 2: return launch_af_small<T, 2>(p, st);
     case 4:
-      if (packed && p.C1 % 16 == 0 && p.C2 % 16 == 0) return launch_af_kron<T, 4>(p, st);
+      if (packed && p.C1 % 16 == 0 && p.C2 % 16 == 0 && !(s_small & 4)) return launch_af_kron<T, 4>(p, st);
       return launch_af_small<T, 4>(p, st);
     case 8:
-      if (packed && p.C1 % 16 == 0 && p.C2 % 16 == 0) return launch_af_kron<T, 8>(p, st);
+      if (packed && p.C1 % 16 == 0 && p.C2 % 16 == 0 && !(s_small & 8)) return launch_af_kron<T, 8>(p, st);
       return launch_af_small<T, 8>(p, st);
     case 16: return launch_af_mfma<T, 16>(p, st);
     case 32: return launch_af_mfma<T, 32>(p, st);
