@@ -1639,6 +1639,12 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
       int z = 1;
       for (int c = 2; c <= 4; ++c)
         if (ncb % c == 0 && tiles * c <= 320) z = c;
+      // AFLDM_CONV3H_Z1=1: no slices from 128 tiles on (the 4x4 level at batch 64 through the per-sample epilogue of the
+      // multi-sample tiles: 12.6 MB less slab traffic and one launch less per layer, conv3x3 family 1.52x -> 1.43x of
+      // its algorithmic bytes) - but 128 workgroups walking 36 K steps lose to 256 walking 18 plus the reduction:
+      // 5.37 -> 5.50 ms/step.  Off.
+      static const int s_z1 = getenv("AFLDM_CONV3H_Z1") ? atoi(getenv("AFLDM_CONV3H_Z1")) : 0;
+      if (s_z1 && tiles >= 128 && elems_per_row == 32) z = 1;
       return z;
     }
     if (kVariants[v].ver == 4 && kVariants[v].stages == 3 && bn_ == 192) {
@@ -1961,6 +1967,10 @@ static int stats_mode(const afldm_conv_args* a, const Exec& e, int* S) {
   if (e.pl.kind == 0 && e.splitk == 1 && kVariants[e.vid].ver >= 2 && HW % kVariants[e.vid].bm == 0 && vec16 &&
       !getenv("AFLDM_CONV_NOSTAGE")) {
     *S = HW / kVariants[e.vid].bm;
+    return ST_EPILOGUE;
+  }
+  if (sizeof(T) == 2 && e.pl.kind == 0 && e.splitk == 1 && kVariants[e.vid].ver == 6 && kVariants[e.vid].bm % HW == 0 && vec16) {
+    *S = 1;           // halo-patch tiles of several whole samples (4x4 planes): one record per sample from the epilogue
     return ST_EPILOGUE;
   }
   if (e.pl.kind == 0 && e.splitk == 1 && kVariants[e.vid].ver >= 2 && kVariants[e.vid].ver <= 4 && HW == 1 && vec16 &&

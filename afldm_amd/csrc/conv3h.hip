@@ -488,16 +488,20 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
       // tile is staged in bf16 - ONE pass for all BM rows (half the LDS bytes of an fp32 tile, two barriers fewer),
       // then leaves as whole rows, 16 bytes per lane; per-channel GroupNorm partial sums of the stored values
       // accumulated by the thread that owns the column (fixed order, no atomics).
+      // A tile of several whole samples (NSEG > 1: the 4x4 planes) carries one (bias + temb) vector and one statistics
+      // record per sample.
       constexpr int NTC = NWC * 64, EO = 8, CPR = BN / EO, RPI = NTC / CPR, OROW = BN + 8;
-      static_assert(1024 + BM * OROW * 2 <= LDS_TOTAL && BN * 4 <= 1024 && RPI * BN * 8 <= LDS_TOTAL, "staging tile");
-      float* sB = reinterpret_cast<float*>(smem);        // [BN] bias + time embedding of this tile (one sample)
-      T* sO = reinterpret_cast<T*>(smem + 1024);         // [BM][OROW]
+      constexpr int SB_BYTES = ((NSEG * BN * 4 + 1023) / 1024) * 1024, HWT = BM / NSEG;      // rows of one sample segment
+      static_assert(SB_BYTES + BM * OROW * 2 <= LDS_TOTAL && RPI * BN * 8 <= LDS_TOTAL, "staging tile");
+      float* sB = reinterpret_cast<float*>(smem);        // [NSEG][BN] bias + time embedding per sample of this tile
+      T* sO = reinterpret_cast<T*>(smem + SB_BYTES);     // [BM][OROW]
       const T* temb = (const T*)p.temb;
       const int etid = cw * 64 + lane;
       __syncthreads();                                    // pipeline buffers idle
-      for (int c = etid; c < BN; c += NTC) {
-        float v = p.bias ? p.bias[n0 + c] : 0.f;
-        if (temb) v += to_f32(temb[(size_t)b_tile * p.temb_stride + (n0 + c) % p.temb_mod]);
+      for (int c = etid; c < NSEG * BN; c += NTC) {
+        const int sgi = c / BN, cc = c - sgi * BN;
+        float v = p.bias ? p.bias[n0 + cc] : 0.f;
+        if (temb) v += to_f32(temb[(size_t)(b_tile + sgi) * p.temb_stride + (n0 + cc) % p.temb_mod]);
         sB[c] = v;
       }
       __syncthreads();
@@ -506,16 +510,64 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
 #pragma unroll
         for (int rq = 0; rq < RQ; ++rq) {
           const int cl = cout_of(tn, rq) - n0;
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(sB + cl);
 #pragma unroll
           for (int t = 0; t < TM; ++t) {
+            const int row = wm * WMS + t * MF + li;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sB + (NSEG == 1 ? 0 : row / HWT) * BN + cl);
             Quad o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(acc[tn][t][4 * rq + e] + b4[e]);
-            *reinterpret_cast<Quad*>(sO + (wm * WMS + t * MF + li) * OROW + cl) = o;
+            *reinterpret_cast<Quad*>(sO + row * OROW + cl) = o;
           }
         }
       __syncthreads();
+      if constexpr (NSEG > 1) {
+        // row lanes are dealt per sample segment: a thread's rows (and its partial sums) belong to ONE sample
+        constexpr int RPS = RPI / NSEG;                   // row lanes per segment
+        static_assert(RPS >= 1, "row lanes");
+        const int ch = etid % CPR, trs = etid / CPR;
+        const int sgi = trs / RPS, lr = trs - sgi * RPS;
+        const bool active = trs < RPS * NSEG;
+        const int n = n0 + ch * EO;
+        float ss1[EO], ss2[EO];
+#pragma unroll
+        for (int e = 0; e < EO; ++e) ss1[e] = ss2[e] = 0.f;
+        if (active) {
+          for (int r = lr; r < HWT; r += RPS) {
+            const int row = sgi * HWT + r;
+            const Chunk o = ld16<Chunk>(sO + row * OROW + ch * EO);
+            if (!(p.dbg & 4)) st16_out<Chunk>((T*)p.y + (size_t)(m0 + row) * p.y_ld + n, o);
+            if (p.stats_out) {
+#pragma unroll
+              for (int e = 0; e < EO; ++e) {
+                const float vr = to_f32(o[e]);
+                ss1[e] += vr;
+                ss2[e] = fmaf(vr, vr, ss2[e]);
+              }
+            }
+          }
+        }
+        if (p.stats_out) {
+          float* sR = reinterpret_cast<float*>(smem);     // [NSEG * RPS][BN][2]
+          __syncthreads();
+          if (active) {
+#pragma unroll
+            for (int e = 0; e < EO; ++e) *reinterpret_cast<f32x2*>(sR + ((trs * BN) + ch * EO + e) * 2) = f32x2{ss1[e], ss2[e]};
+          }
+          __syncthreads();
+          for (int c = etid; c < NSEG * BN; c += NTC) {
+            const int sg2 = c / BN, cc = c - sg2 * BN;
+            float a1 = 0.f, a2 = 0.f;
+            for (int r = 0; r < RPS; ++r) {
+              const f32x2 v = *reinterpret_cast<const f32x2*>(sR + (((sg2 * RPS + r) * BN) + cc) * 2);
+              a1 += v[0];
+              a2 += v[1];
+            }
+            *reinterpret_cast<f32x2*>(p.stats_out + (((size_t)(b_tile + sg2) * p.stats_S) * p.Cout + n0 + cc) * 2) = f32x2{a1, a2};   // S = 1
+          }
+        }
+        return;
+      }
       const bool active = etid < RPI * CPR;
       const int ch = etid % CPR, tr = etid / CPR;
       const int n = n0 + ch * EO;
@@ -716,7 +768,7 @@ bool conv3h_supported(int variant, int dtype_size, const ConvP& p) {
   const int eo = 16 / dtype_size;
   const int HW = p.H * p.W;
   const int z = p.splitk > 0 ? p.splitk : 1;
-  const bool tile_ok = HW % v.bm == 0 || (v.bm % HW == 0 && z > 1);    // several samples per tile: only as split-K slabs
+  const bool tile_ok = HW % v.bm == 0 || (v.bm % HW == 0 && (z > 1 || dtype_size == 2));    // several samples per tile: as split-K slabs, or (bf16) through the per-sample epilogue
   return p.KS == 3 && p.C2 == 0 && p.W == v.w && p.H == p.W && tile_ok && p.M % v.bm == 0 && p.Cout % v.bn == 0 &&
          p.C1 % kstep == 0 && (p.C1 / kstep) % z == 0 && p.out_mode == 0 && !p.y2 && p.y_ld % eo == 0 &&
          (!p.residual || p.res_ld % eo == 0) && (!p.temb || (p.temb_stride % eo == 0 && p.temb_mod % eo == 0)) &&

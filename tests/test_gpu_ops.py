@@ -519,6 +519,42 @@ def test_conv2d_emits_groupnorm_statistics(dtype, case):
     assert (fused.float() - alone.float()).abs().max() <= (1e-5 if dtype == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize("B,Cin,Cout", [(8, 256, 192), (6, 768, 96), (64, 768, 768)])
+def test_conv3x3_halo_patch_several_samples_per_tile_no_split(B, Cin, Cout):
+    """conv3h.hip variant 52 without K slices (bf16): a 64-pixel tile holds four whole 4x4 samples - per-sample time
+    embedding, residual and GroupNorm records come from the epilogue (the batch-64 plan of the 4x4 level; a ragged
+    last tile is not allowed: B % 4 == 0 or the plan falls back)."""
+    import ctypes
+    from afldm_amd import _lib
+    ops = _ops()
+    dtype, N = torch.bfloat16, 4
+    g = torch.Generator().manual_seed(B + Cin)
+    x = rnd(dtype, torch.randn(B, Cin, N, N, generator=g))
+    w = rnd(dtype, torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5))
+    b = torch.randn(Cout, generator=g)
+    temb = rnd(dtype, torch.randn(B, Cout, generator=g))
+    res = rnd(dtype, torch.randn(B, Cout, N, N, generator=g))
+    ref = F.conv2d(x, w, b, padding=1) + temb[:, :, None, None] + res
+    xh, wp, th, rh = nhwc(x, dtype), ops.pack_weight(w.cuda(), dtype), temb.to(device="cuda", dtype=dtype), nhwc(res, dtype)
+    try:
+        _lib.check(_lib.lib.afldm_conv2d_tune(52, 1), "tune")
+        ys = [ops.conv2d(xh, wp, b.cuda(), temb=th, temb_stride=Cout, residual=rh, want_stats=True) for _ in range(2)]
+        probe = ops.conv_args(xh, wp, b.cuda(), temb=th, temb_stride=Cout, residual=rh, out=ys[0])
+        code = _lib.lib.afldm_conv2d_variant(ctypes.byref(probe))
+    finally:
+        _lib.lib.afldm_conv2d_tune(-1, -1)
+    if B % 4 == 0:
+        assert code & 255 == 52 and (code >> 8) & 255 == 1, "variant 52 without slices did not run"
+        assert ys[0].gn_partial.shape == (B, 1, Cout, 2)
+    close(back(ys[0]), ref, dtype, f"conv3h multi-sample tile B={B}", bf16_rms=6e-3)
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0].gn_partial, ys[1].gn_partial)
+    yv = ys[0].float()
+    got = ys[0].gn_partial.double().sum(1).cpu()
+    s1, s2 = yv.sum((1, 2)).cpu(), (yv * yv).sum((1, 2)).cpu()
+    assert (got[..., 0] - s1).abs().max() <= 1e-4 * (1 + s1.abs().max())
+    assert (got[..., 1] - s2).abs().max() <= 1e-4 * (1 + s2.abs().max())
+
+
 SKINNY_CASES = [
     # B, H, W, C1, C2, Cout, residual, temb       (1x1 convolutions / dense layers over few rows: skinny.hip)
     (16, 1, 1, 3072, 0, 3072, True, True),     # a 2x2-level 3x3 convolution in its dense form (batch 16)
