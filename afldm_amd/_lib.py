@@ -24,6 +24,7 @@ class ConvArgs(Structure):
         ("KS", c_int), ("temb_stride", c_int), ("res_ld", c_int), ("y_ld", c_int),
         ("out_mode", c_int), ("dtype", c_int), ("y2", c_void_p), ("split_n", c_int),
         ("stats_out", c_void_p), ("temb_mod", c_int), ("sync", c_void_p), ("sync_bytes", c_size_t),
+        ("defer_reduce", c_int),
     ]
 
 
@@ -60,6 +61,7 @@ def _load():
         "afldm_gn_stats": ([vp, ip, vp, ip, ip, ip, vp], c_int),
         "afldm_gn_apply": ([vp, ip, vp, ip, vp, ip, vp, ip, vp, vp, vp, ip, ip, ip, fp, ip, ip, vp], c_int),
         "afldm_af_act": ([vp, ip, vp, ip, vp, ip, vp, ip, vp, vp, ip, fp, vp, vp, vp, vp, ip, ip, ip, vp], c_int),
+        "afldm_af_act_slabs": ([vp, ip, vp, vp, ip, vp, vp, ip, fp, vp, vp, vp, ip, ip, ip, ip, vp], c_int),
         "afldm_af_pack_bytes": ([ip, ip], c_size_t),
         "afldm_af_pack": ([vp, vp, ip, ip, vp, vp], c_int),
         "afldm_af_up2": ([vp, vp, vp, vp, ip, ip, ip, ip, vp], c_int),

@@ -643,6 +643,134 @@ __global__ void __launch_bounds__(256) k_af_act_small(AfP<T> p) {
   }
 }
 
+// ----------------------------------------------------------------------------- small planes fed by split-K slabs
+// conv1 -> norm2 -> activation of a resnet block on the 2x2 / 4x4 planes (afldm_af_act_slabs): one thread per
+// (sample, channel) plane sums the convolution's K slices, adds bias + time embedding and rounds to T exactly as the
+// reduction kernel would have stored it; a workgroup holds GPB whole groups of one sample (C / G channels each), so the
+// GroupNorm statistics of those rounded values are formed here (per-plane sums through LDS, added per group in
+// channel order in fp64) - no reduction launch, no stored intermediate.
+template <typename T>
+struct AfSlabP {
+  const float* slabs;
+  const float* bias;
+  const T* temb;
+  const float* gamma;
+  const float* beta;
+  const float* U;
+  const float* D;
+  T* y;
+  int nslab, temb_stride, B, C, G, gpb;
+  float eps;
+};
+
+template <typename T, int N>
+__global__ void __launch_bounds__(256) k_af_act_slabs(AfSlabP<T> p) {
+  constexpr int H2 = 2 * N, P = N * N;
+  __shared__ float sS[256][2];
+  __shared__ float sM[32][2];
+  const int cpg = p.C / p.G, bps = p.G / p.gpb;            // channels per group, blocks per sample
+  const int b = blockIdx.x / bps, g0 = (blockIdx.x - b * bps) * p.gpb;
+  const int tid = threadIdx.x, c = g0 * cpg + tid;         // blockDim.x == gpb * cpg
+  const size_t slab = (size_t)p.B * P * p.C;
+  float X[N][N], Y[N][N];
+  float add = p.bias ? p.bias[c] : 0.f;
+  const float tv = p.temb ? to_f32(p.temb[(size_t)b * p.temb_stride + c]) : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+  {
+    // slab order z = 0, 1, ... per pixel (the reduction kernel's order); the first four slabs as fully unrolled
+    // batches of P independent loads (a rolled loop waited out one load latency per pixel and slab)
+    const float* q0 = p.slabs + (size_t)b * P * p.C + c;
+    float v[P];
+#pragma unroll
+    for (int px = 0; px < P; ++px) v[px] = 0.f;
+#pragma unroll
+    for (int z = 0; z < 4; ++z) {
+      if (z < p.nslab) {
+        float t[P];
+#pragma unroll
+        for (int px = 0; px < P; ++px) t[px] = q0[(size_t)z * slab + (size_t)px * p.C];
+#pragma unroll
+        for (int px = 0; px < P; ++px) v[px] += t[px];
+      }
+    }
+    for (int z = 4; z < p.nslab; ++z) {
+#pragma unroll
+      for (int px = 0; px < P; ++px) v[px] += q0[(size_t)z * slab + (size_t)px * p.C];
+    }
+#pragma unroll
+    for (int h = 0; h < N; ++h)
+#pragma unroll
+      for (int w = 0; w < N; ++w) {
+        float vv = v[h * N + w];
+        if (p.bias) vv += add;
+        if (p.temb) vv += tv;
+        const float r = to_f32(from_f32<T>(vv));            // the value the two-launch path stores and normalises
+        X[h][w] = r;
+        s1 += r;
+        s2 = fmaf(r, r, s2);
+      }
+  }
+  sS[tid][0] = s1;
+  sS[tid][1] = s2;
+  __syncthreads();
+  if (tid < p.gpb) {
+    double a1 = 0.0, a2 = 0.0;
+    for (int k = 0; k < cpg; ++k) {
+      a1 += (double)sS[tid * cpg + k][0];
+      a2 += (double)sS[tid * cpg + k][1];
+    }
+    float mean, rstd;
+    gn_mean_rstd(a1, a2, (double)P * cpg, p.eps, mean, rstd);
+    sM[tid][0] = mean;
+    sM[tid][1] = rstd;
+  }
+  __syncthreads();
+  {
+    const float mean = sM[tid / cpg][0], rstd = sM[tid / cpg][1];
+    const float sc = rstd * p.gamma[c], sh = p.beta[c] - mean * sc;
+#pragma unroll
+    for (int h = 0; h < N; ++h)
+#pragma unroll
+      for (int w = 0; w < N; ++w) {
+        X[h][w] = X[h][w] * sc + sh;
+        Y[h][w] = 0.f;
+      }
+  }
+  const float* __restrict__ U = p.U;
+  const float* __restrict__ D = p.D;
+#pragma unroll
+  for (int hp = 0; hp < H2; ++hp) {
+    float t1[N];
+#pragma unroll
+    for (int w = 0; w < N; ++w) {
+      float a = 0.f;
+#pragma unroll
+      for (int h = 0; h < N; ++h) a = fmaf(U[hp * N + h], X[h][w], a);
+      t1[w] = a;
+    }
+    float sz[H2];
+#pragma unroll
+    for (int wp = 0; wp < H2; ++wp) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < N; ++w) a = fmaf(U[wp * N + w], t1[w], a);
+      sz[wp] = silu_f(a);
+    }
+#pragma unroll
+    for (int w = 0; w < N; ++w) {
+      float a = 0.f;
+#pragma unroll
+      for (int wp = 0; wp < H2; ++wp) a = fmaf(D[w * H2 + wp], sz[wp], a);
+#pragma unroll
+      for (int h = 0; h < N; ++h) Y[h][w] = fmaf(D[h * H2 + hp], a, Y[h][w]);
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < N; ++h)
+#pragma unroll
+    for (int w = 0; w < N; ++w) p.y[((size_t)(b * N + h) * N + w) * p.C + c] = from_f32<T>(Y[h][w]);
+}
+
 // ----------------------------------------------------------------------------- one-axis product
 // in  viewed as [B][A][Wd][C];  axis 0: out[b][a'][w][c] = sum_a M[a'][a] in[b][a][w][c]
 //                               axis 1: out[b][a][w'][c] = sum_w M[w'][w] in[b][a][w][c]
@@ -1041,6 +1169,40 @@ static int resample_dispatch(const void* x, const float* M, void* y, float* ws, 
 }  // namespace afldm
 
 using namespace afldm;
+
+template <typename T>
+static int af_act_slabs_launch(const float* slabs, int nslab, const float* bias, const void* temb, int temb_stride,
+                               const float* gamma, const float* beta, int G, float eps, const float* U, const float* D,
+                               void* y, int B, int C, int N, hipStream_t st) {
+  AfSlabP<T> p;
+  p.slabs = slabs; p.bias = bias; p.temb = (const T*)temb; p.gamma = gamma; p.beta = beta; p.U = U; p.D = D; p.y = (T*)y;
+  p.nslab = nslab; p.temb_stride = temb_stride; p.B = B; p.C = C; p.G = G; p.eps = eps;
+  const int cpg = C / G;
+  int gpb = 0;
+  for (int k = 1; k <= G && k <= 32; ++k)
+    if (G % k == 0 && k * cpg <= 256) gpb = k;           // whole groups per workgroup, as many as 256 threads hold
+  AFLDM_REQUIRE(gpb > 0, AFLDM_ESHAPE, "afldm_af_act_slabs: C/G = %d channels per group do not fit a workgroup", cpg);
+  p.gpb = gpb;
+  const int grid = B * (G / gpb);
+  if (N == 2) k_af_act_slabs<T, 2><<<grid, gpb * cpg, 0, st>>>(p);
+  else k_af_act_slabs<T, 4><<<grid, gpb * cpg, 0, st>>>(p);
+  return check_launch("afldm_af_act_slabs");
+}
+
+extern "C" int afldm_af_act_slabs(const float* slabs, int nslab, const float* bias, const void* temb, int temb_stride,
+                                  const float* gamma, const float* beta, int G, float eps, const float* U, const float* D,
+                                  void* y, int B, int C, int N, int dtype, afldm_stream_t stream) {
+  AFLDM_REQUIRE(slabs && gamma && beta && U && D && y, AFLDM_ENULL, "afldm_af_act_slabs: NULL pointer");
+  AFLDM_REQUIRE(N == 2 || N == 4, AFLDM_ESHAPE, "afldm_af_act_slabs: plane size N=%d not in {2,4}", N);
+  AFLDM_REQUIRE(B > 0 && C > 0 && G > 0 && C % G == 0 && nslab >= 1 && nslab <= 64, AFLDM_ESHAPE,
+                "afldm_af_act_slabs: bad shape B=%d C=%d G=%d nslab=%d", B, C, G, nslab);
+  AFLDM_REQUIRE(!temb || temb_stride == 0 || temb_stride >= C, AFLDM_ESHAPE, "afldm_af_act_slabs: temb_stride=%d (0 = one row for all samples, else >= C=%d)", temb_stride, C);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == AFLDM_F32) return af_act_slabs_launch<float>(slabs, nslab, bias, temb, temb_stride, gamma, beta, G, eps, U, D, y, B, C, N, st);
+  if (dtype == AFLDM_BF16) return af_act_slabs_launch<bf16>(slabs, nslab, bias, temb, temb_stride, gamma, beta, G, eps, U, D, y, B, C, N, st);
+  set_error("afldm_af_act_slabs: unknown dtype %d", dtype);
+  return AFLDM_EDTYPE;
+}
 
 extern "C" int afldm_af_act(const void* x1, int C1, const void* x2, int C2, const float* stats1, int S1,
                             const float* stats2, int S2, const float* gamma, const float* beta, int G, float eps,

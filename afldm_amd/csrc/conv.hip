@@ -2080,6 +2080,7 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
     launch_variant<T>(ex.vid, p, st);
     rc = check_launch("afldm_conv2d(igemm)");
     if (rc) return rc;
+    if (p.splitk > 1 && !ex.fused && a->defer_reduce) return AFLDM_OK;      // the caller's consumer finishes the slabs (afldm_af_act_slabs)
     if (p.splitk > 1 && !ex.fused) {
       if (smode == ST_REDUCE) {
         p.stats_out = a->stats_out;

@@ -283,12 +283,46 @@ class ResnetBlock2D(nn.Module):
             return ops.af_act(x1, x2, stats, gamma, beta, norm.num_groups, norm.eps)
         return ops.gn_apply(x1, stats, gamma, beta, norm.num_groups, norm.eps, act=1, x2=x2)
 
+    def _conv1_norm2_act_fused(self, h, temb_proj, temb_stride):
+        """conv1 -> norm2 -> WarpedNonlinearity on the 2x2 / 4x4 planes when conv1 splits K: the activation kernel takes
+        the convolution's fp32 slabs and finishes them itself (afldm_af_act_slabs) - no reduction launch, no stored
+        intermediate.  Returns None when this shape / plan does not qualify (the caller runs the ordinary sequence)."""
+        from ..af_modules.af_blocks import WarpedNonlinearity
+        if (os.environ.get("AFLDM_NO_FUSED_ACT") or not isinstance(self.nonlinearity, WarpedNonlinearity)
+                or isinstance(h, tuple) or h.ndim != 4 or h.shape[1] != h.shape[2] or h.shape[1] not in (2, 4)):
+            return None
+        B, N, _, Cin = h.shape
+        conv, norm = self.conv1, self.norm2
+        Cout = conv.out_channels
+        if tuple(conv.kernel_size) != (3, 3) or Cout % norm.num_groups or Cin % 8 or Cout % 8:
+            return None
+        if N == 2 and not os.environ.get("AFLDM_NO_DENSE2X2"):
+            w2, _ = packed_conv_dense2x2(conv, h.dtype, Cin, 0)          # one dense layer over the flattened plane
+            got = ops.conv2d_slabs(h.reshape(B, 4 * Cin), w2)
+        else:
+            w, _ = packed_conv(conv, h.dtype)
+            got = ops.conv2d_slabs(h, w)
+        if got is None:
+            return None
+        slabs, nslab = got
+        gamma, beta = packed_norm(norm)
+        cache = conv.__dict__.setdefault("_afldm_cache", {})
+        if "bias_f32" not in cache:
+            cache["bias_f32"] = None if conv.bias is None else conv.bias.detach().to(torch.float32).contiguous()
+        bias = cache["bias_f32"]
+        return ops.af_act_slabs(slabs, nslab, bias, temb_proj, temb_stride, gamma, beta, norm.num_groups, norm.eps,
+                                B, N, Cout, h.dtype)
+
     def forward(self, input_tensor, temb_proj=None, temb_stride=0):
         x1, x2 = _pair(input_tensor)
         h = self._norm_act(self.norm1, input_tensor)
-        # (the convs whose outputs feed a GroupNorm emit its statistics from their epilogue)
-        h = conv_forward(self.conv1, h, temb=temb_proj, temb_stride=temb_stride, want_stats=True)
-        h = self._norm_act(self.norm2, h)
+        fused = self._conv1_norm2_act_fused(h, temb_proj, temb_stride)
+        if fused is not None:
+            h = fused
+        else:
+            # (the convs whose outputs feed a GroupNorm emit its statistics from their epilogue)
+            h = conv_forward(self.conv1, h, temb=temb_proj, temb_stride=temb_stride, want_stats=True)
+            h = self._norm_act(self.norm2, h)
         if self.conv_shortcut is not None:
             res = conv_forward(self.conv_shortcut, input_tensor)
         else:

@@ -609,6 +609,49 @@ def conv2d(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, o
     return out
 
 
+def conv2d_slabs(x1, w, x2=None):
+    """The split-K slabs of conv2d(x1 | x2, w) WITHOUT the reduction launch (afldm_conv_args.defer_reduce): returns
+    (slabs fp32 [nslab, M, Cout], nslab), or None when the plan for this shape does not split K (the caller then runs
+    the ordinary conv2d).  Bias, time embedding and residual are NOT applied: the consumer (af_act_slabs) adds them."""
+    Cout = w.shape[0]
+    out = torch.empty(tuple(x1.shape[:-1]) + (Cout,), dtype=x1.dtype, device=x1.device)      # (never written when K is split)
+    a = conv_args(x1, w, None, x2, out=out)
+    need = lib.afldm_conv2d_workspace(ctypes.byref(a))
+    if not need:
+        return None
+    workspace = torch.empty(need // 4, dtype=torch.float32, device=x1.device)
+    a.workspace, a.workspace_bytes = ptr(workspace), need            # (the plan only splits K when it is given the room)
+    code = lib.afldm_conv2d_variant(ctypes.byref(a))
+    nslab = (code >> 8) & 255 if code >= 0 else 1
+    if code < 0 or nslab <= 1 or (code >> 16) & 1 or need < nslab * a.B * a.H * a.W * Cout * 4:
+        return None
+    a.defer_reduce = 1
+    a.keep = a.keep + (workspace,)
+    tok = _begin()
+    check(lib.afldm_conv2d(ctypes.byref(a), stream_ptr()), "conv2d(slabs)")
+    if tok is not None:
+        M, Ct = a.B * a.H * a.W, a.C1 + a.C2
+        es = x1.element_size()
+        kind = "conv3x3" if a.KS == 3 else ("conv1x1" if a.H * a.W > 1 and x1.ndim == 4 else "linear")
+        keep = (a, workspace, out)
+        _end(tok, kind, 2.0 * M * a.Cout * a.KS * a.KS * Ct, (M * Ct + a.Cout * a.KS * a.KS * Ct + M * a.Cout) * es,
+             replay=lambda keep=keep: conv2d_launch(keep[0]))
+    return workspace[:nslab * a.B * a.H * a.W * Cout].view(nslab, a.B * a.H * a.W, Cout), nslab
+
+
+def af_act_slabs(slabs, nslab, bias, temb, temb_stride, gamma, beta, G, eps, B, N, C, dtype):
+    """conv1 -> norm2 -> WarpedNonlinearity on 2x2 / 4x4 planes from the convolution's split-K slabs
+    (afldm_af_act_slabs): returns the activated tensor [B, N, N, C] in `dtype`."""
+    out = torch.empty((B, N, N, C), dtype=dtype, device=slabs.device)
+    U, D = filter_matrices(N, slabs.device)
+    tok = _begin()
+    code = 0 if dtype == torch.float32 else 1
+    check(lib.afldm_af_act_slabs(ptr(slabs), int(nslab), ptr(bias), ptr(temb), int(temb_stride), ptr(gamma), ptr(beta),
+                                 int(G), float(eps), ptr(U), ptr(D), ptr(out), B, C, N, _code(out), stream_ptr()), "af_act_slabs")
+    _end(tok, f"af_act_N{N}", 24.0 * N ** 3 * B * C, B * N * N * C * (4 * nslab + out.element_size()))
+    return out
+
+
 def conv_workspace_bytes(a):
     return lib.afldm_conv2d_workspace(ctypes.byref(a))
 

@@ -119,6 +119,16 @@ int afldm_af_act(const void* x1, int C1, const void* x2, int C2, const float* st
                  const float* stats2, int S2, const float* gamma, const float* beta, int G, float eps,
                  const float* U, const float* D, const void* packed, void* y, int B, int N, int dtype,
                  afldm_stream_t stream);
+/* conv1 -> norm2 -> WarpedNonlinearity of a ResnetBlock2D on the 2x2 / 4x4 planes in one step (diffusers
+ * resnet.py: hidden_states = conv1(...) + temb; norm2; nonlinearity - the latter wrapped by af_api.py:70-83): the
+ * split-K slabs a deferred afldm_conv2d left in its workspace ([nslab][B*N*N][C] fp32) are summed in slab order,
+ * + bias[c] + temb[b*temb_stride + c], rounded to `dtype` (the value the two-launch path stores), GroupNorm-ed
+ * with statistics formed inside the launch (one workgroup holds whole groups of one sample: C / G channels x N*N
+ * pixels each, fp64 finish) and passed through y = D silu(U xn U^T) D^T per plane.  Replaces the reduction launch,
+ * the stored intermediate and its re-read.  N in {2, 4}; bias / temb may be NULL. */
+int afldm_af_act_slabs(const float* slabs, int nslab, const float* bias, const void* temb, int temb_stride,
+                       const float* gamma, const float* beta, int G, float eps, const float* U, const float* D,
+                       void* y, int B, int C, int N, int dtype, afldm_stream_t stream);
 /* y = M x M^T per plane in ONE kernel (MFMA, no fp32 intermediate through HBM) for the two large
  * resampling sites of the UNet: AliasFreeUpsample2D at 16 -> 32 (M = U, af_blocks.py:92-93) and
  * AliasFreeDownsample2D at 32 -> 16 (M = D, af_blocks.py:149-150).  stats_out (optional):
@@ -227,6 +237,11 @@ typedef struct {
    * bit-identical.  NULL = always the two-launch form. */
   unsigned int* sync;
   size_t sync_bytes;
+  /* 1: when the call splits K (afldm_conv2d_variant(args) >> 8 & 255 = nslab > 1), leave the fp32 partial sums in
+   * `workspace` ([nslab][B*H*W][Cout]: plain sums, no bias / temb / residual) and do NOT launch the reduction - the
+   * caller hands them to a consumer that finishes them itself (afldm_af_act_slabs).  y / stats_out are not written.
+   * Ignored (the call completes as usual) when K is not split. */
+  int defer_reduce;
 } afldm_conv_args;
 int afldm_conv2d(const afldm_conv_args* args, afldm_stream_t stream);
 /* Tuning hook (benchmarks only): force tile/pipeline variant `variant` (>= 0) and/or a split-K

@@ -555,6 +555,52 @@ def test_conv3x3_halo_patch_several_samples_per_tile_no_split(B, Cin, Cout):
     assert (got[..., 1] - s2).abs().max() <= 1e-4 * (1 + s2.abs().max())
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,N,Cin,Cout", [(64, 2, 768, 768), (64, 4, 768, 768), (8, 4, 768, 768), (16, 4, 256, 256), (5, 4, 64, 128)])
+def test_resnet_conv1_norm2_act_from_split_k_slabs(dtype, B, N, Cin, Cout):
+    """ResnetBlock2D on 2x2 / 4x4 planes: conv1 -> norm2 -> WarpedNonlinearity with the activation kernel fed by the
+    convolution's split-K slabs (afldm_af_act_slabs: no reduction launch, no stored intermediate) against the ordinary
+    three-launch sequence (same rounding points: equal up to the order of the GroupNorm sums) and against PyTorch."""
+    import torch.nn as nn
+    from afldm_amd import ops as aops
+    from afldm_amd.af_modules.af_blocks import WarpedNonlinearity
+    from afldm_amd.models import blocks
+    g = torch.Generator().manual_seed(B * N + Cin)
+    blk = blocks.ResnetBlock2D(in_channels=Cin, out_channels=Cout, temb_channels=64, groups=8, eps=1e-5)
+    with torch.no_grad():
+        for prm in blk.parameters():
+            prm.copy_(rnd(dtype, torch.randn(prm.shape, generator=g) * (0.05 if prm.ndim > 1 else 0.3)))
+        blk.norm1.weight.add_(1.0)
+        blk.norm2.weight.add_(1.0)
+    blk.nonlinearity = WarpedNonlinearity(nn.SiLU())
+    blk = blk.cuda().to(dtype)
+    x = rnd(dtype, torch.randn(B, Cin, N, N, generator=g))
+    temb = rnd(dtype, torch.randn(B, Cout, generator=g)).to(device="cuda", dtype=dtype)
+    xh = nhwc(x, dtype)
+    h = blk._norm_act(blk.norm1, xh)
+    fused = blk._conv1_norm2_act_fused(h, temb, Cout)
+    plain = blk._norm_act(blk.norm2, blocks.conv_forward(blk.conv1, h, temb=temb, temb_stride=Cout, want_stats=True))
+    if fused is None:
+        pytest.skip("the plan of this shape does not split K: nothing to fuse")
+    assert fused.shape == plain.shape
+    assert rel_rms_t(fused, plain) <= (1e-5 if dtype == torch.float32 else 4e-3)
+    assert torch.equal(fused, blk._conv1_norm2_act_fused(h, temb, Cout))
+    # and the whole block against PyTorch in fp32 on the same (rounded) parameters
+    w1, b1 = blk.conv1.weight.float().cpu(), blk.conv1.bias.float().cpu()
+    h_ref = F.conv2d(back(h), w1, b1, padding=1) + temb.float().cpu()[:, :, None, None]
+    hn = F.group_norm(h_ref, 8, blk.norm2.weight.float().cpu(), blk.norm2.bias.float().cpu(), 1e-5)
+    U, D = aops.filter_matrices(N, "cuda")
+    U, D = U.cpu(), D.cpu()
+    act_ref = torch.einsum("ph,bchw,qw->bcpq", U, hn, U)
+    act_ref = torch.einsum("hp,bcpq,wq->bchw", D, F.silu(act_ref), D)
+    assert rel_rms_t(back(fused), act_ref) <= (1e-4 if dtype == torch.float32 else 2e-2)
+
+
+def rel_rms_t(a, b):
+    a, b = a.detach().float().cpu().double(), b.detach().float().cpu().double()
+    return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-30))
+
+
 SKINNY_CASES = [
     # B, H, W, C1, C2, Cout, residual, temb       (1x1 convolutions / dense layers over few rows: skinny.hip)
     (16, 1, 1, 3072, 0, 3072, True, True),     # a 2x2-level 3x3 convolution in its dense form (batch 16)
