@@ -194,7 +194,7 @@ int skinny_stats_splits(const afldm_conv_args* a) {
   if (off || a->KS != 1 || a->out_mode != 0 || a->y2) return 0;
   const long long M = (long long)a->B * a->H * a->W;
   const int HW = a->H * a->W, K = a->C1 + a->C2;
-  const int esz = a->dtype == AFLDM_F32 ? 4 : 2, kpf = a->dtype == AFLDM_F32 ? 16 : 32;
+  const int esz = a->dtype == AFLDM_F32 ? 4 : 2;
   static const int s_maxm = getenv("AFLDM_SKINNY_MAXM") ? atoi(getenv("AFLDM_SKINNY_MAXM")) : 1024;
   static const int s_maxx = getenv("AFLDM_SKINNY_MAXX") ? atoi(getenv("AFLDM_SKINNY_MAXX")) : 0;
   const int ns = skinny_slices(a);
