@@ -212,6 +212,10 @@ class UNet2DModel(nn.Module):
             h = blk(h, res, take(n))
         gamma, beta = B.packed_norm(self.conv_norm_out)
         gno = self.conv_norm_out
+        wo, bo = B.packed_conv(self.conv_out, h.dtype)
+        fused = ops.conv_out_fused(h, wo, bo, gamma, beta, gno.num_groups, gno.eps)      # norm -> SiLU -> conv in one launch
+        if fused is not None:
+            return fused
         stats = ops.gn_stats(h, gno.num_groups)
         h = ops.gn_apply(h, stats, gamma, beta, gno.num_groups, gno.eps, act=1)          # conv_act is plain SiLU
         return B.conv_forward(self.conv_out, h)

@@ -652,6 +652,23 @@ def af_act_slabs(slabs, nslab, bias, temb, temb_stride, gamma, beta, G, eps, B, 
     return out
 
 
+def conv_out_fused(x, w, bias, gamma, beta, G, eps):
+    """conv_norm_out -> SiLU -> conv_out (3x3, <= 4 couts) of the UNet tail in one launch (afldm_conv_out_fused);
+    returns None when the shape is not covered (the caller runs gn_apply + conv2d)."""
+    if (x.dtype != torch.bfloat16 or x.ndim != 4 or x.shape[1] != 32 or x.shape[2] != 32 or x.shape[3] not in (64, 128, 192)
+            or w.shape[0] > 4 or w.shape[1] != 3 or os.environ.get("AFLDM_NO_CONV_OUT_FUSED")):
+        return None
+    B, N, _, C = x.shape
+    Cout = w.shape[0]
+    st = _tensor_stats(x, None)
+    out = torch.empty((B, N, N, Cout), dtype=x.dtype, device=x.device)
+    tok = _begin()
+    check(lib.afldm_conv_out_fused(ptr(x), ptr(st), st.shape[1], ptr(gamma), ptr(beta), int(G), float(eps), ptr(w), ptr(bias),
+                                   ptr(out), B, N, C, Cout, _code(x), stream_ptr()), "conv_out_fused")
+    _end(tok, "conv_out", 2.0 * B * N * N * Cout * 9 * C, (B * N * N * (C + Cout) + Cout * 9 * C) * x.element_size())
+    return out
+
+
 def conv_workspace_bytes(a):
     return lib.afldm_conv2d_workspace(ctypes.byref(a))
 

@@ -129,6 +129,13 @@ int afldm_af_act(const void* x1, int C1, const void* x2, int C2, const float* st
 int afldm_af_act_slabs(const float* slabs, int nslab, const float* bias, const void* temb, int temb_stride,
                        const float* gamma, const float* beta, int G, float eps, const float* U, const float* D,
                        void* y, int B, int C, int N, int dtype, afldm_stream_t stream);
+/* The tail of UNet2DModel.forward in one launch (bf16, 32x32 planes, C in {64, 128, 192}, Cout <= 4):
+ * conv_norm_out (GroupNorm from the per-channel partial sums stats[B][S][C][2] of x) -> conv_act (plain SiLU:
+ * af_api.py:70-83 leaves it unwrapped) -> conv_out (3x3 'same', weights packed OHWI [Cout][3][3][C], fp32 bias).
+ * x NHWC [B,N,N,C]; y NHWC [B,N,N,Cout].  The activated tensor is never stored. */
+int afldm_conv_out_fused(const void* x, const float* stats, int S, const float* gamma, const float* beta, int G,
+                         float eps, const void* w, const float* bias, void* y, int B, int N, int C, int Cout,
+                         int dtype, afldm_stream_t stream);
 /* y = M x M^T per plane in ONE kernel (MFMA, no fp32 intermediate through HBM) for the two large
  * resampling sites of the UNet: AliasFreeUpsample2D at 16 -> 32 (M = U, af_blocks.py:92-93) and
  * AliasFreeDownsample2D at 32 -> 16 (M = D, af_blocks.py:149-150).  stats_out (optional):

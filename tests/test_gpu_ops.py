@@ -601,6 +601,28 @@ def rel_rms_t(a, b):
     return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-30))
 
 
+@pytest.mark.parametrize("B,C,Cout", [(3, 192, 4), (2, 64, 3), (5, 128, 1)])
+def test_unet_tail_norm_silu_conv_out_in_one_launch(B, C, Cout):
+    """afldm_conv_out_fused (bf16, 32x32): conv_norm_out -> SiLU -> conv_out against gn_apply + conv2d (same rounding
+    of the activated tensor) and against PyTorch in fp32; the statistics come from the producer's partial sums."""
+    ops = _ops()
+    dtype, N, G = torch.bfloat16, 32, 32 if C % 32 == 0 else 16
+    g = torch.Generator().manual_seed(C + Cout)
+    x = rnd(dtype, torch.randn(B, C, N, N, generator=g) * 1.5 + 0.3)
+    w = rnd(dtype, torch.randn(Cout, C, 3, 3, generator=g) / (3 * C ** 0.5))
+    b = torch.randn(Cout, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    ref = F.conv2d(F.silu(F.group_norm(x, G, gamma, beta, 1e-5)), w, b, padding=1)
+    xh, wp = nhwc(x, dtype), ops.pack_weight(w.cuda(), dtype)
+    xh.gn_partial = ops.gn_stats(xh).st1                    # as the producing convolution would have attached them
+    ys = [ops.conv_out_fused(xh, wp, b.cuda(), gamma.cuda(), beta.cuda(), G, 1e-5) for _ in range(2)]
+    assert ys[0] is not None and ys[0].shape == (B, N, N, Cout) and torch.equal(ys[0], ys[1])
+    close(back(ys[0]), ref, dtype, f"fused UNet tail C={C} Cout={Cout}", bf16_rms=8e-3)
+    hn = ops.gn_apply(xh, ops.gn_stats(xh), gamma.cuda(), beta.cuda(), G, 1e-5, act=1)
+    plain = ops.conv2d(hn, wp, b.cuda())
+    assert rel_rms_t(ys[0], plain) <= 6e-3
+
+
 SKINNY_CASES = [
     # B, H, W, C1, C2, Cout, residual, temb       (1x1 convolutions / dense layers over few rows: skinny.hip)
     (16, 1, 1, 3072, 0, 3072, True, True),     # a 2x2-level 3x3 convolution in its dense form (batch 16)
