@@ -61,7 +61,7 @@ def _load():
         "afldm_gn_stats": ([vp, ip, vp, ip, ip, ip, vp], c_int),
         "afldm_gn_apply": ([vp, ip, vp, ip, vp, ip, vp, ip, vp, vp, vp, ip, ip, ip, fp, ip, ip, vp], c_int),
         "afldm_af_act": ([vp, ip, vp, ip, vp, ip, vp, ip, vp, vp, ip, fp, vp, vp, vp, vp, ip, ip, ip, vp], c_int),
-        "afldm_af_act_slabs": ([vp, ip, vp, vp, ip, vp, vp, ip, fp, vp, vp, vp, ip, ip, ip, ip, vp], c_int),
+        "afldm_af_act_slabs": ([vp, ip, vp, vp, ip, vp, vp, vp, vp, ip, fp, ip, vp, vp, vp, ip, ip, ip, ip, vp], c_int),
         "afldm_conv_out_fused": ([vp, vp, ip, vp, vp, ip, fp, vp, vp, vp, ip, ip, ip, ip, ip, vp], c_int),
         "afldm_af_pack_bytes": ([ip, ip], c_size_t),
         "afldm_af_pack": ([vp, vp, ip, ip, vp, vp], c_int),

@@ -659,11 +659,14 @@ struct AfSlabP {
   const float* U;
   const float* D;
   T* y;
+  const T* residual;   // optional [B][N*N][C]: added after bias + temb (conv2 of a resnet block)
+  T* y_raw;            // optional: the finished (rounded) convolution output itself, for its other consumers
   int nslab, temb_stride, B, C, G, gpb;
   float eps;
 };
 
-template <typename T, int N>
+// ACT: 1 = WarpedNonlinearity after the GroupNorm (a resnet's norm2 / norm1), 0 = GroupNorm only (Attention.group_norm)
+template <typename T, int N, int ACT>
 __global__ void __launch_bounds__(256) k_af_act_slabs(AfSlabP<T> p) {
   constexpr int H2 = 2 * N, P = N * N;
   __shared__ float sS[256][2];
@@ -704,7 +707,10 @@ __global__ void __launch_bounds__(256) k_af_act_slabs(AfSlabP<T> p) {
         float vv = v[h * N + w];
         if (p.bias) vv += add;
         if (p.temb) vv += tv;
-        const float r = to_f32(from_f32<T>(vv));            // the value the two-launch path stores and normalises
+        if (p.residual) vv += to_f32(p.residual[((size_t)(b * P + h * N + w)) * p.C + c]);
+        const T rt = from_f32<T>(vv);
+        if (p.y_raw) p.y_raw[((size_t)(b * P + h * N + w)) * p.C + c] = rt;
+        const float r = to_f32(rt);                         // the value the two-launch path stores and normalises
         X[h][w] = r;
         s1 += r;
         s2 = fmaf(r, r, s2);
@@ -735,6 +741,13 @@ __global__ void __launch_bounds__(256) k_af_act_slabs(AfSlabP<T> p) {
         X[h][w] = X[h][w] * sc + sh;
         Y[h][w] = 0.f;
       }
+  }
+  if constexpr (ACT == 0) {
+#pragma unroll
+    for (int h = 0; h < N; ++h)
+#pragma unroll
+      for (int w = 0; w < N; ++w) p.y[((size_t)(b * N + h) * N + w) * p.C + c] = from_f32<T>(X[h][w]);
+    return;
   }
   const float* __restrict__ U = p.U;
   const float* __restrict__ D = p.D;
@@ -1172,10 +1185,11 @@ using namespace afldm;
 
 template <typename T>
 static int af_act_slabs_launch(const float* slabs, int nslab, const float* bias, const void* temb, int temb_stride,
-                               const float* gamma, const float* beta, int G, float eps, const float* U, const float* D,
-                               void* y, int B, int C, int N, hipStream_t st) {
+                               const void* residual, void* y_raw, const float* gamma, const float* beta, int G, float eps,
+                               int act, const float* U, const float* D, void* y, int B, int C, int N, hipStream_t st) {
   AfSlabP<T> p;
   p.slabs = slabs; p.bias = bias; p.temb = (const T*)temb; p.gamma = gamma; p.beta = beta; p.U = U; p.D = D; p.y = (T*)y;
+  p.residual = (const T*)residual; p.y_raw = (T*)y_raw;
   p.nslab = nslab; p.temb_stride = temb_stride; p.B = B; p.C = C; p.G = G; p.eps = eps;
   const int cpg = C / G;
   int gpb = 0;
@@ -1184,22 +1198,25 @@ static int af_act_slabs_launch(const float* slabs, int nslab, const float* bias,
   AFLDM_REQUIRE(gpb > 0, AFLDM_ESHAPE, "afldm_af_act_slabs: C/G = %d channels per group do not fit a workgroup", cpg);
   p.gpb = gpb;
   const int grid = B * (G / gpb);
-  if (N == 2) k_af_act_slabs<T, 2><<<grid, gpb * cpg, 0, st>>>(p);
-  else k_af_act_slabs<T, 4><<<grid, gpb * cpg, 0, st>>>(p);
+  if (N == 2 && act) k_af_act_slabs<T, 2, 1><<<grid, gpb * cpg, 0, st>>>(p);
+  else if (N == 2) k_af_act_slabs<T, 2, 0><<<grid, gpb * cpg, 0, st>>>(p);
+  else if (act) k_af_act_slabs<T, 4, 1><<<grid, gpb * cpg, 0, st>>>(p);
+  else k_af_act_slabs<T, 4, 0><<<grid, gpb * cpg, 0, st>>>(p);
   return check_launch("afldm_af_act_slabs");
 }
 
 extern "C" int afldm_af_act_slabs(const float* slabs, int nslab, const float* bias, const void* temb, int temb_stride,
-                                  const float* gamma, const float* beta, int G, float eps, const float* U, const float* D,
-                                  void* y, int B, int C, int N, int dtype, afldm_stream_t stream) {
-  AFLDM_REQUIRE(slabs && gamma && beta && U && D && y, AFLDM_ENULL, "afldm_af_act_slabs: NULL pointer");
+                                  const void* residual, void* y_raw, const float* gamma, const float* beta, int G, float eps,
+                                  int act, const float* U, const float* D, void* y, int B, int C, int N, int dtype,
+                                  afldm_stream_t stream) {
+  AFLDM_REQUIRE(slabs && gamma && beta && y && (!act || (U && D)), AFLDM_ENULL, "afldm_af_act_slabs: NULL pointer");
   AFLDM_REQUIRE(N == 2 || N == 4, AFLDM_ESHAPE, "afldm_af_act_slabs: plane size N=%d not in {2,4}", N);
   AFLDM_REQUIRE(B > 0 && C > 0 && G > 0 && C % G == 0 && nslab >= 1 && nslab <= 64, AFLDM_ESHAPE,
                 "afldm_af_act_slabs: bad shape B=%d C=%d G=%d nslab=%d", B, C, G, nslab);
   AFLDM_REQUIRE(!temb || temb_stride == 0 || temb_stride >= C, AFLDM_ESHAPE, "afldm_af_act_slabs: temb_stride=%d (0 = one row for all samples, else >= C=%d)", temb_stride, C);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == AFLDM_F32) return af_act_slabs_launch<float>(slabs, nslab, bias, temb, temb_stride, gamma, beta, G, eps, U, D, y, B, C, N, st);
-  if (dtype == AFLDM_BF16) return af_act_slabs_launch<bf16>(slabs, nslab, bias, temb, temb_stride, gamma, beta, G, eps, U, D, y, B, C, N, st);
+  if (dtype == AFLDM_F32) return af_act_slabs_launch<float>(slabs, nslab, bias, temb, temb_stride, residual, y_raw, gamma, beta, G, eps, act, U, D, y, B, C, N, st);
+  if (dtype == AFLDM_BF16) return af_act_slabs_launch<bf16>(slabs, nslab, bias, temb, temb_stride, residual, y_raw, gamma, beta, G, eps, act, U, D, y, B, C, N, st);
   set_error("afldm_af_act_slabs: unknown dtype %d", dtype);
   return AFLDM_EDTYPE;
 }

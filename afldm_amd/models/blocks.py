@@ -313,7 +313,41 @@ class ResnetBlock2D(nn.Module):
         return ops.af_act_slabs(slabs, nslab, bias, temb_proj, temb_stride, gamma, beta, norm.num_groups, norm.eps,
                                 B, N, Cout, h.dtype)
 
-    def forward(self, input_tensor, temb_proj=None, temb_stride=0):
+    def _conv2_to_next_norm_fused(self, h, res, next_gn):
+        """conv2 (+ shortcut) of this block straight into the GroupNorm of the attention block that follows, on the
+        2x2 / 4x4 planes when conv2 splits K (afldm_af_act_slabs, act = 0): the reduction launch and the GroupNorm
+        pass become one.  Returns this block's output with the normalised tensor attached as `.gn_applied =
+        (tensor, norm module)` for AttnProcessor2_0, or None when the shape / plan does not qualify."""
+        if (os.environ.get("AFLDM_NO_FUSED_ACT") or isinstance(h, tuple) or h.ndim != 4 or h.shape[1] != h.shape[2]
+                or h.shape[1] not in (2, 4)):
+            return None
+        B, N, _, Cin = h.shape
+        conv = self.conv2
+        Cout = conv.out_channels
+        if (tuple(conv.kernel_size) != (3, 3) or Cout % next_gn.num_groups or Cin % 8 or Cout % 8
+                or next_gn.num_channels != Cout or res.shape[-1] != Cout):
+            return None
+        if N == 2 and not os.environ.get("AFLDM_NO_DENSE2X2"):
+            w2, _ = packed_conv_dense2x2(conv, h.dtype, Cin, 0)
+            got = ops.conv2d_slabs(h.reshape(B, 4 * Cin), w2)
+        else:
+            w, _ = packed_conv(conv, h.dtype)
+            got = ops.conv2d_slabs(h, w)
+        if got is None:
+            return None
+        slabs, nslab = got
+        gamma, beta = packed_norm(next_gn)
+        cache = conv.__dict__.setdefault("_afldm_cache", {})
+        if "bias_f32" not in cache:
+            cache["bias_f32"] = None if conv.bias is None else conv.bias.detach().to(torch.float32).contiguous()
+        hn, y = ops.af_act_slabs(slabs, nslab, cache["bias_f32"], None, 0, gamma, beta, next_gn.num_groups, next_gn.eps,
+                                 B, N, Cout, h.dtype, residual=res, want_raw=True, act=False)
+        y.gn_applied = (hn, next_gn)
+        return y
+
+    def forward(self, input_tensor, temb_proj=None, temb_stride=0, next_gn=None):
+        """next_gn: the GroupNorm module of an attention block that consumes this block's output next (the block loops
+        pass it): lets conv2 hand its result over already normalised where that saves launches."""
         x1, x2 = _pair(input_tensor)
         h = self._norm_act(self.norm1, input_tensor)
         fused = self._conv1_norm2_act_fused(h, temb_proj, temb_stride)
@@ -328,7 +362,19 @@ class ResnetBlock2D(nn.Module):
         else:
             assert x2 is None
             res = x1
+        if next_gn is not None:
+            out = self._conv2_to_next_norm_fused(h, res, next_gn)
+            if out is not None:
+                return out
         return conv_forward(self.conv2, h, residual=res, want_stats=True)
+
+
+def _next_gn(attn):
+    """The GroupNorm an attention block will apply to its input, when its processor is the plain self-attention one
+    (a cross-frame processor normalises / stores on its own terms: no hand-over)."""
+    if attn is None or attn.group_norm is None or type(attn.processor) is not AttnProcessor2_0:
+        return None
+    return attn.group_norm
 
 
 # ----------------------------------------------------------------------------- attention
@@ -344,8 +390,12 @@ class AttnProcessor2_0:
         B, H, W, C = hidden_states.shape
         gamma, beta = packed_norm(attn.group_norm)
         gn = attn.group_norm
-        stats = ops.gn_stats(hidden_states, gn.num_groups)
-        hn = ops.gn_apply(hidden_states, stats, gamma, beta, gn.num_groups, gn.eps, act=0)
+        pre = getattr(hidden_states, "gn_applied", None)
+        if pre is not None and pre[1] is gn:
+            hn = pre[0]                                   # the producing resnet block already applied this GroupNorm
+        else:
+            stats = ops.gn_stats(hidden_states, gn.num_groups)
+            hn = ops.gn_apply(hidden_states, stats, gamma, beta, gn.num_groups, gn.eps, act=0)
         tokens = hn.view(B, H * W, C)
         if C // attn.heads > 32:
             # large head_dim (the VAE mid block: one head of 512): GEMM - row softmax - GEMM per sample
@@ -436,7 +486,7 @@ class DownBlock2D(_BlockBase):
     def forward(self, hidden_states, temb_slices):
         outs = ()
         for i, resnet in enumerate(self.resnets):
-            hidden_states = resnet(hidden_states, *temb_slices[i])
+            hidden_states = resnet(hidden_states, *temb_slices[i], next_gn=_next_gn(self.attentions[i]) if self.has_attention else None)
             if self.has_attention:
                 hidden_states = self.attentions[i](hidden_states)
             outs += (hidden_states,)
@@ -466,7 +516,7 @@ class UNetMidBlock2D(_BlockBase):
     def forward(self, hidden_states, temb_slices=None):
         if temb_slices is None:                       # VAE: no time embedding
             temb_slices = [(None, 0)] * len(self.resnets)
-        hidden_states = self.resnets[0](hidden_states, *temb_slices[0])
+        hidden_states = self.resnets[0](hidden_states, *temb_slices[0], next_gn=_next_gn(self.attentions[0]) if len(self.attentions) else None)
         for i, (attn, resnet) in enumerate(zip(self.attentions, self.resnets[1:])):
             if attn is not None:
                 hidden_states = attn(hidden_states)
@@ -495,7 +545,8 @@ class UpBlock2D(_BlockBase):
         for i, resnet in enumerate(self.resnets):
             res = res_hidden_states_tuple[-1]
             res_hidden_states_tuple = res_hidden_states_tuple[:-1]
-            hidden_states = resnet((hidden_states, res), *temb_slices[i])      # virtual torch.cat([h, res], 1)
+            hidden_states = resnet((hidden_states, res), *temb_slices[i],      # virtual torch.cat([h, res], 1)
+                                   next_gn=_next_gn(self.attentions[i]) if self.has_attention else None)
             if self.has_attention:
                 hidden_states = self.attentions[i](hidden_states)
         if self.upsamplers is not None:

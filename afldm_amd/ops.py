@@ -639,17 +639,22 @@ def conv2d_slabs(x1, w, x2=None):
     return workspace[:nslab * a.B * a.H * a.W * Cout].view(nslab, a.B * a.H * a.W, Cout), nslab
 
 
-def af_act_slabs(slabs, nslab, bias, temb, temb_stride, gamma, beta, G, eps, B, N, C, dtype):
-    """conv1 -> norm2 -> WarpedNonlinearity on 2x2 / 4x4 planes from the convolution's split-K slabs
-    (afldm_af_act_slabs): returns the activated tensor [B, N, N, C] in `dtype`."""
+def af_act_slabs(slabs, nslab, bias, temb, temb_stride, gamma, beta, G, eps, B, N, C, dtype, residual=None, want_raw=False,
+                 act=True):
+    """A convolution's split-K slabs straight into the following GroupNorm on 2x2 / 4x4 planes (afldm_af_act_slabs):
+    act=True -> GroupNorm + WarpedNonlinearity (conv1 -> norm2 of a resnet), act=False -> GroupNorm only (conv2 ->
+    Attention.group_norm).  Returns the [B, N, N, C] result, or (result, raw) with the finished convolution output
+    itself when want_raw."""
     out = torch.empty((B, N, N, C), dtype=dtype, device=slabs.device)
+    raw = torch.empty((B, N, N, C), dtype=dtype, device=slabs.device) if want_raw else None
     U, D = filter_matrices(N, slabs.device)
     tok = _begin()
-    code = 0 if dtype == torch.float32 else 1
-    check(lib.afldm_af_act_slabs(ptr(slabs), int(nslab), ptr(bias), ptr(temb), int(temb_stride), ptr(gamma), ptr(beta),
-                                 int(G), float(eps), ptr(U), ptr(D), ptr(out), B, C, N, _code(out), stream_ptr()), "af_act_slabs")
-    _end(tok, f"af_act_N{N}", 24.0 * N ** 3 * B * C, B * N * N * C * (4 * nslab + out.element_size()))
-    return out
+    check(lib.afldm_af_act_slabs(ptr(slabs), int(nslab), ptr(bias), ptr(temb), int(temb_stride), ptr(residual), ptr(raw),
+                                 ptr(gamma), ptr(beta), int(G), float(eps), 1 if act else 0, ptr(U), ptr(D), ptr(out), B, C, N,
+                                 _code(out), stream_ptr()), "af_act_slabs")
+    _end(tok, f"af_act_N{N}" if act else "gn_apply", 24.0 * N ** 3 * B * C if act else 0.0,
+         B * N * N * C * (4 * nslab + out.element_size() * (2 if want_raw else 1)))
+    return (out, raw) if want_raw else out
 
 
 def conv_out_fused(x, w, bias, gamma, beta, G, eps):

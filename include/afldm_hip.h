@@ -119,16 +119,20 @@ int afldm_af_act(const void* x1, int C1, const void* x2, int C2, const float* st
                  const float* stats2, int S2, const float* gamma, const float* beta, int G, float eps,
                  const float* U, const float* D, const void* packed, void* y, int B, int N, int dtype,
                  afldm_stream_t stream);
-/* conv1 -> norm2 -> WarpedNonlinearity of a ResnetBlock2D on the 2x2 / 4x4 planes in one step (diffusers
- * resnet.py: hidden_states = conv1(...) + temb; norm2; nonlinearity - the latter wrapped by af_api.py:70-83): the
- * split-K slabs a deferred afldm_conv2d left in its workspace ([nslab][B*N*N][C] fp32) are summed in slab order,
- * + bias[c] + temb[b*temb_stride + c], rounded to `dtype` (the value the two-launch path stores), GroupNorm-ed
- * with statistics formed inside the launch (one workgroup holds whole groups of one sample: C / G channels x N*N
- * pixels each, fp64 finish) and passed through y = D silu(U xn U^T) D^T per plane.  Replaces the reduction launch,
- * the stored intermediate and its re-read.  N in {2, 4}; bias / temb may be NULL. */
+/* A convolution's split-K slabs straight into the GroupNorm that follows it, on the 2x2 / 4x4 planes (diffusers
+ * resnet.py / attention_processor.py): the slabs a deferred afldm_conv2d left in its workspace ([nslab][B*N*N][C]
+ * fp32) are summed in slab order, + bias[c] + temb[b*temb_stride + c] + residual, rounded to `dtype` (the value the
+ * two-launch path stores; written to y_raw when other consumers need it), GroupNorm-ed with statistics formed
+ * inside the launch (one workgroup holds whole groups of one sample: C / G channels x N*N pixels each, fp64
+ * finish) and, with act = 1, passed through y = D silu(U xn U^T) D^T per plane:
+ *   act = 1: conv1(...) + temb -> norm2 -> the WarpedNonlinearity af_api.py:70-83 wraps around `nonlinearity`
+ *   act = 0: conv2(...) + shortcut -> Attention.group_norm of the attention block that follows the resnet
+ * Replaces the reduction launch (and, for act = 1, the stored intermediate and its re-read).  N in {2, 4};
+ * bias / temb / residual / y_raw may be NULL; temb_stride 0 = one row for all samples. */
 int afldm_af_act_slabs(const float* slabs, int nslab, const float* bias, const void* temb, int temb_stride,
-                       const float* gamma, const float* beta, int G, float eps, const float* U, const float* D,
-                       void* y, int B, int C, int N, int dtype, afldm_stream_t stream);
+                       const void* residual, void* y_raw, const float* gamma, const float* beta, int G, float eps,
+                       int act, const float* U, const float* D, void* y, int B, int C, int N, int dtype,
+                       afldm_stream_t stream);
 /* The tail of UNet2DModel.forward in one launch (bf16, 32x32 planes, C in {64, 128, 192}, Cout <= 4):
  * conv_norm_out (GroupNorm from the per-channel partial sums stats[B][S][C][2] of x) -> conv_act (plain SiLU:
  * af_api.py:70-83 leaves it unwrapped) -> conv_out (3x3 'same', weights packed OHWI [Cout][3][3][C], fp32 bias).

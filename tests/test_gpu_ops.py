@@ -596,6 +596,40 @@ def test_resnet_conv1_norm2_act_from_split_k_slabs(dtype, B, N, Cin, Cout):
     assert rel_rms_t(back(fused), act_ref) <= (1e-4 if dtype == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,N,C", [(64, 4, 768), (64, 2, 768), (8, 4, 768)])
+def test_resnet_conv2_hands_attention_its_normalised_input(dtype, B, N, C, monkeypatch):
+    """ResnetBlock2D -> Attention on 2x2 / 4x4 planes: conv2's split-K slabs (+ bias + residual) are finished, stored and
+    GroupNorm-ed for the attention block in one launch (afldm_af_act_slabs, act = 0); block output and attention output
+    against the ordinary sequence (reduction launch, gn_apply)."""
+    import torch.nn as nn
+    from afldm_amd.af_modules.af_blocks import WarpedNonlinearity
+    from afldm_amd.models import blocks
+    g = torch.Generator().manual_seed(B + N + C)
+    blk = blocks.ResnetBlock2D(in_channels=C, out_channels=C, temb_channels=64, groups=32, eps=1e-5)
+    attn = blocks.Attention(C, heads=C // 24, dim_head=24, eps=1e-5, norm_num_groups=32, residual_connection=True, bias=True)
+    with torch.no_grad():
+        for m in (blk, attn):
+            for prm in m.parameters():
+                prm.copy_(rnd(dtype, torch.randn(prm.shape, generator=g) * (0.03 if prm.ndim > 1 else 0.3)))
+        for nrm in (blk.norm1, blk.norm2, attn.group_norm):
+            nrm.weight.add_(1.0)
+    blk.nonlinearity = WarpedNonlinearity(nn.SiLU())
+    blk, attn = blk.cuda().to(dtype), attn.cuda().to(dtype)
+    xh = nhwc(rnd(dtype, torch.randn(B, C, N, N, generator=g)), dtype)
+    temb = rnd(dtype, torch.randn(B, C, generator=g)).to(device="cuda", dtype=dtype)
+    y = blk(xh, temb, C, next_gn=blocks._next_gn(attn))
+    if getattr(y, "gn_applied", None) is None:
+        pytest.skip("the plan of conv2 does not split K for this shape: nothing to hand over")
+    o = attn(y)
+    monkeypatch.setenv("AFLDM_NO_FUSED_ACT", "1")
+    y0 = blk(xh, temb, C, next_gn=blocks._next_gn(attn))
+    assert getattr(y0, "gn_applied", None) is None
+    o0 = attn(y0)
+    tol = 1e-5 if dtype == torch.float32 else 6e-3
+    assert rel_rms_t(y, y0) <= tol and rel_rms_t(o, o0) <= tol
+
+
 def rel_rms_t(a, b):
     a, b = a.detach().float().cpu().double(), b.detach().float().cpu().double()
     return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-30))
