@@ -1619,7 +1619,12 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
   const int ksteps_all = a->KS * a->KS * (Ct / kstep);
   const long long tiles64 = ((M + 63) / 64) * ((a->Cout + 63) / 64);
   if (M <= 4096 && ((ksteps_all <= 64 && tiles64 >= 256 && !(a->Cout % 192 == 0 && ksteps_all >= 27 && M >= 4096)) ||
-                    (ksteps_all <= 16 && tiles64 >= 128))) { vid = 32; bm = 64; bn = 64; }
+                    (ksteps_all <= 16 && tiles64 >= 128))) {
+    vid = 32; bm = 64; bn = 64;
+    // more than two resident rounds of 64x64 tiles (the q|k|v projection of the 4x4 level at batch 64: 576): 128x64
+    // tiles halve the rounds (in situ 5.180 -> 5.159 ms/step; 128x128 / 128x192 with K slices measured slower)
+    if (a->KS == 1 && tiles64 >= 512 && M % 128 == 0) { vid = 31; bm = 128; bn = 64; }
+  }
   else if (M >= 32768 && a->Cout % 192 == 0) { vid = 29; bm = 128; bn = 192; }
   else if (a->Cout % 192 == 0 && ((M >= 4096 && ksteps_all >= 27) || (M >= 1024 && ksteps_all >= 100))) { vid = 33; bm = 128; bn = 192; }
   else if (M >= 4096 && a->Cout % 128 == 0 && a->KS > 1) { vid = 30; bm = 128; bn = 128; }
