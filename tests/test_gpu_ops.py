@@ -139,7 +139,7 @@ def test_af_act_fused_groupnorm_concat(dtype, N, C1, C2, G):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("N,C", [(2, 64), (4, 96), (8, 64), (16, 64), (32, 192)])
+@pytest.mark.parametrize("N,C", [(2, 64), (4, 96), (4, 128), (8, 64), (8, 384), (16, 64), (16, 384), (32, 192)])
 def test_af_resample(dtype, N, C):
     from oracle import ideal_filters as idf
     ops = _ops()
