@@ -27,10 +27,12 @@
 // position c ^ ((q >> 1) & 7) is conflict free for every shift.  An LDS-DMA writes lane-linearly, so the permutation
 // is applied to the per-lane SOURCE chunk (guide rule 21).
 //
-// The accumulators start from the residual (loaded in fragment layout under the pipeline prologue).  Epilogue: the
-// fp32 tile leaves through the idle pipeline buffers 128 rows at a time as whole rows, 16 bytes per lane:
-// (residual + sum) + (bias + temb) in fp32, one rounding, per-channel GroupNorm partial sums of the stored values
-// accumulated by the thread that owns the column (fixed order, no atomics).
+// The residual enters through the ACCUMULATORS during the first K steps (fragment layout: its load latency runs under
+// MFMA work).  Epilogue: (residual + sum) + (bias + temb) in fp32, one rounding; bf16 tiles are staged ONCE in bf16
+// through the idle pipeline buffers and leave as whole rows, 16 bytes per lane (write-through stores), fp32 tiles and
+// split-K slabs 128 rows at a time; per-channel GroupNorm partial sums of the stored values accumulated by the thread
+// that owns the column (fixed order, no atomics); tiles of several whole samples (4x4 planes) carry one time-embedding
+// vector and one statistics record per sample.
 #include "conv_common.hpp"
 
 #include <type_traits>

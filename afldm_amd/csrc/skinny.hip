@@ -1,4 +1,4 @@
-// skinny.hip — 1x1 convolutions / dense layers over FEW rows (M = B*H*W <= 4096) straight from global memory to MFMA
+// skinny.hip — 1x1 convolutions / dense layers over FEW rows (M = B*H*W <= 1024, policy below) straight from global memory to MFMA
 // operand registers (gfx950).
 //
 // The 3x3 convolutions of the 2x2 level run as dense layers over the flattened plane (64 rows x 3072 at batch 64,
