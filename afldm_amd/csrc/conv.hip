@@ -269,7 +269,16 @@ __device__ __forceinline__ void splitk_fused_reduce(const ConvP& p, int m0, int 
   const unsigned ok = flag[0];
   __syncthreads();                                      // flag read by everyone before sR is reused
   if (!ok) {
-    if (etid == 0) __hip_atomic_store(p.sync + 2 * 4096, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // error word
+    // timed out: raise the error word (read + cleared by the host: ops.fused_splitk_error) and still DEPART, so that
+    // the tile's two counters return to zero once every slice has left and later launches start clean
+    if (etid == 0) {
+      __hip_atomic_store(p.sync + 2 * 4096, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned old = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == (unsigned)p.splitk - 1) {
+        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
     return;
   }
   constexpr int QPR = BN / 4;                           // fp32 quads per tile row

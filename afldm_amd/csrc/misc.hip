@@ -326,3 +326,45 @@ extern "C" int afldm_ddim_step_flat(const float* x, const float* eps, float* x_p
                                                             sqrt_1m_a_prev, n);
   return check_launch("afldm_ddim_step_flat");
 }
+
+// ----------------------------------------------------------------------------- box calibration probes
+// bench.py's `box` record: a fixed MFMA loop and a stream copy, timed in every run, so that numbers measured on
+// different MI355X boxes (clocks / power caps differ by ~10 %) can be normalised.
+typedef __attribute__((ext_vector_type(8))) __bf16 probe_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float probe_f32x16;
+
+__global__ __launch_bounds__(256) void k_probe_mfma(float* out, int iters) {
+  probe_bf16x8 a, b;
+  for (int i = 0; i < 8; ++i) {
+    a[i] = (__bf16)(0.001f * (float)((threadIdx.x + i) & 7));
+    b[i] = (__bf16)(0.5f + 0.001f * (float)((threadIdx.x * 3 + i) & 7));
+  }
+  probe_f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  for (int it = 0; it < iters; ++it) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c3, 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
+  if (s == -1.2345f) out[blockIdx.x * 256 + threadIdx.x] = s;      // never true: keeps the loop alive
+}
+
+__global__ __launch_bounds__(256) void k_probe_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+extern "C" int afldm_probe_mfma(float* out, int workgroups, int iters, afldm_stream_t stream) {
+  AFLDM_REQUIRE(out && workgroups > 0 && iters > 0, AFLDM_ESHAPE, "afldm_probe_mfma: out[workgroups * 256], workgroups, iters > 0");
+  k_probe_mfma<<<workgroups, 256, 0, (hipStream_t)stream>>>(out, iters);
+  return check_launch("afldm_probe_mfma");
+}
+
+extern "C" int afldm_probe_copy(const void* src, void* dst, size_t bytes, afldm_stream_t stream) {
+  AFLDM_REQUIRE(src && dst, AFLDM_ENULL, "afldm_probe_copy: NULL pointer");
+  AFLDM_REQUIRE(bytes % 16 == 0 && aligned16(src) && aligned16(dst), AFLDM_EALIGN, "afldm_probe_copy: whole 16-byte chunks");
+  if (bytes == 0) return AFLDM_OK;
+  k_probe_copy<<<256 * 16, 256, 0, (hipStream_t)stream>>>((const uint4*)src, (uint4*)dst, bytes / 16);
+  return check_launch("afldm_probe_copy");
+}

@@ -212,6 +212,11 @@ int skinny_stats_splits(const afldm_conv_args* a) {
   if (!sk_aligned16(a->x1) || !sk_aligned16(a->x2) || !sk_aligned16(a->w) || !sk_aligned16(a->y) || !sk_aligned16(a->residual) ||
       !sk_aligned16(a->temb) || !sk_aligned16(a->bias))
     return 0;
+  // 4-element vector loads / stores along the channel axis of y, the residual and the time-embedding rows
+  if ((a->y_ld & 3) || (a->res_ld & 3) || (a->temb_stride & 3)) return 0;
+  // the GroupNorm partial sums are formed per 64-row block: a block must hold whole samples (64 % HW == 0) or a sample
+  // whole blocks (HW % 64 == 0); 3x3 / 6x6 / 12x12 planes take the generic path + stand-alone statistics
+  if (a->stats_out && !(HW <= SK_ROWS ? SK_ROWS % HW == 0 : HW % SK_ROWS == 0)) return 0;
   return HW <= SK_ROWS ? 1 : HW / SK_ROWS;
 }
 

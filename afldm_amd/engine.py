@@ -10,7 +10,7 @@ increments itself — so a replay needs no host value and no synchronisation:
                                                    MLP and the 27 time_emb_proj layers depend on the timestep only and
                                                    are tabulated once per schedule)
     x_nhwc <- NCHW fp32 latents                   (afldm_nchw_to_nhwc)
-    eps    <- UNet(x_nhwc, t)                     (~450 HIP kernels, all from libafldm_hip.so)
+    eps    <- UNet(x_nhwc, t)                     (~250 HIP kernels at batch 64, all from libafldm_hip.so)
     lat    <- DDIM(lat, eps, coef[step])          (afldm_ddim_step, in place)
 """
 import os
@@ -18,6 +18,16 @@ import os
 import torch
 
 from . import ops
+
+
+def model_state_key(model):
+    """Fingerprint of everything a captured step bakes in: module identities (af_api surgery swaps modules), the
+    attention processors (set_unet_attn_processor), and every parameter's storage + in-place version counter
+    (load_state_dict copies in place -> _version moves; .to() / .half() re-allocate -> data_ptr moves).  ~1 ms for the
+    FFHQ UNet; compared once per DenoiseEngine.reset()."""
+    mods = tuple((id(m), id(getattr(m, "processor", None))) for m in model.modules())
+    params = tuple((p.data_ptr(), p._version) for p in model.parameters())
+    return hash((mods, params))
 
 
 class DenoiseEngine:
@@ -48,6 +58,7 @@ class DenoiseEngine:
         self.temb_table = torch.cat([unet.temb_projection(t) for t in self.timesteps], 0).contiguous()
         self.temb_row = torch.empty_like(self.temb_table[:1])
         self.temb_slices = unet.temb_slices(self.temb_row)
+        self._model_key = model_state_key(unet)
         nb = int(os.environ.get("AFLDM_BRANCHES", branches))
         self.branches = nb if nb > 1 and batch_size % nb == 0 else 1
         self._side = [torch.cuda.Stream() for _ in range(self.branches - 1)]
@@ -104,8 +115,25 @@ class DenoiseEngine:
         self.step_idx.fill_(-1)
         self.lat.copy_(keep)
 
+    def refresh_if_stale(self):
+        """The captured graphs hold the packed-weight pointers and the time-embedding table of the model AS IT WAS at
+        capture: after load_state_dict / .to() / af_api surgery / set_unet_attn_processor they would replay the old
+        model (or freed packed tensors).  Re-tabulate and drop the graphs when the model's fingerprint moved
+        (ADVICE r02)."""
+        key = model_state_key(self.unet)
+        if key == self._model_key:
+            return False
+        from .models.blocks import invalidate_packed
+        torch.cuda.synchronize()
+        self.graph = self.graph_multi = None
+        invalidate_packed(self.unet)       # in-place parameter edits do not pass through the modules' own hooks
+        self.temb_table.copy_(torch.cat([self.unet.temb_projection(t) for t in self.timesteps], 0))
+        self._model_key = key
+        return True
+
     def reset(self, latents):
         """latents: [B, C, H, W] (any device / float dtype); scaled by init_noise_sigma like the reference."""
+        self.refresh_if_stale()
         self.lat.copy_(latents.to(device=self.lat.device, dtype=torch.float32) * self.scheduler.init_noise_sigma)
         self.step_idx.fill_(-1)
 

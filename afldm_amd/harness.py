@@ -33,12 +33,13 @@ def vae_decode(vae, x):
 
 @torch.no_grad()
 def shift_ldm(pipeline, num_inference_steps=50, num_shift_steps=16, output_path="results/shift_ldm.gif",
-              input_path=None, generator=None, rank=0, world=1, batch_offsets=True, reference_exact=False):
+              input_path=None, generator=None, rank=0, world=1, batch_offsets=True, reference_exact=True):
     """batch_offsets: the LOAD passes of this rank's offsets run as ONE batch (samples are independent; the
     cross-frame K/V of the stored pass is shared by the whole batch) instead of the reference's one B = 1
     sampler run per offset (shift_ldm_ffhq.py:124-151) - 50 UNet evaluations instead of 50 per offset.
 
-    Deviations from the reference flow, switched off by reference_exact=True:
+    reference_exact=True (the default) follows the reference flow to the letter; reference_exact=False
+    (scripts: --fixed_resize) opts into two deliberate deviations:
     * `input_path`: the image is resized to sample_size * VAE ratio (256) so that its latent has the UNet's
       sample_size; the reference resizes to (sample_size, sample_size) = 32 x 32 BEFORE the VAE
       (shift_ldm_ffhq.py:110-113), i.e. inverts a 4 x 4 latent.

@@ -325,8 +325,8 @@ class ResnetBlock2D(nn.Module):
         conv = self.conv2
         Cout = conv.out_channels
         if (tuple(conv.kernel_size) != (3, 3) or Cout % next_gn.num_groups or Cin % 8 or Cout % 8
-                or next_gn.num_channels != Cout or res.shape[-1] != Cout):
-            return None
+                or next_gn.num_channels != Cout or res.shape[-1] != Cout or not res.is_contiguous()):
+            return None          # (afldm_af_act_slabs reads the residual as dense [B, N, N, Cout]: no res_ld)
         if N == 2 and not os.environ.get("AFLDM_NO_DENSE2X2"):
             w2, _ = packed_conv_dense2x2(conv, h.dtype, Cin, 0)
             got = ops.conv2d_slabs(h.reshape(B, 4 * Cin), w2)

@@ -8,10 +8,47 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ConvArgs, DTYPE_CODE, SepArgs, check, lib, ptr, stream_ptr
+from ._lib import ConvArgs, DTYPE_CODE, SepArgs, check, stream_ptr
 
 _FILTER_CACHE = {}
 _PROFILE = None
+
+
+class _RecordingLib:
+    """libafldm_hip.so's entry points.  Outside a Profiler this is a plain pass-through; inside one every call is also
+    noted as (function, arguments) so that the launches between _begin() and _end() can be re-issued later on the
+    same buffers: bench.py captures each kernel family's launches of one step into a HIP graph and times the replay
+    (kernel time without host gaps).  The stream is the last argument of every launching entry point; a replay
+    substitutes the stream that is current then."""
+
+    def __init__(self, raw):
+        self._raw = raw
+        self._wrapped = {}
+
+    def __getattr__(self, name):
+        w = self._wrapped.get(name)
+        if w is None:
+            f = getattr(self._raw, name)
+
+            def w(*a, _f=f):
+                if _PROFILE is not None:
+                    _PROFILE.pending.append((_f, a))
+                return _f(*a)
+            self._wrapped[name] = w
+        return w
+
+
+lib = _RecordingLib(_lib.lib)
+
+
+def ptr(t):
+    """Device address of a tensor (None -> NULL).  Under a Profiler the tensor is also kept alive, so that a recorded
+    launch can be replayed on buffers that still hold the step's real activations."""
+    if t is None:
+        return None
+    if _PROFILE is not None:
+        _PROFILE.live.append(t)
+    return t.data_ptr()
 
 
 class Profiler:
@@ -20,6 +57,8 @@ class Profiler:
 
     def __init__(self):
         self.records = []
+        self.pending = []        # (function, args) of the library calls since the last _begin()
+        self.live = []           # tensors whose addresses went into recorded calls
 
     def __enter__(self):
         global _PROFILE
@@ -45,9 +84,19 @@ class Profiler:
 def _begin():
     if _PROFILE is None:
         return None
+    _PROFILE.pending = []
     e = torch.cuda.Event(enable_timing=True)
     e.record()
     return e
+
+
+def _replay_of(calls):
+    """Re-issue recorded launches on the current stream (their last argument is the stream)."""
+    def replay():
+        st = stream_ptr()
+        for f, a in calls:
+            check(f(*a[:-1], st), "replay")
+    return replay
 
 
 def _end(tok, kind, flops=0.0, nbytes=0.0, replay=None):
@@ -57,6 +106,12 @@ def _end(tok, kind, flops=0.0, nbytes=0.0, replay=None):
         return
     e = torch.cuda.Event(enable_timing=True)
     e.record()
+    if replay is None:
+        st = stream_ptr()
+        calls = [(f, a) for f, a in _PROFILE.pending if a and a[-1] == st]       # launches only (queries take no stream)
+        if calls:
+            replay = _replay_of(calls)
+    _PROFILE.pending = []
     _PROFILE.records.append((kind, float(flops), float(nbytes), tok, e, replay))
 
 
@@ -523,11 +578,24 @@ _SYNC = {}
 
 def _sync_words(device):
     """Zero-initialised counter words for the in-kernel split-K reduction (afldm_conv_args.sync): one buffer per
-    device, shared by every launch in stream order - each launch leaves it zero."""
-    key = str(device)
+    (device, stream) - launches of ONE stream share it in stream order and each leaves it zero; concurrent streams
+    (DenoiseEngine branches) must not share tile counters."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     if key not in _SYNC:
         _SYNC[key] = torch.zeros(16384, dtype=torch.int32, device=device)
     return _SYNC[key]
+
+
+def fused_splitk_error(device=None):
+    """True if an in-kernel split-K reduction (AFLDM_FUSED_SPLITK) gave up waiting for a slice since the last call;
+    reads and clears the error word of every sync buffer of the device (synchronises)."""
+    hit = False
+    for (dev, _), buf in _SYNC.items():
+        if device is None or dev == str(device):
+            if int(buf[8192].item()):
+                hit = True
+                buf[8192] = 0
+    return hit
 
 
 def conv_args(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, out=None, out_mode=0,
@@ -661,7 +729,8 @@ def conv_out_fused(x, w, bias, gamma, beta, G, eps):
     """conv_norm_out -> SiLU -> conv_out (3x3, <= 4 couts) of the UNet tail in one launch (afldm_conv_out_fused);
     returns None when the shape is not covered (the caller runs gn_apply + conv2d)."""
     if (x.dtype != torch.bfloat16 or x.ndim != 4 or x.shape[1] != 32 or x.shape[2] != 32 or x.shape[3] not in (64, 128, 192)
-            or w.shape[0] > 4 or w.shape[1] != 3 or os.environ.get("AFLDM_NO_CONV_OUT_FUSED")):
+            or w.shape[0] > 4 or w.shape[1] != 3 or os.environ.get("AFLDM_NO_CONV_OUT_FUSED")
+            or G > 64 or G <= 0 or x.shape[3] % G or not x.is_contiguous()):      # the C side's own constraints
         return None
     B, N, _, C = x.shape
     Cout = w.shape[0]

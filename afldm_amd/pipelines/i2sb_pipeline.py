@@ -13,11 +13,11 @@ class I2SBLDMPipeline(MyLDMPipeline):
 
     @torch.no_grad()
     def __call__(self, images, generator=None, is_ode=False, num_inference_steps=50, output_type="pil",
-                 return_dict=True, reference_exact=False, **kwargs):
+                 return_dict=True, reference_exact=True, **kwargs):
         """images: [B, 3, H, W] tensor in [-1, 1] (the reference's VaeImageProcessor.preprocess leaves
-        such tensors unchanged).  The posterior sample of the start latent is drawn from `generator` (seeded runs are
-        reproducible); the reference calls latent_dist.sample() without it (i2sb_pipeline.py) - reference_exact=True
-        does the same."""
+        such tensors unchanged).  Like the reference (i2sb_pipeline.py:43) the posterior sample of the start latent is
+        drawn by latent_dist.sample() WITHOUT the caller's generator; reference_exact=False opts into drawing it from
+        `generator` (seeded runs become reproducible end to end)."""
         if self.vae is None:
             raise NotImplementedError("I2SBLDMPipeline needs a VAE to encode the degraded image")
         start = self.vae.encode(images.to(device=self.device, dtype=self.unet.dtype)).latent_dist.sample(

@@ -69,34 +69,32 @@ def roofline_pass(unet, batch, dtype):
                       share=round(d["ms"] / total_ms, 4),
                       tflops=round(d["flops"] / d["ms"] / 1e9, 2) if d["ms"] > 0 else 0.0,
                       gbs=round(d["bytes"] / d["ms"] / 1e6, 1) if d["ms"] > 0 else 0.0)
-    dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
-    name, d = dom
-    # The eager pass brackets every launch with events on the launch stream, but the host needs 10-20 us of Python per
-    # launch: short kernels (the 8x8 .. 2x2 levels) are timed together with the gap in front of them.  For the dominant
-    # family the SAME launches - same argument blocks, same buffers holding the step's real activations - are therefore
-    # also captured back to back into one HIP graph and timed with events around its replay: kernel time including the
-    # boundaries between the family's own launches, no host gaps.  This replay time is what `achieved` is computed from.
-    replay = None
-    calls = [r for r in prof.records if r[0] == name and r[5] is not None]
-    if calls and len(calls) == d["launches"]:
+    # Every family again WITHOUT host gaps: the launches of ONE step of the family - same argument blocks, same buffers
+    # still holding the step's real activations - captured back to back into one HIP graph and timed with events around
+    # its replay.  `ms_per_step` / `tflops` / `gbs` of a family are from this replay (kernel time incl. the boundaries
+    # between the family's own launches); the eager figures (each launch bracketed by events, 10-20 us of Python in
+    # front of it) are kept as eager_ms_per_step.
+    replays = {}
+    for k, d in agg.items():
+        calls = [r for r in prof.records if r[0] == k]
+        if not calls or any(r[5] is None for r in calls) or len(calls) % 3:
+            continue
         calls = calls[:len(calls) // 3]                      # the launches of ONE step
-        for r in calls:
-            r[5]()
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for r in calls:
-                r[5]()
-        ts = []
-        for _ in range(7):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            g.replay()
-            e1.record()
-            torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1))
-        replay = dict(ms=median(ts[2:]), launches=len(calls), flops=sum(r[1] for r in calls), bytes=sum(r[2] for r in calls))
-        del g
+        rp = replay_family(calls)
+        replays[k] = rp
+        f = fam[k]
+        f["eager_ms_per_step"] = f["ms_per_step"]
+        f["ms_per_step"] = round(rp["ms"], 4)
+        f["tflops"] = round(rp["flops"] / rp["ms"] / 1e9, 2) if rp["ms"] > 0 else 0.0
+        f["gbs"] = round(rp["bytes"] / rp["ms"] / 1e6, 1) if rp["ms"] > 0 else 0.0
+        f["timing"] = "graph replay"
+    tot = sum(f["ms_per_step"] for f in fam.values())
+    for f in fam.values():
+        f["share"] = round(f["ms_per_step"] / tot, 4) if tot > 0 else 0.0
+    fam = dict(sorted(fam.items(), key=lambda kv: -kv[1]["ms_per_step"]))
+    name = next(iter(fam))
+    d = agg[name]
+    replay = replays.get(name)
     # HBM bytes per launch of the dominant family from the PMC counters (FETCH_SIZE / WRITE_SIZE in separate
     # rocprofv3 passes, gfx950 x2 read correction): a PMC pass cannot run inside the timed process, so it is
     # collected by profiles/run_pmc_conv3x3.sh over a replay of exactly this family's launches and committed
@@ -137,6 +135,96 @@ def roofline_pass(unet, batch, dtype):
                     launches_per_step=d["launches"] // 3, avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
                     bytes_per_launch=d["bytes"] / d["launches"])
     return roof, fam
+
+
+def replay_family(calls):
+    """HIP-graph replay of recorded launches (ops.Profiler records): median of 5 replays after 2 warm ones."""
+    for r in calls:
+        r[5]()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for r in calls:
+            r[5]()
+    ts = []
+    for _ in range(7):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    del g
+    return dict(ms=median(ts[2:]), launches=len(calls), flops=sum(r[1] for r in calls), bytes=sum(r[2] for r in calls))
+
+
+def _sysfs_first(paths):
+    import glob
+    for pat in paths:
+        for fn in sorted(glob.glob(pat)):
+            try:
+                return open(fn).read().strip()
+            except OSError:
+                pass
+    return None
+
+
+def box_record(dev):
+    """Fingerprint of THIS box, measured in this run: a fixed MFMA loop (~50 ms of back-to-back
+    v_mfma_f32_32x32x16_bf16 on every SIMD: the sustained MFMA clock under load), a 1 GiB device-to-device stream copy,
+    and the clock / power-cap state the driver exposes.  Box-to-box spread of one build was 3-12 % in rounds 1-2; dividing a
+    kernel figure by `mfma_tflops` (MFMA-bound) or `copy_gbs` (HBM-bound) of its own run makes lines from different
+    boxes comparable."""
+    from afldm_amd import _lib
+    lib = _lib.lib
+    st = torch.cuda.current_stream().cuda_stream
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    wgs = cus * 4                                              # 4 waves per SIMD
+    out = torch.zeros(wgs * 256, dtype=torch.float32, device=dev)
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return median(ts)
+
+    iters = 240000
+    ms = timed(lambda: _lib.check(lib.afldm_probe_mfma(out.data_ptr(), wgs, iters, st), "probe_mfma"), 3)
+    flops = wgs * 4.0 * iters * 4 * 32 * 32 * 16 * 2
+    nbytes = 1 << 30
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 255)
+    dst = torch.empty_like(src)
+    cms = timed(lambda: _lib.check(lib.afldm_probe_copy(src.data_ptr(), dst.data_ptr(), nbytes, st), "probe_copy"), 5)
+    rec = dict(mfma_tflops=round(flops / ms / 1e9, 1), mfma_probe_ms=round(ms, 2),
+               # one 32x32x16 bf16 MFMA (32768 flop) occupies its SIMD's matrix pipe for 32 cycles
+               mfma_clock_ghz=round(flops / (ms * 1e-3) / 32768.0 / (cus * 4) * 32 / 1e9, 3),
+               copy_gbs=round(2.0 * nbytes / cms / 1e6, 1), copy_probe_ms=round(cms, 3), cus=cus,
+               device=torch.cuda.get_device_properties(dev).name)
+    # clocks / power cap as exposed by the amdgpu driver (absent inside some containers: recorded as null)
+    base = "/sys/class/drm/card*/device/"
+    def cur(txt):
+        if not txt:
+            return None
+        for line in txt.splitlines():
+            if line.rstrip().endswith("*"):
+                return line.split(":")[1].strip(" *")
+        return txt.splitlines()[-1].split(":")[-1].strip()
+    rec["sclk"] = cur(_sysfs_first([base + "pp_dpm_sclk"]))
+    rec["mclk"] = cur(_sysfs_first([base + "pp_dpm_mclk"]))
+    cap = _sysfs_first([base + "hwmon/hwmon*/power1_cap"])
+    rec["power_cap_w"] = round(int(cap) / 1e6, 1) if cap and cap.isdigit() else None
+    pw = _sysfs_first([base + "hwmon/hwmon*/power1_average", base + "hwmon/hwmon*/power1_input"])
+    rec["power_now_w"] = round(int(pw) / 1e6, 1) if pw and pw.isdigit() else None
+    del src, dst, out
+    torch.cuda.empty_cache()
+    return rec
 
 
 def cpu_baseline(budget_s=14.0):
@@ -358,10 +446,15 @@ def main():
             "config": {"workload": "FFHQ-256 AF-UNet single denoise step, batch 64 per GPU (BASELINE configs[1])",
                        "batch_per_gpu": B, "global_batch": total, "sharding": "batch, one all-gather of final latents per region",
                        "hip_graph": not args.no_graph, "latents_finite": finite,
+                       "loop_invariant_hoisting": "time_proj -> time_embedding MLP -> SiLU -> the 27 time_emb_proj layers depend on "
+                                                  "the timestep only and are tabulated once per 50-step schedule in DenoiseEngine.__init__ "
+                                                  "(outside the timed region; < 0.1 % of the step's flops, 6 launches): a timed step copies "
+                                                  "its table row instead of recomputing them as the reference does per step",
                        "timing": f"median of {len(regions)} timed regions of {args.steps} steps, each bracketed by barrier + "
                                  "synchronize, MAX over ranks",
                        "regions_ms_per_step": [round(1e3 * r / args.steps, 4) for r in regions]},
         }
+        out["box"] = box_record(dev)
         if not args.no_roofline:
             roof, fam = roofline_pass(unet, B, dtype)
             out["roofline"] = roof

@@ -328,6 +328,15 @@ int afldm_upfirdn2d(const void* x, const float* f, void* y, int planes, int H, i
 /* Output extent along one axis for the arguments above, -1 when the plane is smaller than the filter. */
 int afldm_upfirdn2d_out_size(int in, int up, int down, int pad0, int pad1, int ftaps);
 
+/* ---- box calibration probes (measurement only: bench.py's `box` record) --------------------------------
+ * afldm_probe_mfma: `workgroups` x 4 waves, each issuing iters x 4 independent v_mfma_f32_32x32x16_bf16
+ * (flops = workgroups * 4 * iters * 4 * 32768); out [workgroups * 256] fp32 is never written.
+ * afldm_probe_copy: 16-byte-per-lane grid-stride copy of `bytes` (a multiple of 16) device -> device.
+ * Neither replaces a reference computation: they fingerprint the box (MFMA clock under load, HBM copy rate)
+ * so that cross-box numbers can be normalised. */
+int afldm_probe_mfma(float* out, int workgroups, int iters, afldm_stream_t stream);
+int afldm_probe_copy(const void* src, void* dst, size_t bytes, afldm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -383,6 +383,28 @@ def part_f():
     np.savez_compressed(os.path.join(OUT, "g12_full_vae.npz"), **g)
 
 
+def part_g():
+    """Round 3: the FULL 50-step DDIM run of BASELINE configs[0] (FFHQ-size UNet, batch 1, fp32
+    oracle; reference loop ldm_pipeline.py:103-109) and the FFHQ-size fractional-shift equivariance values of the
+    oracle itself (STORE pass + two ideal-crop shifted LOAD passes, 4 steps; reference shift_ldm_ffhq.py:124-151),
+    so that the at-size GPU tests compare with the oracle instead of with the HIP fp32 run."""
+    from . import configs, pipeline, unet
+    torch.set_num_threads(8)
+    cfg = configs.FFHQ_UNET
+    sd = unet.init_unet_params(cfg, seed=0, conv_out_scale=0.1)
+    x = torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(1234))
+    g = {"ffhq_x": x.numpy()}
+    lat, traj = pipeline.ddim_sample(sd, cfg, x, 50, af=True, return_traj=True)
+    g["ffhq_ddim_final"] = lat.numpy()
+    g["ffhq_ddim_step25"] = traj[24].numpy()
+    base, res = pipeline.shift_equivariance(sd, cfg, x, [0.375, 1.0], 4, ratio=8)
+    g["ffhq_equiv_base"] = base.numpy()
+    for k, r in enumerate(res):
+        g[f"ffhq_equiv_lat_{k}"] = r["latent"].numpy()
+        g[f"ffhq_equiv_mse_{k}"] = np.float64(r["mse"])
+    np.savez_compressed(os.path.join(OUT, "g13_r03.npz"), **g)
+
+
 def idf_warp(x):
     from .ideal_filters import warped_nonlinearity
     return warped_nonlinearity(x)
@@ -403,5 +425,7 @@ if __name__ == "__main__":
         part_e()
     if which in ("f", "all"):
         part_f()
+    if which in ("g", "all"):
+        part_g()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -395,6 +395,7 @@ def test_conv2d_split_k_reduced_inside_the_launch(dtype, case):
         torch.cuda.synchronize()
     finally:
         _lib.lib.afldm_conv2d_fused_splitk(0)
+    assert not ops.fused_splitk_error()        # no slice timed out (the error word of the sync buffers stays clear)
     for y1, st1, _ in ys:
         assert torch.equal(y0, y1)
         torch.testing.assert_close(st1.sum(1), st0.sum(1), rtol=1e-5, atol=1e-3)

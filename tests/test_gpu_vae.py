@@ -173,7 +173,7 @@ def test_i2sb_scheduler_step_and_pipeline(golden):
     pipe.set_progress_bar_config(disable=True)
     img = (torch.rand(1, 3, 128, 128, generator=g) * 2 - 1)
     lat = pipe(img, is_ode=True, num_inference_steps=4, output_type="latent",
-               generator=torch.Generator().manual_seed(3))
+               generator=torch.Generator().manual_seed(3), reference_exact=False)   # seeded posterior draw (opt-in)
     # oracle: same chain on CPU
     mom = ov.encode_moments(vsd, vcfg, img)
     mean, logvar = mom.chunk(2, 1)
