@@ -1599,6 +1599,7 @@ static const Variant kVariants[] = {
     {128, 96, 6, 3},   // 55  32x32 planes, 4 rows x 96 couts (small batches)
     {64, 32, 4, 12},   // 56  64x32 tiles, 12 stages (a skinny GEMM's K step costs DMA latency / ring depth): dense layers over <= 64 rows (the 2x2 level at batch 64) WITHOUT split-K
     {256, 192, 6, 2},  // 57  = 41 with a 2-deep weight ring (lookahead experiment)
+    {256, 128, 6, 3},  // 58  halo-patch on planes of 64^2 and up (AF-VAE): 8 x 32 pixel blocks x 128 couts
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -1648,7 +1649,7 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
     if (kVariants[v].ver == 6) {
       // halo-patch kernel: the small-tile variants (51+) may split the CHANNEL BLOCKS over up to 4 slices when the
       // tiles alone leave most CUs idle; the slice count must divide the number of 128-byte channel blocks
-      if (v < 51 || v == 57) return 1;
+      if (v < 51 || v >= 57) return 1;
       const int ncb = Ct / (2 * elems_per_row);
       int z = 1;
       for (int c = 2; c <= 4; ++c)
@@ -1700,6 +1701,13 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
         else if (a->W == 4 && M >= 64) vid = 52;
       }
     }
+  }
+  {
+    // planes of 64^2 and up (the AF-VAE): the halo-patch kernel on 8 x 32 pixel blocks of the plane (variant 58)
+    static const bool off = getenv("AFLDM_NO_CONV3H_SUB") != nullptr;
+    if (!off && a->KS == 3 && a->C2 == 0 && a->W >= 64 && a->W % 32 == 0 && a->H % 8 == 0 && a->Cout % 128 == 0 &&
+        Ct % (2 * elems_per_row) == 0 && M >= 256 * 192)
+      vid = 58;
   }
   {
     // a dense layer over <= 64 rows (the 3x3 convolutions of the 2x2 level in their flattened form at batch 64) on 96+
@@ -2162,24 +2170,51 @@ extern "C" int afldm_conv2d_fused_splitk(int enable) {
   return AFLDM_OK;
 }
 
-extern "C" int afldm_conv2d_variant(const afldm_conv_args* a) {
-  if (!a || (a->dtype != AFLDM_F32 && a->dtype != AFLDM_BF16)) return -1;
+// Batch chunking.  The LDS-DMA kernels address their pixel operand through a buffer descriptor (32-bit byte offsets, 2 GiB):
+// the AF-VAE's 256^2 levels at batch 128 (128 x 65536 pixels x 128 channels x 2 B = 2.1 GB) used to fall back to the
+// round-1 register-staged kernel at 0.43 PFLOP/s for that reason alone (profiles/r03/r03a_vae_kernel_stats.csv: 28 % of
+// the C4 workload).  Samples are independent, so such a call is issued as B / c launches over c whole samples each
+// (c the largest divisor of B whose operand fits), every one on the fast kernels; the queries below answer for the
+// chunk, so plan, statistics splits and workspace agree with what is launched.
+static int conv_batch_chunk(const afldm_conv_args* a) {
+  const long long esz = a->dtype == AFLDM_F32 ? 4 : 2;
+  const long long per = (long long)a->H * a->W * (a->C1 > a->C2 ? a->C1 : a->C2) * esz;
+  if (a->B <= 1 || (long long)a->B * per < (1ll << 31) || per >= (1ll << 31)) return a->B;
+  int c = (int)(((1ll << 31) - 1) / per);
+  while (c > 1 && a->B % c) --c;
+  return c;
+}
+
+static afldm_conv_args conv_chunk_args(const afldm_conv_args* a, int c) {
+  afldm_conv_args q = *a;
+  q.B = c;
+  return q;
+}
+
+extern "C" int afldm_conv2d_variant(const afldm_conv_args* a0) {
+  if (!a0 || (a0->dtype != AFLDM_F32 && a0->dtype != AFLDM_BF16)) return -1;
+  const afldm_conv_args ac = conv_chunk_args(a0, conv_batch_chunk(a0));
+  const afldm_conv_args* a = &ac;
   const Exec e = a->dtype == AFLDM_F32 ? resolve_exec<float>(a) : resolve_exec<bf16>(a);
   if (skinny_stats_splits(a)) return -16;        // skinny.hip
   if (e.pl.kind != 0) return -1 - e.pl.kind;
   return e.vid | (e.splitk << 8) | (e.fused << 16);
 }
 
-extern "C" int afldm_conv2d_stats_splits(const afldm_conv_args* a) {
-  if (!a || (a->dtype != AFLDM_F32 && a->dtype != AFLDM_BF16)) return 0;
+extern "C" int afldm_conv2d_stats_splits(const afldm_conv_args* a0) {
+  if (!a0 || (a0->dtype != AFLDM_F32 && a0->dtype != AFLDM_BF16)) return 0;
+  const afldm_conv_args ac = conv_chunk_args(a0, conv_batch_chunk(a0));
+  const afldm_conv_args* a = &ac;
   int S = 0;
   if (a->dtype == AFLDM_F32) stats_mode<float>(a, resolve_exec<float>(a), &S);
   else stats_mode<bf16>(a, resolve_exec<bf16>(a), &S);
   return S;
 }
 
-extern "C" size_t afldm_conv2d_workspace(const afldm_conv_args* a) {
-  if (!a || (a->dtype != AFLDM_F32 && a->dtype != AFLDM_BF16)) return 0;
+extern "C" size_t afldm_conv2d_workspace(const afldm_conv_args* a0) {
+  if (!a0 || (a0->dtype != AFLDM_F32 && a0->dtype != AFLDM_BF16)) return 0;
+  const afldm_conv_args ac = conv_chunk_args(a0, conv_batch_chunk(a0));
+  const afldm_conv_args* a = &ac;
   if (lin_wreg_bm(a) || skinny_stats_splits(a)) return 0;
   Plan pl = make_plan(a, a->dtype == AFLDM_F32 ? 16 : 32);
   if (pl.kind != 0 || pl.splitk <= 1) return 0;
@@ -2190,8 +2225,27 @@ extern "C" int afldm_conv2d(const afldm_conv_args* a, afldm_stream_t stream) {
   int rc = conv_validate(a);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (a->dtype == AFLDM_F32) return conv_dispatch<float>(a, st);
-  if (a->dtype == AFLDM_BF16) return conv_dispatch<bf16>(a, st);
-  set_error("afldm_conv2d: unknown dtype %d", a->dtype);
-  return AFLDM_EDTYPE;
+  if (a->dtype != AFLDM_F32 && a->dtype != AFLDM_BF16) {
+    set_error("afldm_conv2d: unknown dtype %d", a->dtype);
+    return AFLDM_EDTYPE;
+  }
+  const int c = conv_batch_chunk(a);
+  if (c == a->B) return a->dtype == AFLDM_F32 ? conv_dispatch<float>(a, st) : conv_dispatch<bf16>(a, st);
+  // whole-sample chunks (see conv_batch_chunk): every per-sample operand advances by its own stride
+  const size_t esz = a->dtype == AFLDM_F32 ? 4 : 2;
+  const size_t HW = (size_t)a->H * a->W;
+  afldm_conv_args q = conv_chunk_args(a, c);
+  const int S = a->stats_out ? afldm_conv2d_stats_splits(&q) : 0;
+  for (int b0 = 0; b0 < a->B; b0 += c) {
+    q.x1 = (const char*)a->x1 + (size_t)b0 * HW * a->C1 * esz;
+    q.x2 = a->x2 ? (const char*)a->x2 + (size_t)b0 * HW * a->C2 * esz : nullptr;
+    q.y = (char*)a->y + (size_t)b0 * (a->out_mode == 1 ? (size_t)a->Cout * HW : HW * a->y_ld) * esz;
+    q.y2 = a->y2 ? (char*)a->y2 + (size_t)b0 * (size_t)(a->Cout - a->split_n) * HW * esz : nullptr;
+    q.residual = a->residual ? (const char*)a->residual + (size_t)b0 * HW * a->res_ld * esz : nullptr;
+    q.temb = a->temb ? (const char*)a->temb + (size_t)b0 * a->temb_stride * esz : nullptr;
+    q.stats_out = a->stats_out ? a->stats_out + (size_t)b0 * S * a->Cout * 2 : nullptr;
+    rc = a->dtype == AFLDM_F32 ? conv_dispatch<float>(&q, st) : conv_dispatch<bf16>(&q, st);
+    if (rc) return rc;
+  }
+  return AFLDM_OK;
 }

@@ -107,7 +107,11 @@ __device__ __forceinline__ int h_chunk_at(int pos, int sw) {   // source chunk t
 // levels, one MFMA wave per SIMD) do 3 taps between two barriers so that a step still carries 36 MFMAs per wave.
 // Tiles may hold several whole samples (BM >= H * W: NSEG segments of SEG = H rows, each with its own halo rows) and
 // the channel blocks may be split over blockIdx.z (fp32 slabs, reduced by k_splitk_reduce*, conv.hip).
-template <typename T, int BM, int W_, int BN, int WGM, int WGN, int NPROD, int STAGES, int MINW, int MF, int TPS>
+// SUB: the plane is LARGER than the tile (the AF-VAE's 64^2 .. 256^2 planes): a tile is a ROWS x W_ block of an
+// H x W plane, its patch the (ROWS + 2) x (W_ + 2) block around it - zero only where that leaves the image - and the
+// tile's pixels are W_-long runs p.W pixels apart in memory.  (The implicit GEMM re-fetched the pixel tile for every
+// tap there too: 0.69 PFLOP/s at 256^2 x 128 channels, profiles/r03.)
+template <typename T, int BM, int W_, int BN, int WGM, int WGN, int NPROD, int STAGES, int MINW, int MF, int TPS, bool SUB = false>
 __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP p) {
   typedef Mma<T> MM;
   typedef typename MM::Chunk Chunk;
@@ -152,14 +156,33 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
     tile_m = tile / p.tiles_n;
     tile_n = tile - tile_m * p.tiles_n;
   }
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int Ct = p.C1, HW = W_ * W_;
+  static_assert(!SUB || (NSEG == 1 && TPS == 1), "sub-tiled planes: one segment per tile");
+  const int n0 = tile_n * BN;
+  const int Ct = p.C1, HW = SUB ? p.H * p.W : W_ * W_;
   const int ncb = Ct / KSTEP;
   const int ks = blockIdx.z;
   const int cb_lo = (ncb * ks) / p.splitk, cb_hi = (ncb * (ks + 1)) / p.splitk;   // this slice's channel blocks
   const int G = (cb_hi - cb_lo) * SPC;
-  const int b_tile = m0 / HW;
-  const int oh0 = NSEG == 1 ? (m0 - b_tile * HW) / W_ : 0;      // first image row of the (single) segment
+  int m0, b_tile, oh0, ow0 = 0, sp_tile;                         // first pixel, sample, tile origin, tile index inside the sample
+  if constexpr (SUB) {
+    const int tw = p.W / W_, tps = (p.H / ROWS) * tw;
+    b_tile = tile_m / tps;
+    sp_tile = tile_m - b_tile * tps;
+    const int ty = sp_tile / tw;
+    oh0 = ty * ROWS;
+    ow0 = (sp_tile - ty * tw) * W_;
+    m0 = b_tile * HW + oh0 * p.W + ow0;
+  } else {
+    m0 = tile_m * BM;
+    b_tile = m0 / HW;
+    oh0 = NSEG == 1 ? (m0 - b_tile * HW) / W_ : 0;               // first image row of the (single) segment
+    sp_tile = (m0 - b_tile * HW) / BM;
+  }
+  // global pixel (row of x / y / residual) of tile pixel tp
+  auto gpix = [&](int tp) -> int {
+    if constexpr (SUB) return m0 + (tp / W_) * p.W + (tp % W_);
+    else return m0 + tp;
+  };
 
   if (is_producer) {
     const int wave = wave_all - NWC;
@@ -179,8 +202,16 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
       const int pr = q / PW, pc = q - pr * PW;
       const int sg = pr / (SEG + 2), jj = pr - sg * (SEG + 2);            // segment (one sample's rows) and row inside it
       const int ih = oh0 + jj - 1;
-      const bool ok = q < NPQ && pc >= 1 && pc <= W_ && ih >= 0 && ih < W_;
-      const int pixel = m0 + (sg * SEG + jj - 1) * W_ + (pc - 1);
+      bool ok;
+      int pixel;
+      if constexpr (SUB) {
+        const int iw = ow0 + pc - 1;
+        ok = q < NPQ && iw >= 0 && iw < p.W && ih >= 0 && ih < p.H;
+        pixel = b_tile * HW + ih * p.W + iw;
+      } else {
+        ok = q < NPQ && pc >= 1 && pc <= W_ && ih >= 0 && ih < W_;
+        pixel = m0 + (sg * SEG + jj - 1) * W_ + (pc - 1);
+      }
       poff[i] = ok ? ((unsigned)pixel * (unsigned)Ct + (unsigned)(c * EPC)) * ESZ : OOB;
     }
 #pragma unroll
@@ -292,7 +323,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
 #pragma unroll
         for (int rq = 0; rq < RQ; ++rq) {
           float r0, r1, r2, r3;
-          load4<T>(res + (size_t)(m0 + wm * WMS + b * MF + li) * p.res_ld + cout_of(a, rq), r0, r1, r2, r3);
+          load4<T>(res + (size_t)gpix(wm * WMS + b * MF + li) * p.res_ld + cout_of(a, rq), r0, r1, r2, r3);
           acc[a][b][4 * rq] = r0; acc[a][b][4 * rq + 1] = r1; acc[a][b][4 * rq + 2] = r2; acc[a][b][4 * rq + 3] = r3;
         }
   }
@@ -303,7 +334,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
       const int idx = chunk * RCH + k;
       if (idx < NRT) {
         const int a = idx / (TM * RQ), b = (idx / RQ) % TM, rq = idx % RQ;
-        rv[k] = *reinterpret_cast<const Quad*>(res + (size_t)(m0 + wm * WMS + b * MF + li) * p.res_ld + cout_of(a, rq));
+        rv[k] = *reinterpret_cast<const Quad*>(res + (size_t)gpix(wm * WMS + b * MF + li) * p.res_ld + cout_of(a, rq));
       }
     }
   };
@@ -580,7 +611,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
 #pragma unroll 4
         for (int row = tr; row < BM; row += RPI) {
           const Chunk o = ld16<Chunk>(sO + row * OROW + ch * EO);
-          if (!(p.dbg & 4)) st16_out<Chunk>((T*)p.y + (size_t)(m0 + row) * p.y_ld + n, o);      // write-through (build.py: AFLDM_WT)
+          if (!(p.dbg & 4)) st16_out<Chunk>((T*)p.y + (size_t)gpix(row) * p.y_ld + n, o);      // write-through (build.py: AFLDM_WT)
           if (p.stats_out) {
 #pragma unroll
             for (int e = 0; e < EO; ++e) {
@@ -606,8 +637,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
             a1 += v[0];
             a2 += v[1];
           }
-          const int sp = (m0 - b_tile * HW) / BM;
-          *reinterpret_cast<f32x2*>(p.stats_out + (((size_t)b_tile * p.stats_S + sp) * p.Cout + n0 + c) * 2) = f32x2{a1, a2};
+          *reinterpret_cast<f32x2*>(p.stats_out + (((size_t)b_tile * p.stats_S + sp_tile) * p.Cout + n0 + c) * 2) = f32x2{a1, a2};
         }
       }
       return;
@@ -674,14 +704,14 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
         for (int i = etid; i < PROWS * QPR; i += NTC) {
           const int row = i / QPR, q = i - row * QPR;
           const f32x4 a = *reinterpret_cast<const f32x4*>(sC + row * SROW + 4 * q);
-          *reinterpret_cast<f32x4*>(p.ws + ((size_t)ks * p.M + m0 + ps * PROWS + row) * p.Cout + n0 + 4 * q) = a;
+          *reinterpret_cast<f32x4*>(p.ws + ((size_t)ks * p.M + gpix(ps * PROWS + row)) * p.Cout + n0 + 4 * q) = a;
         }
         continue;
       }
       if (active) {
 #pragma unroll 2
         for (int row = tr; row < PROWS; row += RPI) {
-          const int m = m0 + ps * PROWS + row;
+          const int m = gpix(ps * PROWS + row);
           float v[EO];
 #pragma unroll
           for (int q = 0; q < EO / 4; ++q) {
@@ -720,8 +750,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
           a1 += v[0];
           a2 += v[1];
         }
-        const int sp = (m0 - b_tile * HW) / BM;
-        *reinterpret_cast<f32x2*>(p.stats_out + (((size_t)b_tile * p.stats_S + sp) * p.Cout + n0 + c) * 2) = f32x2{a1, a2};
+        *reinterpret_cast<f32x2*>(p.stats_out + (((size_t)b_tile * p.stats_S + sp_tile) * p.Cout + n0 + c) * 2) = f32x2{a1, a2};
       }
     }
   }
@@ -730,6 +759,7 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
 // ----------------------------------------------------------------------------------------------- host side
 struct H3Variant {
   int bm, w, bn, wgm, wgn, mf, tps;
+  int sub;     // 1: a tile is a (bm / w) x w block of a LARGER plane (p.W % w == 0, p.H % (bm / w) == 0)
 };
 // ids kConv3hFirst + index
 static const H3Variant kH3[] = {
@@ -750,6 +780,7 @@ static const H3Variant kH3[] = {
     {128, 32, 96, 2, 2, 16, 3},    // 55: 32x32 planes, 4 rows x 96 couts (small batches)
     {0, 0, 0, 0, 0, 0, 0},         // 56: (implicit-GEMM variant, conv.hip)
     {256, 32, 192, 4, 2, 16, 1},   // 57: as 41 with a 2-deep weight ring (lookahead experiment)
+    {256, 32, 128, 4, 2, 16, 1, 1},   // 58: planes of 64^2 and up (AF-VAE): 8 x 32 pixel blocks x 128 couts, 8 + 4 waves
 };
 constexpr int kNumH3 = (int)(sizeof(kH3) / sizeof(kH3[0]));
 
@@ -771,14 +802,15 @@ bool conv3h_supported(int variant, int dtype_size, const ConvP& p) {
   const int HW = p.H * p.W;
   const int z = p.splitk > 0 ? p.splitk : 1;
   const bool tile_ok = HW % v.bm == 0 || (v.bm % HW == 0 && (z > 1 || dtype_size == 2));    // several samples per tile: as split-K slabs, or (bf16) through the per-sample epilogue
-  return p.KS == 3 && p.C2 == 0 && p.W == v.w && p.H == p.W && tile_ok && p.M % v.bm == 0 && p.Cout % v.bn == 0 &&
+  const bool plane_ok = v.sub ? (p.W > v.w && p.W % v.w == 0 && p.H % (v.bm / v.w) == 0 && z == 1) : (p.W == v.w && p.H == p.W && tile_ok);
+  return p.KS == 3 && p.C2 == 0 && plane_ok && p.M % v.bm == 0 && p.Cout % v.bn == 0 &&
          p.C1 % kstep == 0 && (p.C1 / kstep) % z == 0 && p.out_mode == 0 && !p.y2 && p.y_ld % eo == 0 &&
          (!p.residual || p.res_ld % eo == 0) && (!p.temb || (p.temb_stride % eo == 0 && p.temb_mod % eo == 0)) &&
          (long long)p.M * p.C1 * dtype_size < (1ll << 31) && (long long)p.Cout * 9 * p.C1 * dtype_size < (1ll << 31) &&
          p.Cout % 4 == 0 && aligned16(p.y) && aligned16(p.x1) && aligned16(p.w);
 }
 
-template <typename T, int BM, int W_, int BN, int WGM, int WGN, int MF, int TPS, int STAGES = 3>
+template <typename T, int BM, int W_, int BN, int WGM, int WGN, int MF, int TPS, int STAGES = 3, bool SUB = false>
 static void launch_h3(const ConvP& p0, hipStream_t st) {
   constexpr int NPROD = 4;
   constexpr int NWC = WGM * WGN;
@@ -805,7 +837,7 @@ static void launch_h3(const ConvP& p0, hipStream_t st) {
     if (s_gn >= 0) best = (s_gn == 0 || (tiles % 8 == 0 && p.tiles_n % s_gn == 0 && 8 % s_gn == 0 && tiles_m % (8 / s_gn) == 0)) ? s_gn : 0;
     p.xcd_gn = best;
   }
-  auto kern = k_conv3h<T, BM, W_, BN, WGM, WGN, NPROD, STAGES, MINW, MF, TPS>;
+  auto kern = k_conv3h<T, BM, W_, BN, WGM, WGN, NPROD, STAGES, MINW, MF, TPS, SUB>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -834,6 +866,7 @@ static void launch_h3_variant(int k, const ConvP& p, hipStream_t st) {
     case 14: launch_h3<T, 128, 32, 96, 2, 2, 16, 3>(p, st); break;
     case 15: break;                                                   // (id 56 is an implicit-GEMM variant, conv.hip)
     case 16: launch_h3<T, 256, 32, 192, 4, 2, 16, 1, 2>(p, st); break;  // 57: as 41 with a 2-deep weight ring (lookahead experiment)
+    case 17: launch_h3<T, 256, 32, 128, 4, 2, 16, 1, 3, true>(p, st); break;   // 58: sub-tiled large planes
   }
 }
 

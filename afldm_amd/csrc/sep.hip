@@ -40,7 +40,8 @@ struct SepCfg {
   static constexpr int M_ELEMS = RT * 16 * KPS;
   static constexpr int M2_ELEMS = R2 > 0 ? R2T * 16 * RPS : 0;
   static constexpr int TILE = 16 * KPS;
-  static constexpr int LDS_BYTES = (M_ELEMS + M2_ELEMS + 4 * TILE) * (int)sizeof(T);
+  static constexpr int OST = 32 * 16;                      // per wave: output staging, 32 rows x 16 lines
+  static constexpr int LDS_BYTES = (M_ELEMS + M2_ELEMS + 4 * TILE + 4 * OST) * (int)sizeof(T);
   static constexpr bool PERM = sizeof(T) == 2;
 };
 
@@ -58,7 +59,15 @@ __global__ void __launch_bounds__(256) k_sep(SepP p) {
   T* M2s = Ms + CF::M_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   T* tile = M2s + CF::M2_ELEMS + wave * CF::TILE;
+  T* sO = M2s + CF::M2_ELEMS + 4 * CF::TILE + wave * CF::OST;
   const int li = lane & 15, lg = lane >> 4;
+  // Output rows leave through a wave-private LDS tile: an MFMA result holds ONE line per lane (2 / 4 bytes per row),
+  // and storing it as such was 4 x 16 two-byte scattered stores per 16-row tile - the passes ran 5x off their HBM
+  // time on store issue (profiles/r03/r03a_vae_kernel_stats.csv: 2.1 ms for a 2 x 1.07 GB pass).  Two tiles (32 rows
+  // x 16 lines) are staged and leave as 16-byte pieces, a row's 16 lines (32 / 64 bytes) contiguous.
+  constexpr int LPR = 16 / EPC;                            // lanes per row of 16 lines
+  constexpr int RPI = 64 / LPR;                            // rows per store instruction
+  const int orow = lane / LPR, ocol = (lane % LPR) * EPC;
 
   // ---- matrices -> LDS (zero padded; M2 columns chain-permuted for bf16), once per workgroup
   for (int i = tid; i < CF::M_ELEMS; i += 256) {
@@ -92,63 +101,100 @@ __global__ void __launch_bounds__(256) k_sep(SepP p) {
   const long long ngroups = p.outer_count * groups_per_outer;
   const T* x = (const T*)p.x;
   T* y = (T*)p.y;
-  for (long long g0 = (long long)blockIdx.x * 4; g0 < ngroups; g0 += (long long)gridDim.x * 4) {
+  // Software pipeline over this wave's groups: the NEXT group's lines (and its GroupNorm table entries) are fetched into
+  // registers while the current group runs its MFMAs and stores.  The staging tile and the output tile are wave-private
+  // and a wave's LDS operations execute in order, so the loop needs no workgroup barrier: with the matrices filling the
+  // LDS there is ONE wave per SIMD, and the serial load -> barrier -> compute -> barrier chain left every pass at ~1 TB/s
+  // (HBM latency per group un-hidden; profiles/r03/r03b_vae_kernel_stats.csv).
+  constexpr int CQ = 16 / EPC, KQ = K / EPC, UNITS = CQ * KQ;
+  constexpr int UPL = (UNITS + 63) / 64;                   // staging units per lane
+  static_assert(K % EPC == 0 && 64 % CQ == 0, "staging units");
+  const int ucq = lane % CQ, ukq = lane / CQ;              // unit j of this lane: (ucq, ukq + j * 64 / CQ)
+  Chunk pre[UPL][EPC];
+  float psc = 1.f, psh = 0.f;
+  auto fetch = [&](long long grp) {
+    if (grp >= ngroups) return;
+    const long long outer = grp / groups_per_outer;
+    const long long inner0 = (grp - outer * groups_per_outer) * 16;
+    const T* src = x + outer * p.in_outer_stride + inner0;
+#pragma unroll
+    for (int j = 0; j < UPL; ++j) {
+      const int kq = ukq + j * (64 / CQ);
+      if (kq < KQ) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) pre[j][e] = ld16<Chunk>(src + (long long)(kq * EPC + e) * p.in_k_stride + ucq * EPC);
+      }
+    }
+    psc = 1.f;
+    psh = 0.f;
+    if (p.gn_table) {    // per-line GroupNorm scale / shift (line = inner0 + li; channel = line % C)
+      const int c = (int)((inner0 + li) % p.C);
+      const long long b = outer / p.outer_per_sample;
+      const f32x2 t = *reinterpret_cast<const f32x2*>(p.gn_table + ((size_t)b * p.C + c) * 2);
+      psc = t[0];
+      psh = t[1];
+    }
+  };
+  const long long gstep = (long long)gridDim.x * 4;
+  fetch((long long)blockIdx.x * 4 + wave);
+  for (long long g0 = (long long)blockIdx.x * 4; g0 < ngroups; g0 += gstep) {
     const long long grp = g0 + wave;
     const bool live = grp < ngroups;
     const long long outer = live ? grp / groups_per_outer : 0;
     const long long inner0 = live ? (grp - outer * groups_per_outer) * 16 : 0;
-    const T* src = x + outer * p.in_outer_stride + inner0;
-    // per-line GroupNorm scale / shift (line = inner0 + li; channel = line % C)
-    float sc = 1.f, sh = 0.f;
-    if (p.gn_table) {
-      const int c = (int)((inner0 + li) % p.C);
-      const long long b = outer / p.outer_per_sample;
-      const f32x2 t = *reinterpret_cast<const f32x2*>(p.gn_table + ((size_t)b * p.C + c) * 2);
-      sc = t[0];
-      sh = t[1];
-    }
-    constexpr int CQ = 16 / EPC, KQ = K / EPC, UNITS = CQ * KQ;
-    static_assert(K % EPC == 0, "K must be a whole number of chunks");
-    float usc[EPC], ush[EPC];
-#pragma unroll
-    for (int cc = 0; cc < EPC; ++cc) {
-      usc[cc] = __shfl(sc, (lane % CQ) * EPC + cc, 64);
-      ush[cc] = __shfl(sh, (lane % CQ) * EPC + cc, 64);
-    }
-    __syncthreads();   // the previous group's fragment reads of `tile` are complete
     if (live) {
-      for (int u = lane; u < UNITS; u += 64) {
-        const int cq = u % CQ, kq = u / CQ;
-        Chunk ch[EPC];
+      float usc[EPC], ush[EPC];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) ch[e] = ld16<Chunk>(src + (long long)(kq * EPC + e) * p.in_k_stride + cq * EPC);
+      for (int cc = 0; cc < EPC; ++cc) {
+        usc[cc] = __shfl(psc, ucq * EPC + cc, 64);
+        ush[cc] = __shfl(psh, ucq * EPC + cc, 64);
+      }
 #pragma unroll
-        for (int cc = 0; cc < EPC; ++cc) {
-          Chunk o;
+      for (int j = 0; j < UPL; ++j) {
+        const int kq = ukq + j * (64 / CQ);
+        if (kq < KQ) {
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) o[e] = from_f32<T>(to_f32(ch[e][cc]) * usc[cc] + ush[cc]);
-          st16<Chunk>(tile + (cq * EPC + cc) * KPS + kq * EPC, o);
+          for (int cc = 0; cc < EPC; ++cc) {
+            Chunk o;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o[e] = from_f32<T>(to_f32(pre[j][e][cc]) * usc[cc] + ush[cc]);
+            st16<Chunk>(tile + (ucq * EPC + cc) * KPS + kq * EPC, o);
+          }
         }
       }
     }
-    __syncthreads();
+    fetch(grp + gstep);          // in flight during this group's products and stores
 
     Chunk xf[NKF1];
 #pragma unroll
     for (int kf = 0; kf < NKF1; ++kf) xf[kf] = ld16<Chunk>(tile + li * KPS + kf * KPF + lg * EPC);
-    T* dst = y + outer * p.out_outer_stride + inner0 + li;
+    T* dst = y + outer * p.out_outer_stride + inner0;
+    // tile t of the result -> staging slot t & 1; every second tile (and the last) the staged rows are stored
+    auto put = [&](int t, const f32x4& v) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sO[((t & 1) * 16 + 4 * lg + r) * 16 + li] = from_f32<T>(v[r]);
+    };
+    auto flush = [&](int t, int nt, int rows_total) {      // after tile t of nt
+      if (!((t & 1) || t == nt - 1)) return;
+      const int row0 = 16 * (t & ~1), nrows = 16 * ((t & 1) + 1);
+#pragma unroll
+      for (int i = 0; i < 32 / RPI; ++i) {
+        const int rr = i * RPI + orow;
+        if (live && rr < nrows && row0 + rr < rows_total)
+          st16<Chunk>(dst + (long long)(row0 + rr) * p.out_k_stride + ocol, ld16<Chunk>(sO + rr * 16 + ocol));
+      }
+    };
     if constexpr (R2 == 0) {
       for (int t = 0; t < RT; ++t) {
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kf = 0; kf < NKF1; ++kf) MM::mma(z, ld16<Chunk>(Ms + (16 * t + li) * KPS + kf * KPF + lg * EPC), xf[kf]);
-        if (live) {
+        if (p.act) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 16 * t + 4 * lg + r;
-            if (row < R) dst[(long long)row * p.out_k_stride] = from_f32<T>(p.act ? silu_f(z[r]) : z[r]);
-          }
+          for (int r = 0; r < 4; ++r) z[r] = silu_f(z[r]);
         }
+        put(t, z);
+        flush(t, RT, R);
       }
     } else {
       f32x4 z[RT];
@@ -178,13 +224,8 @@ __global__ void __launch_bounds__(256) k_sep(SepP p) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int f = 0; f < NKF2; ++f) MM::mma(v, ld16<Chunk>(M2s + (16 * t + li) * RPS + f * KPF + lg * EPC), pb[f]);
-        if (live) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 16 * t + 4 * lg + r;
-            if (row < R2) dst[(long long)row * p.out_k_stride] = from_f32<T>(v[r]);
-          }
-        }
+        put(t, v);
+        flush(t, R2T, R2);
       }
     }
   }
@@ -282,6 +323,8 @@ extern "C" int afldm_sep_pass(const afldm_sep_args* a, afldm_stream_t stream) {
                 "afldm_sep_pass: inner_count=%lld must be a positive multiple of 16", (long long)a->inner_count);
   AFLDM_REQUIRE(a->in_k_stride % 8 == 0 && a->in_outer_stride % 8 == 0 && aligned16(a->x), AFLDM_EALIGN,
                 "afldm_sep_pass: input strides must keep 16-byte chunks aligned");
+  AFLDM_REQUIRE(a->out_k_stride % 8 == 0 && a->out_outer_stride % 8 == 0 && aligned16(a->y), AFLDM_EALIGN,
+                "afldm_sep_pass: output strides must keep 16-byte chunks aligned");
   AFLDM_REQUIRE(!a->gn_table || (a->C > 0 && a->outer_per_sample > 0), AFLDM_ESHAPE, "afldm_sep_pass: GN table needs C and outer_per_sample");
   AFLDM_REQUIRE(a->R2 == 0 || a->M2, AFLDM_ENULL, "afldm_sep_pass: R2 > 0 needs M2");
   SepP p;

@@ -212,7 +212,10 @@ int afldm_softmax_rows(const void* x, void* y, long long rows, int cols, float s
  * conv_in/conv_out, and nn.Linear (H = W = 1, B = rows) of Attention.to_q/k/v/to_out and the
  * time MLP.  x is the virtual concat of x1/x2.  out_mode 0: y NHWC with leading dim y_ld
  * (>= Cout, lets several GEMMs write column slices of one buffer); out_mode 1: channel-major
- * y[(b*Cout + n)*H*W + pix] (V^T for afldm_attention). */
+ * y[(b*Cout + n)*H*W + pix] (V^T for afldm_attention).
+ * A pixel operand of 2 GiB or more (AF-VAE 256^2 levels at batch 128) is processed as B / c launches over c whole
+ * samples each, c the largest divisor of B whose operand fits a buffer descriptor; afldm_conv2d_variant /
+ * _stats_splits / _workspace answer for such a chunk. */
 typedef struct {
   const void* x1;
   const void* x2;

@@ -475,6 +475,53 @@ def test_conv3x3_halo_patch_variants(dtype, case):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, temb, residual
+    (2, 64, 64, 128, 128, True, True),
+    (1, 72, 96, 64, 256, False, True),        # non-square plane, 9 x 3 blocks of 8 x 32 pixels
+    (3, 128, 128, 128, 128, False, False),
+])
+def test_conv3x3_halo_patch_on_blocks_of_large_planes(dtype, case):
+    """conv3h.hip variant 58 (round 3): the halo-patch kernel on 8 x 32 pixel blocks of planes larger than a tile (the
+    AF-VAE's 64^2 .. 256^2 levels) - zero padding only at the image border, neighbours' pixels elsewhere - against
+    F.conv2d, with residual / time embedding and the fused GroupNorm statistics (one record per block)."""
+    from afldm_amd import _lib
+    import ctypes
+    ops = _ops()
+    B, H, W, Cin, Cout, use_temb, use_res = case
+    g = torch.Generator().manual_seed(H + W + Cin)
+    x = rnd(dtype, torch.randn(B, Cin, H, W, generator=g))
+    w = rnd(dtype, torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5))
+    b = torch.randn(Cout, generator=g)
+    temb = rnd(dtype, torch.randn(B, Cout, generator=g)) if use_temb else None
+    res = rnd(dtype, torch.randn(B, Cout, H, W, generator=g)) if use_res else None
+    ref = F.conv2d(x, w, b, padding=1)
+    if use_temb:
+        ref = ref + temb[:, :, None, None]
+    if use_res:
+        ref = ref + res
+    xh, wp = nhwc(x, dtype), ops.pack_weight(w.cuda(), dtype)
+    th = temb.to(device="cuda", dtype=dtype) if use_temb else None
+    rh = nhwc(res, dtype) if use_res else None
+    try:
+        _lib.check(_lib.lib.afldm_conv2d_tune(58, -1), "tune")
+        ys = [ops.conv2d(xh, wp, b.cuda(), temb=th, temb_stride=Cout if use_temb else 0, residual=rh, want_stats=True)
+              for _ in range(2)]
+        probe = ops.conv_args(xh, wp, b.cuda(), temb=th, temb_stride=Cout if use_temb else 0, residual=rh, out=ys[0])
+        assert _lib.lib.afldm_conv2d_variant(ctypes.byref(probe)) & 255 == 58, "variant 58 did not take this shape"
+    finally:
+        _lib.lib.afldm_conv2d_tune(-1, -1)
+    assert ys[0].gn_partial.shape == (B, H * W // 256, Cout, 2)
+    close(back(ys[0]), ref, dtype, f"conv3h on blocks {case}", bf16_rms=6e-3)
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0].gn_partial, ys[1].gn_partial)
+    yv = ys[0].float()
+    got = ys[0].gn_partial.double().sum(1).cpu()
+    s1, s2 = yv.sum((1, 2)).cpu(), (yv * yv).sum((1, 2)).cpu()
+    assert (got[..., 0] - s1).abs().max() <= 1e-4 * (1 + s1.abs().max())
+    assert (got[..., 1] - s2).abs().max() <= 1e-4 * (1 + s2.abs().max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
     (2, 32, 32, 64, 0, 192, 3, True),      # H*W % 128 == 0, no split-K: statistics from the GEMM epilogue
     (2, 16, 16, 128, 64, 192, 3, True),    # virtual concat input, epilogue
     (3, 8, 8, 128, 0, 64, 3, False),       # 64x64 tiles: one tile per sample
