@@ -28,7 +28,7 @@ struct SepP {
   int C, outer_per_sample, act;
 };
 
-template <typename T, int K, int R, int R2>
+template <typename T, int K, int R, int R2, int NWV = 4>
 struct SepCfg {
   typedef Mma<T> MM;
   static constexpr int EPC = MM::EPC, KPF = MM::KPF;
@@ -41,13 +41,18 @@ struct SepCfg {
   static constexpr int M2_ELEMS = R2 > 0 ? R2T * 16 * RPS : 0;
   static constexpr int TILE = 16 * KPS;
   static constexpr int OST = 32 * 16;                      // per wave: output staging, 32 rows x 16 lines
-  static constexpr int LDS_BYTES = (M_ELEMS + M2_ELEMS + 4 * TILE + 4 * OST) * (int)sizeof(T);
+  static constexpr int LDS_BYTES = (M_ELEMS + M2_ELEMS + NWV * TILE + NWV * OST) * (int)sizeof(T);
   static constexpr bool PERM = sizeof(T) == 2;
 };
 
-template <typename T, int K, int R, int R2>
-__global__ void __launch_bounds__(256) k_sep(SepP p) {
-  typedef SepCfg<T, K, R, R2> CF;
+// NWV waves per workgroup share one LDS image of the matrices: the large-plane configurations (matrices of 67 - 137 KB)
+// hold one workgroup per CU, and with four waves that is ONE wave per SIMD whose load -> MFMA -> SiLU -> store chain
+// nothing overlaps (the passes ran at 1 - 1.5 TB/s); eight waves where the tiles still fit give every SIMD a second
+// wave to issue from.
+template <typename T, int K, int R, int R2, int NWV>
+__global__ void __launch_bounds__(NWV * 64) k_sep(SepP p) {
+  typedef SepCfg<T, K, R, R2, NWV> CF;
+  constexpr int NT = NWV * 64;
   typedef Mma<T> MM;
   typedef typename MM::Chunk Chunk;
   constexpr int EPC = CF::EPC, KPF = CF::KPF, KP = CF::KP, KPS = CF::KPS, RP = CF::RP, RPS = CF::RPS;
@@ -59,7 +64,7 @@ __global__ void __launch_bounds__(256) k_sep(SepP p) {
   T* M2s = Ms + CF::M_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   T* tile = M2s + CF::M2_ELEMS + wave * CF::TILE;
-  T* sO = M2s + CF::M2_ELEMS + 4 * CF::TILE + wave * CF::OST;
+  T* sO = M2s + CF::M2_ELEMS + NWV * CF::TILE + wave * CF::OST;
   const int li = lane & 15, lg = lane >> 4;
   // Output rows leave through a wave-private LDS tile: an MFMA result holds ONE line per lane (2 / 4 bytes per row),
   // and storing it as such was 4 x 16 two-byte scattered stores per 16-row tile - the passes ran 5x off their HBM
@@ -70,12 +75,12 @@ __global__ void __launch_bounds__(256) k_sep(SepP p) {
   const int orow = lane / LPR, ocol = (lane % LPR) * EPC;
 
   // ---- matrices -> LDS (zero padded; M2 columns chain-permuted for bf16), once per workgroup
-  for (int i = tid; i < CF::M_ELEMS; i += 256) {
+  for (int i = tid; i < CF::M_ELEMS; i += NT) {
     const int r = i / KPS, k = i - r * KPS;
     Ms[i] = from_f32<T>((r < R && k < K) ? p.M[(size_t)r * K + k] : 0.f);
   }
   if constexpr (R2 > 0) {
-    for (int i = tid; i < CF::M2_ELEMS; i += 256) {
+    for (int i = tid; i < CF::M2_ELEMS; i += NT) {
       const int r = i / RPS;
       int k = i - r * RPS;
       float v = 0.f;
@@ -135,9 +140,9 @@ __global__ void __launch_bounds__(256) k_sep(SepP p) {
       psh = t[1];
     }
   };
-  const long long gstep = (long long)gridDim.x * 4;
-  fetch((long long)blockIdx.x * 4 + wave);
-  for (long long g0 = (long long)blockIdx.x * 4; g0 < ngroups; g0 += gstep) {
+  const long long gstep = (long long)gridDim.x * NWV;
+  fetch((long long)blockIdx.x * NWV + wave);
+  for (long long g0 = (long long)blockIdx.x * NWV; g0 < ngroups; g0 += gstep) {
     const long long grp = g0 + wave;
     const bool live = grp < ngroups;
     const long long outer = live ? grp / groups_per_outer : 0;
@@ -279,21 +284,33 @@ __global__ void __launch_bounds__(256) k_softmax_rows(const T* __restrict__ x, T
   for (int i = threadIdx.x; i < cols; i += 256) yr[i] = from_f32<T>(__expf(to_f32(xr[i]) * scale - m) * inv);
 }
 
-template <typename T, int K, int R, int R2>
-static int launch_sep(const SepP& p, hipStream_t st) {
-  typedef SepCfg<T, K, R, R2> CF;
-  static_assert(CF::LDS_BYTES <= 160 * 1024, "LDS budget");
+template <typename T, int K, int R, int R2, int NWV>
+static int launch_sep_w(const SepP& p, int per_cu, hipStream_t st) {
+  typedef SepCfg<T, K, R, R2, NWV> CF;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_sep<T, K, R, R2>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)k_sep<T, K, R, R2, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
     attr_set = true;
   }
   const long long ngroups = p.outer_count * (p.inner_count / 16);
-  const int per_cu = (160 * 1024) / CF::LDS_BYTES >= 2 ? 2 : 1;
   long long grid = 256 * per_cu;
-  if (grid * 4 > ngroups) grid = (ngroups + 3) / 4;
-  k_sep<T, K, R, R2><<<(int)grid, 256, CF::LDS_BYTES, st>>>(p);
+  if (grid * NWV > ngroups) grid = (ngroups + NWV - 1) / NWV;
+  k_sep<T, K, R, R2, NWV><<<(int)grid, NWV * 64, CF::LDS_BYTES, st>>>(p);
   return check_launch("afldm_sep_pass");
+}
+
+template <typename T, int K, int R, int R2>
+static int launch_sep(const SepP& p, hipStream_t st) {
+  typedef SepCfg<T, K, R, R2, 4> C4;
+  typedef SepCfg<T, K, R, R2, 8> C8;
+  static_assert(C4::LDS_BYTES <= 160 * 1024, "LDS budget");
+  constexpr int LDS = 160 * 1024;
+  // waves per CU: as many 4-wave workgroups as fit (up to 4), or - when only one fits - one 8-wave workgroup if its
+  // eight tiles still fit next to the matrices
+  constexpr int n4 = LDS / C4::LDS_BYTES;
+  if constexpr (n4 >= 2) return launch_sep_w<T, K, R, R2, 4>(p, n4 > 4 ? 4 : n4, st);
+  else if constexpr (C8::LDS_BYTES <= LDS) return launch_sep_w<T, K, R, R2, 8>(p, 1, st);
+  else return launch_sep_w<T, K, R, R2, 4>(p, 1, st);
 }
 
 template <typename T>

@@ -510,7 +510,7 @@ def test_conv3x3_halo_patch_on_blocks_of_large_planes(dtype, case):
         assert _lib.lib.afldm_conv2d_variant(ctypes.byref(probe)) & 255 == 58, "variant 58 did not take this shape"
     finally:
         _lib.lib.afldm_conv2d_tune(-1, -1)
-    assert ys[0].gn_partial.shape == (B, H * W // 256, Cout, 2)
+    assert ys[0].gn_partial.shape == (B, min(H * W // 256, 32), Cout, 2)       # one record per block (ops folds past 32)
     close(back(ys[0]), ref, dtype, f"conv3h on blocks {case}", bf16_rms=6e-3)
     assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0].gn_partial, ys[1].gn_partial)
     yv = ys[0].float()
