@@ -26,17 +26,6 @@ def _pair(x):
     return x if isinstance(x, tuple) else (x, None)
 
 
-_SHORTCUT_BRANCH = os.environ.get("AFLDM_SHORTCUT_BRANCH", "1") != "0"
-_SIDE_STREAMS = {}
-
-
-def _side_stream(device):
-    key = str(device)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _SIDE_STREAMS[key]
-
-
 class PackedMixin:
     """Caches kernel-ready copies of parameters (OHWI weights in the activation dtype, fp32
     biases / affine params).  Invalidated by _apply (.to / .cuda / .half ...) and load_state_dict."""
@@ -360,17 +349,6 @@ class ResnetBlock2D(nn.Module):
         """next_gn: the GroupNorm module of an attention block that consumes this block's output next (the block loops
         pass it): lets conv2 hand its result over already normalised where that saves launches."""
         x1, x2 = _pair(input_tensor)
-        # conv_shortcut depends on the block input only: inside a graph capture it is issued on a side stream, i.e. as a
-        # parallel branch of the captured graph next to norm1 -> activation -> conv1 -> norm2 -> activation, and joined in
-        # front of conv2 (its 1x1 GEMM streams the - usually cold - concatenated skip input from HBM while the main branch
-        # sits on VALU / MFMA work).  AFLDM_SHORTCUT_BRANCH=0: issued in line.
-        res, side = None, None
-        if self.conv_shortcut is not None and _SHORTCUT_BRANCH and torch.cuda.is_current_stream_capturing():
-            main = torch.cuda.current_stream()
-            side = _side_stream(x1.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                res = conv_forward(self.conv_shortcut, input_tensor)
         h = self._norm_act(self.norm1, input_tensor)
         fused = self._conv1_norm2_act_fused(h, temb_proj, temb_stride)
         if fused is not None:
@@ -379,9 +357,7 @@ class ResnetBlock2D(nn.Module):
             # (the convs whose outputs feed a GroupNorm emit its statistics from their epilogue)
             h = conv_forward(self.conv1, h, temb=temb_proj, temb_stride=temb_stride, want_stats=True)
             h = self._norm_act(self.norm2, h)
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
-        elif self.conv_shortcut is not None:
+        if self.conv_shortcut is not None:
             res = conv_forward(self.conv_shortcut, input_tensor)
         else:
             assert x2 is None
