@@ -35,7 +35,7 @@ class SepArgs(Structure):
         ("in_outer_stride", ctypes.c_longlong), ("in_k_stride", ctypes.c_longlong),
         ("out_outer_stride", ctypes.c_longlong), ("out_k_stride", ctypes.c_longlong),
         ("K", c_int), ("R", c_int), ("R2", c_int), ("C", c_int), ("outer_per_sample", c_int),
-        ("act", c_int), ("dtype", c_int),
+        ("act", c_int), ("dtype", c_int), ("up_identity", c_int),
     ]
 
 

@@ -28,7 +28,12 @@ struct SepP {
   int C, outer_per_sample, act;
 };
 
-template <typename T, int K, int R, int R2, int NWV = 4>
+// UID ("up identity", chained passes only): the caller guarantees M[2i][k] = delta(i, k) - the x2 periodic-sinc
+// upsampler of the reference, U[::2, :] = I (ideal_lpf.py:96-121: the even phase of the
+// zero-stuffed, recon-filtered signal is the signal itself).  Then  M2 silu(M x) = M2[:, 0::2] silu(x) + M2[:, 1::2]
+// silu(M[1::2] x):  the even rows need no product, the first matrix shrinks to its K odd rows (69 -> 35 KB at K = 128),
+// all three matrices are K wide and EIGHT waves fit next to them (104 + 43 KB) where four were alone with 137 KB.
+template <typename T, int K, int R, int R2, int NWV = 4, bool UID = false>
 struct SepCfg {
   typedef Mma<T> MM;
   static constexpr int EPC = MM::EPC, KPF = MM::KPF;
@@ -37,8 +42,9 @@ struct SepCfg {
   static constexpr int RP = ((R + KPF - 1) / KPF) * KPF;   // K extent of the chained product
   static constexpr int RPS = RP + EPC;
   static constexpr int RT = (R + 15) / 16, R2T = (R2 + 15) / 16;
-  static constexpr int M_ELEMS = RT * 16 * KPS;
-  static constexpr int M2_ELEMS = R2 > 0 ? R2T * 16 * RPS : 0;
+  static constexpr int M_ELEMS = UID ? K * KPS : RT * 16 * KPS;              // UID: the K odd rows of M
+  static constexpr int M2_ELEMS = R2 > 0 ? (UID ? 2 * R2T * 16 * KPS : R2T * 16 * RPS) : 0;   // UID: even | odd columns of M2
+  static_assert(!UID || (R2 > 0 && R == 2 * K && K % KPF == 0), "identity form: chained x2 passes with whole K steps");
   static constexpr int TILE = 16 * KPS;
   static constexpr int OST = 32 * 16;                      // per wave: output staging, 32 rows x 16 lines
   static constexpr int LDS_BYTES = (M_ELEMS + M2_ELEMS + NWV * TILE + NWV * OST) * (int)sizeof(T);
@@ -49,15 +55,16 @@ struct SepCfg {
 // hold one workgroup per CU, and with four waves that is ONE wave per SIMD whose load -> MFMA -> SiLU -> store chain
 // nothing overlaps (the passes ran at 1 - 1.5 TB/s); eight waves where the tiles still fit give every SIMD a second
 // wave to issue from.
-template <typename T, int K, int R, int R2, int NWV>
+template <typename T, int K, int R, int R2, int NWV, bool UID = false>
 __global__ void __launch_bounds__(NWV * 64) k_sep(SepP p) {
-  typedef SepCfg<T, K, R, R2, NWV> CF;
+  typedef SepCfg<T, K, R, R2, NWV, UID> CF;
   constexpr int NT = NWV * 64;
   typedef Mma<T> MM;
   typedef typename MM::Chunk Chunk;
   constexpr int EPC = CF::EPC, KPF = CF::KPF, KP = CF::KP, KPS = CF::KPS, RP = CF::RP, RPS = CF::RPS;
   constexpr int RT = CF::RT, R2T = CF::R2T, NKF1 = KP / KPF, NKF2 = R2 > 0 ? RP / KPF : 1;
   static_assert(R2 == 0 || (RT % 2 == 0 || !CF::PERM), "chained bf16 product packs row tiles in pairs");
+  static_assert(!UID || ((K / 16) % 2 == 0 || !CF::PERM), "identity form: odd-row tiles pack in pairs");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* Ms = reinterpret_cast<T*>(smem);
@@ -75,11 +82,33 @@ __global__ void __launch_bounds__(NWV * 64) k_sep(SepP p) {
   const int orow = lane / LPR, ocol = (lane % LPR) * EPC;
 
   // ---- matrices -> LDS (zero padded; M2 columns chain-permuted for bf16), once per workgroup
+  if constexpr (UID) {
+    for (int i = tid; i < CF::M_ELEMS; i += NT) {            // odd rows of M
+      const int r = i / KPS, k = i - r * KPS;
+      Ms[i] = from_f32<T>(k < K ? p.M[(size_t)(2 * r + 1) * K + k] : 0.f);
+    }
+    constexpr int HALF = R2T * 16 * KPS;
+    for (int i = tid; i < 2 * HALF; i += NT) {               // [even columns, standard order | odd columns, chain order]
+      const int odd = i >= HALF, j = i - odd * HALF;
+      const int r = j / KPS;
+      int k = j - r * KPS;
+      float v = 0.f;
+      if (k < K) {
+        if (odd && CF::PERM) {
+          const int f = k >> 5, g = (k >> 3) & 3, e = k & 7;
+          k = 32 * f + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4));
+        }
+        if (r < R2) v = p.M2[(size_t)r * R + 2 * k + odd];
+      }
+      M2s[i] = from_f32<T>(v);
+    }
+  } else {
   for (int i = tid; i < CF::M_ELEMS; i += NT) {
     const int r = i / KPS, k = i - r * KPS;
     Ms[i] = from_f32<T>((r < R && k < K) ? p.M[(size_t)r * K + k] : 0.f);
   }
-  if constexpr (R2 > 0) {
+  }
+  if constexpr (R2 > 0 && !UID) {
     for (int i = tid; i < CF::M2_ELEMS; i += NT) {
       const int r = i / RPS;
       int k = i - r * RPS;
@@ -201,6 +230,46 @@ __global__ void __launch_bounds__(NWV * 64) k_sep(SepP p) {
         put(t, z);
         flush(t, RT, R);
       }
+    } else if constexpr (UID) {
+      constexpr int KT = K / 16, NKFO = K / KPF, HALF = R2T * 16 * KPS;
+      f32x4 z[KT];                                           // odd rows of the up-sampled line, SiLU applied
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kf = 0; kf < NKF1; ++kf) MM::mma(z[t], ld16<Chunk>(Ms + (16 * t + li) * KPS + kf * KPF + lg * EPC), xf[kf]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[t][r] = silu_f(z[t][r]);
+      }
+      Chunk pbo[NKFO];
+      if constexpr (CF::PERM) {
+#pragma unroll
+        for (int f = 0; f < NKFO; ++f) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pbo[f][r] = (bf16)z[2 * f][r];
+            pbo[f][4 + r] = (bf16)z[2 * f + 1][r];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int f = 0; f < NKFO; ++f) pbo[f] = z[f];
+      }
+      Chunk xs[NKF1];                                        // even rows = the line itself: SiLU in place, standard K order
+#pragma unroll
+      for (int kf = 0; kf < NKF1; ++kf) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) xs[kf][e] = from_f32<T>(silu_f(to_f32(xf[kf][e])));
+      }
+      for (int t = 0; t < R2T; ++t) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kf = 0; kf < NKF1; ++kf) MM::mma(v, ld16<Chunk>(M2s + (16 * t + li) * KPS + kf * KPF + lg * EPC), xs[kf]);
+#pragma unroll
+        for (int f = 0; f < NKFO; ++f) MM::mma(v, ld16<Chunk>(M2s + HALF + (16 * t + li) * KPS + f * KPF + lg * EPC), pbo[f]);
+        put(t, v);
+        flush(t, R2T, R2);
+      }
     } else {
       f32x4 z[RT];
 #pragma unroll
@@ -284,37 +353,44 @@ __global__ void __launch_bounds__(256) k_softmax_rows(const T* __restrict__ x, T
   for (int i = threadIdx.x; i < cols; i += 256) yr[i] = from_f32<T>(__expf(to_f32(xr[i]) * scale - m) * inv);
 }
 
-template <typename T, int K, int R, int R2, int NWV>
+template <typename T, int K, int R, int R2, int NWV, bool UID = false>
 static int launch_sep_w(const SepP& p, int per_cu, hipStream_t st) {
-  typedef SepCfg<T, K, R, R2, NWV> CF;
+  typedef SepCfg<T, K, R, R2, NWV, UID> CF;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_sep<T, K, R, R2, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)k_sep<T, K, R, R2, NWV, UID>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
     attr_set = true;
   }
   const long long ngroups = p.outer_count * (p.inner_count / 16);
   long long grid = 256 * per_cu;
   if (grid * NWV > ngroups) grid = (ngroups + NWV - 1) / NWV;
-  k_sep<T, K, R, R2, NWV><<<(int)grid, NWV * 64, CF::LDS_BYTES, st>>>(p);
+  k_sep<T, K, R, R2, NWV, UID><<<(int)grid, NWV * 64, CF::LDS_BYTES, st>>>(p);
   return check_launch("afldm_sep_pass");
 }
 
-template <typename T, int K, int R, int R2>
+template <typename T, int K, int R, int R2, bool UID = false>
 static int launch_sep(const SepP& p, hipStream_t st) {
-  typedef SepCfg<T, K, R, R2, 4> C4;
-  typedef SepCfg<T, K, R, R2, 8> C8;
+  typedef SepCfg<T, K, R, R2, 4, UID> C4;
+  typedef SepCfg<T, K, R, R2, 8, UID> C8;
   static_assert(C4::LDS_BYTES <= 160 * 1024, "LDS budget");
   constexpr int LDS = 160 * 1024;
   // waves per CU: as many 4-wave workgroups as fit (up to 4), or - when only one fits - one 8-wave workgroup if its
   // eight tiles still fit next to the matrices
   constexpr int n4 = LDS / C4::LDS_BYTES;
-  if constexpr (n4 >= 2) return launch_sep_w<T, K, R, R2, 4>(p, n4 > 4 ? 4 : n4, st);
-  else if constexpr (C8::LDS_BYTES <= LDS) return launch_sep_w<T, K, R, R2, 8>(p, 1, st);
-  else return launch_sep_w<T, K, R, R2, 4>(p, 1, st);
+  if constexpr (n4 >= 2) return launch_sep_w<T, K, R, R2, 4, UID>(p, n4 > 4 ? 4 : n4, st);
+  else if constexpr (C8::LDS_BYTES <= LDS) return launch_sep_w<T, K, R, R2, 8, UID>(p, 1, st);
+  else return launch_sep_w<T, K, R, R2, 4, UID>(p, 1, st);
 }
 
 template <typename T>
-static int sep_dispatch(const SepP& p, int K, int R, int R2, hipStream_t st) {
+static int sep_dispatch(const SepP& p, int K, int R, int R2, int up_identity, hipStream_t st) {
+  if (up_identity) {      // (see SepCfg: chained x2 passes whose first matrix has identity even rows)
+    if (K == 32 && R == 64 && R2 == 32) return launch_sep<T, 32, 64, 32, true>(p, st);
+    if (K == 64 && R == 128 && R2 == 64) return launch_sep<T, 64, 128, 64, true>(p, st);
+    if constexpr (sizeof(T) == 2) {
+      if (K == 128 && R == 256 && R2 == 128) return launch_sep<T, 128, 256, 128, true>(p, st);
+    }
+  }
 #define AFLDM_SEP(K_, R_, R2_) \
   if (K == K_ && R == R_ && R2 == R2_) return launch_sep<T, K_, R_, R2_>(p, st);
   // x2 upsampling passes (K = N, R = 2N), decimating passes (K = N, R = N/2) and the 2N -> N
@@ -351,8 +427,8 @@ extern "C" int afldm_sep_pass(const afldm_sep_args* a, afldm_stream_t stream) {
   p.out_outer_stride = a->out_outer_stride; p.out_k_stride = a->out_k_stride;
   p.C = a->C; p.outer_per_sample = a->outer_per_sample; p.act = a->act;
   hipStream_t st = (hipStream_t)stream;
-  if (a->dtype == AFLDM_F32) return sep_dispatch<float>(p, a->K, a->R, a->R2, st);
-  if (a->dtype == AFLDM_BF16) return sep_dispatch<bf16>(p, a->K, a->R, a->R2, st);
+  if (a->dtype == AFLDM_F32) return sep_dispatch<float>(p, a->K, a->R, a->R2, a->up_identity, st);
+  if (a->dtype == AFLDM_BF16) return sep_dispatch<bf16>(p, a->K, a->R, a->R2, a->up_identity, st);
   set_error("afldm_sep_pass: unknown dtype %d", a->dtype);
   return AFLDM_EDTYPE;
 }

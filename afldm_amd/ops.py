@@ -416,8 +416,9 @@ def af_lpf_down2(x, out=None, workspace=None, want_stats=False):
 
 # ----------------------------------------------------------------------------- large planes (AF-VAE)
 def sep_pass(x, y, M, K, R, outer_count, inner_count, in_outer_stride, in_k_stride, out_outer_stride, out_k_stride,
-             M2=None, R2=0, gn_table=None, C=0, outer_per_sample=1, act=0):
-    """One separable pass (afldm_sep_pass): y[line][r] = act(M xn[line]) or M2 silu(M xn[line])."""
+             M2=None, R2=0, gn_table=None, C=0, outer_per_sample=1, act=0, up_identity=False):
+    """One separable pass (afldm_sep_pass): y[line][r] = act(M xn[line]) or M2 silu(M xn[line]).
+    up_identity: M is the x2 upsampler U, whose even rows are the identity (afldm_sep_args.up_identity)."""
     a = SepArgs()
     a.x, a.y, a.M, a.M2, a.gn_table = ptr(x), ptr(y), ptr(M), ptr(M2), ptr(gn_table)
     a.outer_count, a.inner_count = int(outer_count), int(inner_count)
@@ -425,6 +426,7 @@ def sep_pass(x, y, M, K, R, outer_count, inner_count, in_outer_stride, in_k_stri
     a.out_outer_stride, a.out_k_stride = int(out_outer_stride), int(out_k_stride)
     a.K, a.R, a.R2, a.C, a.outer_per_sample, a.act = int(K), int(R), int(R2), int(C), int(outer_per_sample), int(act)
     a.dtype = _code(x)
+    a.up_identity = 1 if up_identity else 0
     tok = _begin()
     check(lib.afldm_sep_pass(ctypes.byref(a), stream_ptr()), "sep_pass")
     lines = outer_count * inner_count
@@ -441,6 +443,9 @@ def gn_table(stats, gamma, beta, B, C, G, HW, eps):
     return out
 
 
+_UP_IDENTITY = os.environ.get("AFLDM_NO_UP_IDENTITY", "0") != "1"
+
+
 def _af_act_large(x, stats, gamma, beta, G, eps, out):
     """WarpedNonlinearity on planes too large for LDS (N >= 64): up-H, (up-W, SiLU, down-W) chained,
     down-H — three MFMA passes through HBM with intermediates in the activation dtype."""
@@ -451,7 +456,7 @@ def _af_act_large(x, stats, gamma, beta, G, eps, out):
     sep_pass(x, t1, U, N, 2 * N, B, N * C, N * N * C, N * C, 2 * N * N * C, N * C,
              gn_table=table, C=C, outer_per_sample=1)
     v = torch.empty((B, 2 * N, N, C), dtype=x.dtype, device=x.device)
-    sep_pass(t1, v, U, N, 2 * N, B * 2 * N, C, N * C, C, N * C, C, M2=D, R2=N)
+    sep_pass(t1, v, U, N, 2 * N, B * 2 * N, C, N * C, C, N * C, C, M2=D, R2=N, up_identity=_UP_IDENTITY)
     del t1
     sep_pass(v, out, D, 2 * N, N, B, N * C, 2 * N * N * C, N * C, N * N * C, N * C)
     return out

@@ -194,6 +194,10 @@ typedef struct {
   int C, outer_per_sample;
   int act;   /* 1: SiLU after M (only when R2 == 0) */
   int dtype;
+  /* 1 (chained passes, R == 2 K): the caller guarantees M[2 i][k] = delta(i, k) - true of the reference's x2
+   * periodic-sinc upsampler (ideal_lpf.py:96-121: the even phase of the zero-stuffed, recon-filtered signal is the
+   * signal itself).  The even rows then need no product: M2 silu(M x) = M2[:, 0::2] silu(x) + M2[:, 1::2] silu(M[1::2] x). */
+  int up_identity;
 } afldm_sep_args;
 int afldm_sep_pass(const afldm_sep_args* args, afldm_stream_t stream);
 /* table[b][c] = (rstd * gamma[c], beta[c] - mean * rstd * gamma[c]) from per-channel partial sums */

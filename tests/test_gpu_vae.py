@@ -55,6 +55,31 @@ def test_large_plane_activation_n128_bf16():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N", [32, 64, 128])
+def test_chained_pass_identity_form_matches_full_product(dtype, N):
+    """afldm_sep_pass, chained up -> SiLU -> down along one axis: the identity form (round 3: U[::2] = I, so only the odd
+    rows of U are multiplied and silu(x) itself feeds the even columns of D) against the full two-matrix product and
+    against fp64 on the same rounded inputs."""
+    from afldm_amd import ops
+    if dtype == torch.float32 and N > 64:
+        pytest.skip("the 128-wide matrices fit the LDS in bf16 only")
+    U, D = ops.filter_matrices(N, torch.device("cuda"))
+    assert torch.equal(U[::2], torch.eye(N, device="cuda"))        # the property the identity form relies on
+    g = torch.Generator().manual_seed(N)
+    lines, C = 24, 32
+    x = torch.randn(lines, N, C, generator=g).to(dtype).cuda()     # [outer, k, inner]: lines along k, C adjacent lines
+    outs = []
+    for ident in (False, True):
+        y = torch.empty(lines, N, C, dtype=dtype, device="cuda")
+        ops.sep_pass(x, y, U, N, 2 * N, lines, C, N * C, C, N * C, C, M2=D, R2=N, up_identity=ident)
+        outs.append(y.float().cpu())
+    ref = torch.einsum("rk,okc->orc", D.double().cpu(), F.silu(torch.einsum("rk,okc->orc", U.double().cpu(), x.double().cpu())))
+    tol = 2e-5 if dtype == torch.float32 else 1.2e-2
+    assert rel_rms(outs[0], ref.float()) <= tol and rel_rms(outs[1], ref.float()) <= tol
+    assert rel_rms(outs[1], outs[0]) <= (1e-6 if dtype == torch.float32 else 8e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("N", [32, 64, 128, 256])
 def test_large_plane_resample(dtype, N):
     from afldm_amd import ops
