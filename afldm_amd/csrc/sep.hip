@@ -376,17 +376,23 @@ static int launch_sep(const SepP& p, hipStream_t st) {
   constexpr int LDS = 160 * 1024;
   // waves per CU: as many 4-wave workgroups as fit (up to 4), or - when only one fits - one 8-wave workgroup if its
   // eight tiles still fit next to the matrices
+  // Measured (profiles/r03/vae_sep_ab.txt): two 4-wave workgroups per CU is the sweet spot of the plain passes - three or
+  // four per CU and an 8-wave workgroup for the 67 - 69 KB matrices all measured 5 - 40 % SLOWER (the passes sit at ~2.5 TB/s
+  // of 32-byte row pieces; more waves only add contention); the 8-wave workgroup pays for the identity-form chained pass,
+  // which is compute-bound (MFMA + SiLU per wave in series): 2.03 -> 1.25 ms at K = 128.
   constexpr int n4 = LDS / C4::LDS_BYTES;
-  if constexpr (n4 >= 2) return launch_sep_w<T, K, R, R2, 4, UID>(p, n4 > 4 ? 4 : n4, st);
-  else if constexpr (C8::LDS_BYTES <= LDS) return launch_sep_w<T, K, R, R2, 8, UID>(p, 1, st);
-  else return launch_sep_w<T, K, R, R2, 4, UID>(p, 1, st);
+  if constexpr (UID && n4 < 2 && C8::LDS_BYTES <= LDS) return launch_sep_w<T, K, R, R2, 8, UID>(p, 1, st);
+  else return launch_sep_w<T, K, R, R2, 4, UID>(p, n4 >= 2 ? 2 : 1, st);
 }
 
 template <typename T>
 static int sep_dispatch(const SepP& p, int K, int R, int R2, int up_identity, hipStream_t st) {
   if (up_identity) {      // (see SepCfg: chained x2 passes whose first matrix has identity even rows)
-    if (K == 32 && R == 64 && R2 == 32) return launch_sep<T, 32, 64, 32, true>(p, st);
-    if (K == 64 && R == 128 && R2 == 64) return launch_sep<T, 64, 128, 64, true>(p, st);
+    // K = 128 is where it pays (the matrices drop under the 8-wave budget); at K = 64 the full product measured faster
+    // (35.0 vs 41.7 ms over the C4 workload: the SiLU of the line itself costs more VALU than the MFMAs it saves) - the
+    // small forms stay selectable for the tests (up_identity = 2)
+    if (up_identity == 2 && K == 32 && R == 64 && R2 == 32) return launch_sep<T, 32, 64, 32, true>(p, st);
+    if (up_identity == 2 && K == 64 && R == 128 && R2 == 64) return launch_sep<T, 64, 128, 64, true>(p, st);
     if constexpr (sizeof(T) == 2) {
       if (K == 128 && R == 256 && R2 == 128) return launch_sep<T, 128, 256, 128, true>(p, st);
     }

@@ -426,7 +426,7 @@ def sep_pass(x, y, M, K, R, outer_count, inner_count, in_outer_stride, in_k_stri
     a.out_outer_stride, a.out_k_stride = int(out_outer_stride), int(out_k_stride)
     a.K, a.R, a.R2, a.C, a.outer_per_sample, a.act = int(K), int(R), int(R2), int(C), int(outer_per_sample), int(act)
     a.dtype = _code(x)
-    a.up_identity = 1 if up_identity else 0
+    a.up_identity = int(up_identity)       # True / 1: where it pays; 2: every size that has the form (tests)
     tok = _begin()
     check(lib.afldm_sep_pass(ctypes.byref(a), stream_ptr()), "sep_pass")
     lines = outer_count * inner_count

@@ -196,7 +196,8 @@ typedef struct {
   int dtype;
   /* 1 (chained passes, R == 2 K): the caller guarantees M[2 i][k] = delta(i, k) - true of the reference's x2
    * periodic-sinc upsampler (ideal_lpf.py:96-121: the even phase of the zero-stuffed, recon-filtered signal is the
-   * signal itself).  The even rows then need no product: M2 silu(M x) = M2[:, 0::2] silu(x) + M2[:, 1::2] silu(M[1::2] x). */
+   * signal itself).  The even rows then need no product: M2 silu(M x) = M2[:, 0::2] silu(x) + M2[:, 1::2] silu(M[1::2] x).
+   * Used where it pays (K = 128, bf16); 2 = also at K = 32 / 64, where the full product is faster (tests). */
   int up_identity;
 } afldm_sep_args;
 int afldm_sep_pass(const afldm_sep_args* args, afldm_stream_t stream);

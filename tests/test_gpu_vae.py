@@ -64,12 +64,13 @@ def test_chained_pass_identity_form_matches_full_product(dtype, N):
     if dtype == torch.float32 and N > 64:
         pytest.skip("the 128-wide matrices fit the LDS in bf16 only")
     U, D = ops.filter_matrices(N, torch.device("cuda"))
-    assert torch.equal(U[::2], torch.eye(N, device="cuda"))        # the property the identity form relies on
+    dev = (U[::2] - torch.eye(N, device="cuda")).abs().max().item()
+    assert dev <= 2e-7, dev                                        # the property the identity form relies on
     g = torch.Generator().manual_seed(N)
     lines, C = 24, 32
     x = torch.randn(lines, N, C, generator=g).to(dtype).cuda()     # [outer, k, inner]: lines along k, C adjacent lines
     outs = []
-    for ident in (False, True):
+    for ident in (0, 2):
         y = torch.empty(lines, N, C, dtype=dtype, device="cuda")
         ops.sep_pass(x, y, U, N, 2 * N, lines, C, N * C, C, N * C, C, M2=D, R2=N, up_identity=ident)
         outs.append(y.float().cpu())
