@@ -80,7 +80,7 @@ struct PlaneCfg {
   // bf16: the constant fragments are copied to registers once, so their LDS image shares the Vt
   // region (N = 32, 8-channel items: 54 -> 38 KB, three workgroups per CU instead of two)
   static constexpr int CV = CREG ? (CONST_ELEMS > NW * VT ? CONST_ELEMS : NW * VT) : CONST_ELEMS + NW * VT;
-  static constexpr int LDS_BYTES = (XS + CV) * (int)sizeof(T) + 2 * 16 * (int)sizeof(float);
+  static constexpr int LDS_BYTES = (XS + CV) * (int)sizeof(T) + 6 * 16 * (int)sizeof(float);   // + scale / shift (2 items) + group scratch
   static_assert(N * YRP <= XS, "output staging tile must fit in the X region");
   static_assert(NW * 16 * 2 * 8 <= NW * VT * (int)sizeof(T), "GroupNorm reduction scratch aliases Vt");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -163,8 +163,9 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
   T* Xs = reinterpret_cast<T*>(smem);
   T* Cs = Xs + CF::XS;                                   // constants (aliased by Vt when they live in registers)
   T* Vt = CF::CREG ? Cs : Cs + CF::CONST_ELEMS;
-  float* gsc = reinterpret_cast<float*>(Cs + CF::CV);
-  float* gsh = gsc + 16;   // (16 slots, CH used)
+  float* gscb = reinterpret_cast<float*>(Cs + CF::CV);   // [2][16] per-channel GroupNorm scale of the current / next item (CH used)
+  float* gshb = gscb + 32;                               // [2][16] shift
+  float* gmsn = gshb + 32;                               // [16][2] (mean, rstd) of the NEXT item's groups
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -174,19 +175,18 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
   const int cpg = p.gs.st1 ? Ct / p.G : 1;
   T* Vw = Vt + wave * CF::VT;
 
-  // ---- once per (persistent) workgroup: constant fragments -> LDS (-> registers for bf16)
-  {
-    const Chunk* src = reinterpret_cast<const Chunk*>(p.packed);
-    Chunk* dst = reinterpret_cast<Chunk*>(Cs);
-    for (int i = tid; i < CF::CONST_ELEMS / EPC; i += NT) dst[i] = src[i];
-  }
-  __syncthreads();
+  // ---- once per (persistent) workgroup: constant fragments -> registers (bf16: straight from the packed image, one
+  // coalesced 1 KB read per fragment, no LDS round trip and no barrier) or -> LDS (fp32: 4x the registers)
   Chunk creg[CF::CREG ? CF::NFRAG : 1];
   if constexpr (CF::CREG) {
 #pragma unroll
-    for (int f = 0; f < CF::NFRAG; ++f) creg[f] = ld16<Chunk>(Cs + (f * 64 + lane) * EPC);
+    for (int f = 0; f < CF::NFRAG; ++f) creg[f] = ld16<Chunk>(reinterpret_cast<const T*>(p.packed) + (f * 64 + lane) * EPC);
+  } else {
+    const Chunk* src = reinterpret_cast<const Chunk*>(p.packed);
+    Chunk* dst = reinterpret_cast<Chunk*>(Cs);
+    for (int i = tid; i < CF::CONST_ELEMS / EPC; i += NT) dst[i] = src[i];
+    __syncthreads();
   }
-  if constexpr (CF::CREG) __syncthreads();   // every wave has its copy before Vt (same LDS bytes) is written
   auto cfrag = [&](int f) -> Chunk {
     if constexpr (CF::CREG) return creg[f];
     else return ld16<Chunk>(Cs + (f * 64 + lane) * EPC);
@@ -221,38 +221,120 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
   const int item_end = (wl + 1) * ipw < nitems ? (wl + 1) * ipw : nitems;
   int item = wl * ipw;
   if (item < item_end) fetch(item);
-  for (; item < item_end; ++item) {
-    const int b = item / ctiles;
-    const int c0 = (item - b * ctiles) * CH;
 
-    // ---- GroupNorm scale / shift of the 16 channels: the S partial sums are added by 16 x S lanes
+  // ---- GroupNorm scale / shift of an item's CH channels, buffered for two items (gscb / gshb[buf]).
+  // One wave per group touched by the item's channels (usually 2-4): the cpg x S per-channel partial sums strided over
+  // its lanes, folded with xor-shuffles, mean / rstd finished in fp64 by lane 0.  The FIRST item of a workgroup does this
+  // in line (two barriers); every later item is PIPELINED: its partial sums (and gamma / beta) are requested into
+  // registers before the current item's MFMA passes and folded after them, so the dependent load chain that used to
+  // open every item (~2 us with nothing else to issue: 3 items per workgroup at N = 16) now runs under the passes.
+  // Same loads, same order of additions: bit-identical statistics.
+  constexpr int SPL = 2;                                   // partial-sum loads a lane keeps in flight
+  const int smax = p.gs.S1 > p.gs.S2 ? p.gs.S1 : p.gs.S2;
+  auto stats_inline = [&](int it, int buf) {               // (contains workgroup barriers: every thread calls it)
+    const int b = it / ctiles, c0 = (it - b * ctiles) * CH;
     if (tid < CH) {
-      gsc[tid] = 1.f;
-      gsh[tid] = 0.f;
+      gscb[buf * 16 + tid] = 1.f;
+      gshb[buf * 16 + tid] = 0.f;
     }
     if (p.gs.st1) {
-      // one wave per group touched by the item's channels (usually 2-4): cpg x S partials strided
-      // over its lanes; the per-channel scale / shift follow from the group results in LDS
       const int g_first = c0 / cpg, g_last = (c0 + CH - 1) / cpg;
-      float* gms = reinterpret_cast<float*>(Vt);  // Vt is idle here (the previous item's planes are done)
       for (int g = g_first + wave; g <= g_last; g += CF::NW) {
         double s1, s2;
         gn_group_sums_wave(p.gs, b, g, cpg, lane, s1, s2);
         if (lane == 0) {
           float mean, rstd;
           gn_mean_rstd(s1, s2, (double)N * N * cpg, p.eps, mean, rstd);
-          gms[2 * (g - g_first)] = mean;
-          gms[2 * (g - g_first) + 1] = rstd;
+          gmsn[2 * (g - g_first)] = mean;
+          gmsn[2 * (g - g_first) + 1] = rstd;
         }
       }
       __syncthreads();
       if (tid < CH) {
         const int gl = (c0 + tid) / cpg - g_first;
-        const float sc = gms[2 * gl + 1] * p.gamma[c0 + tid];
-        gsc[tid] = sc;
-        gsh[tid] = p.beta[c0 + tid] - gms[2 * gl] * sc;
+        const float sc = gmsn[2 * gl + 1] * p.gamma[c0 + tid];
+        gscb[buf * 16 + tid] = sc;
+        gshb[buf * 16 + tid] = p.beta[c0 + tid] - gmsn[2 * gl] * sc;
       }
     }
+  };
+  // (N = 32 with 8-channel items sits at 166 VGPRs - 3 waves per SIMD - and the ~10 registers this state keeps live across
+  //  the passes would cost it the third wave: there every item takes the in-line path; 2 items per workgroup, 14 us each)
+  //  likewise N = 16 with 16-channel items: 126 -> 140 VGPRs would drop it from 4 to 3 waves per SIMD)
+  constexpr bool PIPE = !(N == 32 && CH == 8) && !(N == 16 && CH == 16);
+  f32x2 sreg[SPL];
+  float gmr = 1.f, btr = 0.f;
+  int n_c0 = 0, n_gfirst = 0, n_g = 0;
+  bool n_piped = false, n_mine = false;
+  auto stats_request = [&](int it) {                       // the next item's partial sums -> registers
+    const int b = it / ctiles;
+    n_c0 = (it - b * ctiles) * CH;
+    n_gfirst = n_c0 / cpg;
+    const int g_last = (n_c0 + CH - 1) / cpg;
+    n_piped = PIPE && p.gs.st1 != nullptr && g_last - n_gfirst + 1 <= CF::NW && cpg * smax <= 64 * SPL;     // (workgroup-uniform)
+    n_g = n_gfirst + wave;
+    n_mine = n_piped && n_g <= g_last;
+    if (n_mine) {
+#pragma unroll
+      for (int u = 0; u < SPL; ++u) {
+        const int j = lane + 64 * u;
+        sreg[u] = f32x2{0.f, 0.f};
+        if (j < cpg * smax) {
+          const int c = n_g * cpg + j / smax, sp = j - (j / smax) * smax;
+          const bool second = c >= p.gs.C1;
+          const int S = second ? p.gs.S2 : p.gs.S1;
+          if (sp < S) {
+            const float* st = second ? p.gs.st2 : p.gs.st1;
+            const int Cs = second ? p.gs.C2 : p.gs.C1, cc = second ? c - p.gs.C1 : c;
+            sreg[u] = *reinterpret_cast<const f32x2*>(st + (((size_t)b * S + sp) * Cs + cc) * 2);
+          }
+        }
+      }
+    }
+    if (n_piped && tid < CH) {
+      gmr = p.gamma[n_c0 + tid];
+      btr = p.beta[n_c0 + tid];
+    }
+  };
+  auto stats_fold = [&]() {                                // after the passes, in front of the barrier that follows them
+    if (!n_mine) return;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int u = 0; u < SPL; ++u) {
+      if (lane + 64 * u < cpg * smax) {                    // (exactly the terms, in the order, of gn_group_sums_wave)
+        s1 += (double)sreg[u][0];
+        s2 += (double)sreg[u][1];
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s1 += __shfl_xor(s1, o, 64);
+      s2 += __shfl_xor(s2, o, 64);
+    }
+    if (lane == 0) {
+      float mean, rstd;
+      gn_mean_rstd(s1, s2, (double)N * N * cpg, p.eps, mean, rstd);
+      gmsn[2 * (n_g - n_gfirst)] = mean;
+      gmsn[2 * (n_g - n_gfirst) + 1] = rstd;
+    }
+  };
+  auto stats_publish = [&](int buf) {                      // behind that barrier: per-channel scale / shift of the next item
+    if (n_piped && tid < CH) {
+      const int gl = (n_c0 + tid) / cpg - n_gfirst;
+      const float sc = gmsn[2 * gl + 1] * gmr;
+      gscb[buf * 16 + tid] = sc;
+      gshb[buf * 16 + tid] = btr - gmsn[2 * gl] * sc;
+    }
+  };
+
+  bool have_stats = false;                                 // the pipelined path already published this item's scale / shift
+  int ibuf = 0;
+  for (; item < item_end; ++item, ibuf ^= 1) {
+    const int b = item / ctiles;
+    const int c0 = (item - b * ctiles) * CH;
+    const float* gsc = gscb + ibuf * 16;
+    const float* gsh = gshb + ibuf * 16;
+    if (!have_stats) stats_inline(item, ibuf);
     __syncthreads();  // gsc/gsh ready; also: the previous item's output copy out of the X region is done
     if constexpr (KH > N) {  // the output staging of the previous item overwrote the X region: re-zero its K padding
       for (int i = tid; i < N * CH * (KH - N); i += NT) {
@@ -277,7 +359,12 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
       }
     }
     __syncthreads();
-    if (item + 1 < item_end) fetch(item + 1);  // in flight during the MFMA passes
+    have_stats = false;
+    n_piped = n_mine = false;
+    if (item + 1 < item_end) {                 // in flight during the MFMA passes
+      fetch(item + 1);
+      if constexpr (PIPE) stats_request(item + 1);
+    }
 
     // ---- this wave's CPW channel planes, each carried through P1..P4 without a workgroup barrier
     f32x4 yacc[CPW][TN][TN];
@@ -351,7 +438,12 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
           for (int kf = 0; kf < NKF3; ++kf) MM::mma(yacc[pl][t4][tw], cfrag(CF::F_DA + t4 * NKF3 + kf), vb[tw][kf]);
         }
     }
+    if constexpr (PIPE) stats_fold();
     __syncthreads();  // every wave has finished reading the X planes: the region becomes the output tile
+    if constexpr (PIPE) {
+      stats_publish(ibuf ^ 1);
+      have_stats = n_piped;
+    }
 
     // ---- output: stage the [N][N][16] tile through LDS -> coalesced 16-byte stores
     T* Ys = Xs;
