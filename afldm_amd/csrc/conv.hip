@@ -1600,6 +1600,8 @@ static const Variant kVariants[] = {
     {64, 32, 4, 12},   // 56  64x32 tiles, 12 stages (a skinny GEMM's K step costs DMA latency / ring depth): dense layers over <= 64 rows (the 2x2 level at batch 64) WITHOUT split-K
     {256, 192, 6, 2},  // 57  = 41 with a 2-deep weight ring (lookahead experiment)
     {256, 128, 6, 3},  // 58  halo-patch on planes of 64^2 and up (AF-VAE): 8 x 32 pixel blocks x 128 couts
+    {256, 128, 6, 3},  // 59  = 58 with 4 consumer waves (128 x 64 each)
+    {256, 128, 6, 3},  // 60  = 58 on 32x32x16 MFMAs
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -1706,8 +1708,10 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
     // planes of 64^2 and up (the AF-VAE): the halo-patch kernel on 8 x 32 pixel blocks of the plane (variant 58)
     static const bool off = getenv("AFLDM_NO_CONV3H_SUB") != nullptr;
     if (!off && a->KS == 3 && a->C2 == 0 && a->W >= 64 && a->W % 32 == 0 && a->H % 8 == 0 && a->Cout % 128 == 0 &&
-        Ct % (2 * elems_per_row) == 0 && M >= 256 * 192)
-      vid = 58;
+        Ct % (2 * elems_per_row) == 0 && M >= 256 * 192) {
+      static const int s_subv = getenv("AFLDM_CONV3H_SUBV") ? atoi(getenv("AFLDM_CONV3H_SUBV")) : 58;     // 58 / 59 / 60 (A/B)
+      vid = s_subv >= 58 && s_subv <= 60 ? s_subv : 58;
+    }
   }
   {
     // a dense layer over <= 64 rows (the 3x3 convolutions of the 2x2 level in their flattened form at batch 64) on 96+

@@ -781,6 +781,8 @@ static const H3Variant kH3[] = {
     {0, 0, 0, 0, 0, 0, 0},         // 56: (implicit-GEMM variant, conv.hip)
     {256, 32, 192, 4, 2, 16, 1},   // 57: as 41 with a 2-deep weight ring (lookahead experiment)
     {256, 32, 128, 4, 2, 16, 1, 1},   // 58: planes of 64^2 and up (AF-VAE): 8 x 32 pixel blocks x 128 couts, 8 + 4 waves
+    {256, 32, 128, 2, 2, 16, 1, 1},   // 59: as 58 with 4 consumer waves (128 x 64 each) + 4 producers
+    {256, 32, 128, 4, 2, 32, 1, 1},   // 60: as 58 on 32x32x16 MFMAs
 };
 constexpr int kNumH3 = (int)(sizeof(kH3) / sizeof(kH3[0]));
 
@@ -867,6 +869,8 @@ static void launch_h3_variant(int k, const ConvP& p, hipStream_t st) {
     case 15: break;                                                   // (id 56 is an implicit-GEMM variant, conv.hip)
     case 16: launch_h3<T, 256, 32, 192, 4, 2, 16, 1, 2>(p, st); break;  // 57: as 41 with a 2-deep weight ring (lookahead experiment)
     case 17: launch_h3<T, 256, 32, 128, 4, 2, 16, 1, 3, true>(p, st); break;   // 58: sub-tiled large planes
+    case 18: launch_h3<T, 256, 32, 128, 2, 2, 16, 1, 3, true>(p, st); break;   // 59
+    case 19: launch_h3<T, 256, 32, 128, 4, 2, 32, 1, 3, true>(p, st); break;   // 60
   }
 }
 

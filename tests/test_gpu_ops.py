@@ -473,6 +473,31 @@ def test_conv3x3_halo_patch_variants(dtype, case):
         _lib.lib.afldm_conv2d_tune(-1, -1)
 
 
+def test_conv2d_operand_beyond_2gib_runs_in_whole_sample_chunks():
+    """A pixel operand of 2 GiB or more (the AF-VAE's 256^2 levels at batch 128; here 34 x 256^2 x 512 channels bf16 =
+    2.28 GB) does not fit a buffer descriptor: afldm_conv2d issues it as launches over whole-sample chunks on the fast
+    kernels (round 3; it used to fall back to the round-1 register-staged kernel).  Every sample of the chunked call
+    must equal the same sample convolved on its own, bit for bit, statistics included."""
+    ops = _ops()
+    dt = torch.bfloat16
+    B, H, W, Cin, Cout = 34, 256, 256, 512, 128
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(B, H, W, Cin, generator=g, device="cuda", dtype=torch.float32).to(dt)
+    assert x.numel() * 2 >= 1 << 31
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g, device="cuda") / (3 * Cin ** 0.5)).to(dt)
+    b = torch.randn(Cout, generator=g, device="cuda")
+    temb = torch.randn(B, Cout, generator=g, device="cuda").to(dt)
+    y = ops.conv2d(x, w, b, temb=temb, temb_stride=Cout, want_stats=True)
+    assert torch.isfinite(y.float()).all()
+    for i in (0, 16, 17, 33):
+        yi = ops.conv2d(x[i:i + 1].contiguous(), w, b, temb=temb[i:i + 1].contiguous(), temb_stride=Cout, want_stats=True)
+        assert torch.equal(yi[0], y[i]), i
+        assert torch.equal(yi.gn_partial[0], y.gn_partial[i]), i
+    ref = F.conv2d(x[33:34, :64, :64].float().permute(0, 3, 1, 2).cpu(), w.float().permute(0, 3, 1, 2).cpu(), b.cpu(), padding=1)
+    ref = ref + temb[33].float().cpu()[None, :, None, None]
+    close(back(y[33:34, :60, :60]), ref[:, :, :60, :60], dt, "chunked conv vs F.conv2d (interior crop)", bf16_rms=6e-3)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [
     # B, H, W, Cin, Cout, temb, residual
