@@ -12,6 +12,8 @@ python tools/trace_breakdown.py $F 60 > gpurun_out/${TAG}_step_breakdown.txt 2>&
 python tools/trace_timeline.py $F > gpurun_out/${TAG}_step_timeline.txt 2>&1
 bash tools/prof_batches.sh $TAG > gpurun_out/batches_$TAG.log 2>&1
 bash profiles/run_pmc_step.sh $TAG > gpurun_out/pmc_step_$TAG.log 2>&1
+bash profiles/run_pmc_sq.sh $TAG > gpurun_out/pmc_sq_$TAG.log 2>&1
+bash profiles/run_vae_profile.sh $TAG > gpurun_out/prof_vae_$TAG.log 2>&1
 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
 python bench.py --workload vae --no-cpu-baseline > gpurun_out/bench_vae_$TAG.json 2> gpurun_out/bench_vae_$TAG.err
 tail -c 600 gpurun_out/pmc_$TAG.log; tail -c 300 gpurun_out/bench_$TAG.json
