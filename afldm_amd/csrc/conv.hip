@@ -1602,6 +1602,8 @@ static const Variant kVariants[] = {
     {256, 128, 6, 3},  // 58  halo-patch on planes of 64^2 and up (AF-VAE): 8 x 32 pixel blocks x 128 couts
     {256, 128, 6, 3},  // 59  = 58 with 4 consumer waves (128 x 64 each)
     {256, 128, 6, 3},  // 60  = 58 on 32x32x16 MFMAs
+    {128, 96, 6, 2},   // 61  halo-patch, 32x32 planes, 128 x 96 tiles sized for TWO workgroups per CU (4 + 2 waves, 2-deep ring)
+    {128, 96, 6, 2},   // 62  the same for 16x16 planes
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -1691,7 +1693,11 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
       // tile by plane size; the large tiles only while they still give every CU a workgroup
       const long long t256 = (M / 256) * (a->Cout / 192), t128 = (M / 128) * (a->Cout / 192);
       const bool bf = elems_per_row == 32;      // (64-byte row pieces: 32 bf16 / 16 fp32)
-      if (a->W == 32 && t256 >= 192) vid = 41;
+      static const int s_co = getenv("AFLDM_CONV3H_CO") ? atoi(getenv("AFLDM_CONV3H_CO")) : 0;      // bit 0: 32x32 planes, bit 1: 16x16 planes on the two-per-CU tiles (A/B)
+      const long long t96 = (M / 128) * (a->Cout / 96);
+      if (bf && (s_co & 1) && a->W == 32 && t96 >= 512 && a->Cout % 96 == 0) vid = 61;
+      else if (bf && (s_co & 2) && a->W == 16 && t96 >= 512 && a->Cout % 96 == 0) vid = 62;
+      else if (a->W == 32 && t256 >= 192) vid = 41;
       else if (a->W == 32 && t128 >= 192 && s_h3 >= 4 && bf) vid = 46;
       else if (a->W == 16 && t128 >= 192) vid = s_h3 == 2 ? 42 : 43;      // 4 consumer waves (64x96) measured best at 16x16
       else if (s_h3 >= 3 && a->W == 8 && M >= 2048 && a->Cout % 96 == 0) vid = 51;

@@ -783,6 +783,10 @@ static const H3Variant kH3[] = {
     {256, 32, 128, 4, 2, 16, 1, 1},   // 58: planes of 64^2 and up (AF-VAE): 8 x 32 pixel blocks x 128 couts, 8 + 4 waves
     {256, 32, 128, 2, 2, 16, 1, 1},   // 59: as 58 with 4 consumer waves (128 x 64 each) + 4 producers
     {256, 32, 128, 4, 2, 32, 1, 1},   // 60: as 58 on 32x32x16 MFMAs
+    // Two workgroups in flight per CU: 128 x 96 tiles, 4 consumer waves (64 x 48) + 2 producers, 2-deep
+    // weight ring: 72 - 78 KB of LDS and <= 168 VGPRs, so that one workgroup's prologue / epilogue runs under the other's K loop
+    {128, 32, 96, 2, 2, 16, 1},       // 61: 32x32 planes, 4 rows x 96 couts
+    {128, 16, 96, 2, 2, 16, 1},       // 62: 16x16 planes, 8 rows x 96 couts
 };
 constexpr int kNumH3 = (int)(sizeof(kH3) / sizeof(kH3[0]));
 
@@ -812,11 +816,10 @@ bool conv3h_supported(int variant, int dtype_size, const ConvP& p) {
          p.Cout % 4 == 0 && aligned16(p.y) && aligned16(p.x1) && aligned16(p.w);
 }
 
-template <typename T, int BM, int W_, int BN, int WGM, int WGN, int MF, int TPS, int STAGES = 3, bool SUB = false>
+template <typename T, int BM, int W_, int BN, int WGM, int WGN, int MF, int TPS, int STAGES = 3, bool SUB = false, int NPROD = 4, int MINW_ = 0>
 static void launch_h3(const ConvP& p0, hipStream_t st) {
-  constexpr int NPROD = 4;
   constexpr int NWC = WGM * WGN;
-  constexpr int MINW = (NWC + NPROD + 3) / 4;
+  constexpr int MINW = MINW_ > 0 ? MINW_ : (NWC + NPROD + 3) / 4;
   constexpr int ROWS = BM / W_, SEG = ROWS < W_ ? ROWS : W_, NSEG = ROWS / SEG;
   constexpr int NPI = (NSEG * (SEG + 2) * (W_ + 2) + 7) / 8;
   constexpr int lds = 2 * NPI * 1024 + STAGES * TPS * BN * 128;
@@ -871,6 +874,8 @@ static void launch_h3_variant(int k, const ConvP& p, hipStream_t st) {
     case 17: launch_h3<T, 256, 32, 128, 4, 2, 16, 1, 3, true>(p, st); break;   // 58: sub-tiled large planes
     case 18: launch_h3<T, 256, 32, 128, 2, 2, 16, 1, 3, true>(p, st); break;   // 59
     case 19: launch_h3<T, 256, 32, 128, 4, 2, 32, 1, 3, true>(p, st); break;   // 60
+    case 20: launch_h3<T, 128, 32, 96, 2, 2, 16, 1, 2, false, 2, 3>(p, st); break;   // 61: two workgroups per CU
+    case 21: launch_h3<T, 128, 16, 96, 2, 2, 16, 1, 2, false, 2, 3>(p, st); break;   // 62
   }
 }
 

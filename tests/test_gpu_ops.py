@@ -422,6 +422,8 @@ H3_CASES = [
     (4, 4, 256, 96, False, False, (52,)),
     (2, 16, 384, 96, True, True, (54,)),
     (2, 32, 192, 288, True, True, (55,)),
+    (3, 32, 192, 192, True, True, (61,)),          # 128 x 96 tiles sized for two workgroups per CU (round 3, A/B variants)
+    (5, 16, 384, 384, True, True, (62,)),
 ]
 
 
