@@ -48,25 +48,21 @@ def _get_filter_size(f):
 
 
 def setup_filter(f, device=torch.device("cpu"), normalize=True, flip_filter=False, gain=1, separable=None):
-    """Convenience function to set up a FIR filter for upfirdn2d() (reference :72-118)."""
-    if f is None:
-        f = 1
-    f = torch.as_tensor(f, dtype=torch.float32)
-    assert f.ndim in [0, 1, 2]
-    assert f.numel() > 0
-    if f.ndim == 0:
-        f = f[np.newaxis]
-    if separable is None:
-        separable = (f.ndim == 1 and f.numel() >= 8)
-    if f.ndim == 1 and not separable:
-        f = f.ger(f)
-    assert f.ndim == (1 if separable else 2)
+    """FIR taps for upfirdn2d() with the reference's conventions (upfirdn2d.py:72-118): a scalar or None is the 1-tap
+    identity; 1-D taps stay separable from 8 taps on (or when asked), otherwise they become the outer-product 2-D
+    filter; optional unit DC gain, optional flip, and `gain` spread evenly over the filter's axes."""
+    taps = torch.as_tensor(1 if f is None else f, dtype=torch.float32)
+    assert 0 <= taps.ndim <= 2 and taps.numel() > 0
+    taps = taps.reshape(1) if taps.ndim == 0 else taps
+    keep_1d = taps.ndim == 1 and (taps.numel() >= 8 if separable is None else bool(separable))
+    if taps.ndim == 1 and not keep_1d:
+        taps = torch.outer(taps, taps)
+    assert taps.ndim == (1 if (separable if separable is not None else keep_1d) else 2)
     if normalize:
-        f = f / f.sum()
+        taps = taps / taps.sum()
     if flip_filter:
-        f = f.flip(list(range(f.ndim)))
-    f = f * (gain ** (f.ndim / 2))
-    return f.to(device=device)
+        taps = taps.flip(tuple(range(taps.ndim)))
+    return (taps * gain ** (taps.ndim / 2)).to(device=device)
 
 
 def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl="cuda"):
@@ -101,28 +97,33 @@ def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl="cu
     return y if y.dtype == x.dtype else y.to(x.dtype)
 
 
+def _centred(x, f, up, down, padding, flip_filter, gain, impl, lead, trail):
+    """upfirdn2d with the filter's footprint absorbed into the padding: `lead(taps, u, d)` / `trail(taps, u, d)` give
+    the extra samples in front of / behind each axis - the three conventions of the reference's wrappers
+    (upfirdn2d.py:273-387) differ only there."""
+    upx, upy = _parse_scaling(up)
+    downx, downy = _parse_scaling(down)
+    px0, px1, py0, py1 = _parse_padding(padding)
+    fw, fh = _get_filter_size(f)
+    pad = [px0 + lead(fw, upx, downx), px1 + trail(fw, upx, downx), py0 + lead(fh, upy, downy), py1 + trail(fh, upy, downy)]
+    return upfirdn2d(x, f, up=up, down=down, padding=pad, flip_filter=flip_filter, gain=gain, impl=impl)
+
+
 def filter2d(x, f, padding=0, flip_filter=False, gain=1, impl="cuda"):
     """Filter a batch of 2D images; by default the result keeps the input shape (reference :273-309)."""
-    padx0, padx1, pady0, pady1 = _parse_padding(padding)
-    fw, fh = _get_filter_size(f)
-    p = [padx0 + fw // 2, padx1 + (fw - 1) // 2, pady0 + fh // 2, pady1 + (fh - 1) // 2]
-    return upfirdn2d(x, f, padding=p, flip_filter=flip_filter, gain=gain, impl=impl)
+    return _centred(x, f, 1, 1, padding, flip_filter, gain, impl,
+                    lambda n, u, d: n // 2, lambda n, u, d: (n - 1) // 2)
 
 
 def upsample2d(x, f, up=2, padding=0, flip_filter=False, gain=1, impl="cuda"):
-    """Upsample a batch of 2D images with the given filter (reference :313-347)."""
+    """Upsample a batch of 2D images with the given filter: output = input x up, gain compensated for the
+    zero-stuffing (reference :313-347)."""
     upx, upy = _parse_scaling(up)
-    padx0, padx1, pady0, pady1 = _parse_padding(padding)
-    fw, fh = _get_filter_size(f)
-    p = [padx0 + (fw + upx - 1) // 2, padx1 + (fw - upx) // 2, pady0 + (fh + upy - 1) // 2, pady1 + (fh - upy) // 2]
-    return upfirdn2d(x, f, up=up, padding=p, flip_filter=flip_filter, gain=gain * upx * upy, impl=impl)
+    return _centred(x, f, up, 1, padding, flip_filter, gain * upx * upy, impl,
+                    lambda n, u, d: (n + u - 1) // 2, lambda n, u, d: (n - u) // 2)
 
 
 def downsample2d(x, f, down=2, padding=0, flip_filter=False, gain=1, impl="cuda"):
-    """Downsample a batch of 2D images with the given filter (reference :351-387)."""
-    downx, downy = _parse_scaling(down)
-    padx0, padx1, pady0, pady1 = _parse_padding(padding)
-    fw, fh = _get_filter_size(f)
-    p = [padx0 + (fw - downx + 1) // 2, padx1 + (fw - downx) // 2, pady0 + (fh - downy + 1) // 2,
-         pady1 + (fh - downy) // 2]
-    return upfirdn2d(x, f, down=down, padding=p, flip_filter=flip_filter, gain=gain, impl=impl)
+    """Downsample a batch of 2D images with the given filter: output = input / down (reference :351-387)."""
+    return _centred(x, f, 1, down, padding, flip_filter, gain, impl,
+                    lambda n, u, d: (n - d + 1) // 2, lambda n, u, d: (n - d) // 2)

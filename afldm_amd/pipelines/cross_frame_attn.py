@@ -12,49 +12,45 @@ from ..models.blocks import AttnProcessor2_0, packed_norm
 
 
 class AttnState:
-    STORE = 0
-    LOAD = 1
-    IDLE = 2
+    """What the cross-frame processors of one UNet share (API of the reference's AttnState, cross_frame_attn.py:6-51):
+    the mode - STORE the attention inputs of this pass / LOAD the stored ones as K, V / IDLE - plus the timestep that keys
+    the stored maps, the slot a STORE pass writes (`store_id`, two slots for the interpolating processor) and the blend
+    weight `alpha` of a LOAD pass.  `state`, `timestep`, `store_id` and `alpha` are read-only views; they change through
+    the set_* / to_* methods only, exactly as in the reference."""
+    STORE, LOAD, IDLE = 0, 1, 2
+    _FIELDS = ("state", "timestep", "store_id", "alpha")
 
     def __init__(self):
+        self._v = {}
         self.reset()
 
-    @property
-    def state(self):
-        return self.__state
+    def reset(self):
+        self._v.update(state=self.STORE, timestep=0, store_id=0, alpha=0)
 
-    @property
-    def alpha(self):
-        return self.__alpha
+    def __getattr__(self, name):                      # only reached for names that are not real attributes
+        if name in AttnState._FIELDS:
+            return self.__dict__["_v"][name]
+        raise AttributeError(name)
 
-    @property
-    def store_id(self):
-        return self.__store_id
-
-    @property
-    def timestep(self):
-        return self.__timestep
+    def __setattr__(self, name, value):
+        if name in AttnState._FIELDS:
+            raise AttributeError(f"AttnState.{name} is read-only: use set_{name}() / to_load() / to_idle() / reset()")
+        object.__setattr__(self, name, value)
 
     def set_timestep(self, t):
-        self.__timestep = t.item() if isinstance(t, torch.Tensor) else t
+        self._v["timestep"] = t.item() if torch.is_tensor(t) else t
 
     def set_alpha(self, alpha):
-        self.__alpha = alpha
+        self._v["alpha"] = alpha
 
     def set_store_id(self, store_id):
-        self.__store_id = store_id
-
-    def reset(self):
-        self.__state = AttnState.STORE
-        self.__timestep = 0
-        self.__store_id = 0
-        self.__alpha = 0
+        self._v["store_id"] = store_id
 
     def to_load(self):
-        self.__state = AttnState.LOAD
+        self._v["state"] = self.LOAD
 
     def to_idle(self):
-        self.__state = AttnState.IDLE
+        self._v["state"] = self.IDLE
 
 
 class CrossFrameAttnProcessor(AttnProcessor2_0):

@@ -139,6 +139,33 @@ def test_af_act_fused_groupnorm_concat(dtype, N, C1, C2, G):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,C,S", [(16, 384, 2), (32, 192, 4), (16, 192, 1)])
+def test_af_act_plane_pipelined_statistics_match_the_inline_path(dtype, N, C, S):
+    """k_af_act_plane, round 3: a persistent workgroup requests the NEXT item's GroupNorm partial sums before the MFMA
+    passes of the current one and folds them afterwards (its first item still does it in line).  At batch 64 every
+    workgroup walks 2 - 3 items (pipelined path); the same samples run alone take the in-line path (one item per
+    workgroup): the two must agree bit for bit, and both with GroupNorm -> WarpedNonlinearity of the oracle."""
+    from oracle import ideal_filters as idf
+    ops = _ops()
+    g = torch.Generator().manual_seed(N + C)
+    B, G = 64, 32
+    x = rnd(dtype, torch.randn(B, C, N, N, generator=g) * 1.3 + 0.2)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).cuda()
+    beta = (0.1 * torch.randn(C, generator=g)).cuda()
+    xh = nhwc(x, dtype)
+    # partial sums in S row splits per sample, as a producing convolution's epilogue would leave them
+    rows = xh.float().view(B, S, N * N // S, C)
+    st = ops.GNStats(torch.stack([rows.sum(2), (rows * rows).sum(2)], -1).contiguous(), None)
+    y = ops.af_act(xh, None, st, gamma, beta, G, 1e-5)
+    for b0 in (0, 31, 62):
+        sub = ops.GNStats(st.st1[b0:b0 + 2].contiguous(), None)
+        y2 = ops.af_act(xh[b0:b0 + 2].contiguous(), None, sub, gamma, beta, G, 1e-5)
+        assert torch.equal(y2, y[b0:b0 + 2]), b0
+    ref = idf.warped_nonlinearity(F.group_norm(x[:3], G, gamma.cpu(), beta.cpu(), 1e-5))
+    close(back(y[:3]), ref, dtype, f"pipelined gn+af_act N={N}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("N,C", [(2, 64), (4, 96), (4, 128), (8, 64), (8, 384), (16, 64), (16, 384), (32, 192)])
 def test_af_resample(dtype, N, C):
     from oracle import ideal_filters as idf
