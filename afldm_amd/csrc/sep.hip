@@ -33,7 +33,10 @@ struct SepP {
 // zero-stuffed, recon-filtered signal is the signal itself).  Then  M2 silu(M x) = M2[:, 0::2] silu(x) + M2[:, 1::2]
 // silu(M[1::2] x):  the even rows need no product, the first matrix shrinks to its K odd rows (69 -> 35 KB at K = 128),
 // all three matrices are K wide and EIGHT waves fit next to them (104 + 43 KB) where four were alone with 137 KB.
-template <typename T, int K, int R, int R2, int NWV = 4, bool UID = false>
+// CT: 16-line column tiles per wave (plain passes only).  A wave owns 16 CT memory-adjacent lines: with CT = 4 (bf16) every
+// row of a group is ONE 128-byte piece for loads and stores - at CT = 1 the 32-byte pieces of the batch-128 H passes (1 + 2 GB,
+// beyond the MALL) reached 0.9 TB/s of HBM - and a matrix fragment read from LDS feeds CT MFMAs instead of one.
+template <typename T, int K, int R, int R2, int NWV = 4, bool UID = false, int CT = 1>
 struct SepCfg {
   typedef Mma<T> MM;
   static constexpr int EPC = MM::EPC, KPF = MM::KPF;
@@ -45,8 +48,11 @@ struct SepCfg {
   static constexpr int M_ELEMS = UID ? K * KPS : RT * 16 * KPS;              // UID: the K odd rows of M
   static constexpr int M2_ELEMS = R2 > 0 ? (UID ? 2 * R2T * 16 * KPS : R2T * 16 * RPS) : 0;   // UID: even | odd columns of M2
   static_assert(!UID || (R2 > 0 && R == 2 * K && K % KPF == 0), "identity form: chained x2 passes with whole K steps");
-  static constexpr int TILE = 16 * KPS;
-  static constexpr int OST = 32 * 16;                      // per wave: output staging, 32 rows x 16 lines
+  static constexpr int LPW = 16 * CT;                      // lines per wave (group)
+  static constexpr int TILE = LPW * KPS;
+  static constexpr int OST = 32 * LPW;                     // per wave: output staging, 32 rows x LPW lines
+  static_assert(CT == 1 || R2 == 0, "several column tiles per wave: plain passes only");
+  static_assert(LPW <= 64, "one GroupNorm table entry per lane");
   static constexpr int LDS_BYTES = (M_ELEMS + M2_ELEMS + NWV * TILE + NWV * OST) * (int)sizeof(T);
   static constexpr bool PERM = sizeof(T) == 2;
 };
@@ -55,9 +61,10 @@ struct SepCfg {
 // hold one workgroup per CU, and with four waves that is ONE wave per SIMD whose load -> MFMA -> SiLU -> store chain
 // nothing overlaps (the passes ran at 1 - 1.5 TB/s); eight waves where the tiles still fit give every SIMD a second
 // wave to issue from.
-template <typename T, int K, int R, int R2, int NWV, bool UID = false>
+template <typename T, int K, int R, int R2, int NWV, bool UID = false, int CT = 1>
 __global__ void __launch_bounds__(NWV * 64) k_sep(SepP p) {
-  typedef SepCfg<T, K, R, R2, NWV, UID> CF;
+  typedef SepCfg<T, K, R, R2, NWV, UID, CT> CF;
+  constexpr int LPW = CF::LPW;
   constexpr int NT = NWV * 64;
   typedef Mma<T> MM;
   typedef typename MM::Chunk Chunk;
@@ -77,7 +84,7 @@ __global__ void __launch_bounds__(NWV * 64) k_sep(SepP p) {
   // and storing it as such was 4 x 16 two-byte scattered stores per 16-row tile - the passes ran 5x off their HBM
   // time on store issue (profiles/r03/r03a_vae_kernel_stats.csv: 2.1 ms for a 2 x 1.07 GB pass).  Two tiles (32 rows
   // x 16 lines) are staged and leave as 16-byte pieces, a row's 16 lines (32 / 64 bytes) contiguous.
-  constexpr int LPR = 16 / EPC;                            // lanes per row of 16 lines
+  constexpr int LPR = LPW / EPC;                           // lanes per row of LPW lines
   constexpr int RPI = 64 / LPR;                            // rows per store instruction
   const int orow = lane / LPR, ocol = (lane % LPR) * EPC;
 
@@ -124,14 +131,14 @@ __global__ void __launch_bounds__(NWV * 64) k_sep(SepP p) {
     }
   }
   if constexpr (KP > K) {  // K padding of this wave's tile (never overwritten)
-    for (int i = lane; i < 16 * (KP - K); i += 64) {
+    for (int i = lane; i < LPW * (KP - K); i += 64) {
       const int row = i / (KP - K), k = K + (i - row * (KP - K));
       tile[row * KPS + k] = from_f32<T>(0.f);
     }
   }
   __syncthreads();
 
-  const long long groups_per_outer = p.inner_count / 16;
+  const long long groups_per_outer = p.inner_count / LPW;
   const long long ngroups = p.outer_count * groups_per_outer;
   const T* x = (const T*)p.x;
   T* y = (T*)p.y;
@@ -140,7 +147,7 @@ __global__ void __launch_bounds__(NWV * 64) k_sep(SepP p) {
   // and a wave's LDS operations execute in order, so the loop needs no workgroup barrier: with the matrices filling the
   // LDS there is ONE wave per SIMD, and the serial load -> barrier -> compute -> barrier chain left every pass at ~1 TB/s
   // (HBM latency per group un-hidden; profiles/r03/r03b_vae_kernel_stats.csv).
-  constexpr int CQ = 16 / EPC, KQ = K / EPC, UNITS = CQ * KQ;
+  constexpr int CQ = LPW / EPC, KQ = K / EPC, UNITS = CQ * KQ;
   constexpr int UPL = (UNITS + 63) / 64;                   // staging units per lane
   static_assert(K % EPC == 0 && 64 % CQ == 0, "staging units");
   const int ucq = lane % CQ, ukq = lane / CQ;              // unit j of this lane: (ucq, ukq + j * 64 / CQ)
@@ -149,7 +156,7 @@ __global__ void __launch_bounds__(NWV * 64) k_sep(SepP p) {
   auto fetch = [&](long long grp) {
     if (grp >= ngroups) return;
     const long long outer = grp / groups_per_outer;
-    const long long inner0 = (grp - outer * groups_per_outer) * 16;
+    const long long inner0 = (grp - outer * groups_per_outer) * LPW;
     const T* src = x + outer * p.in_outer_stride + inner0;
 #pragma unroll
     for (int j = 0; j < UPL; ++j) {
@@ -161,8 +168,8 @@ __global__ void __launch_bounds__(NWV * 64) k_sep(SepP p) {
     }
     psc = 1.f;
     psh = 0.f;
-    if (p.gn_table) {    // per-line GroupNorm scale / shift (line = inner0 + li; channel = line % C)
-      const int c = (int)((inner0 + li) % p.C);
+    if (p.gn_table) {    // per-line GroupNorm scale / shift: lane l holds line inner0 + l (channel = line % C)
+      const int c = (int)((inner0 + (lane < LPW ? lane : 0)) % p.C);
       const long long b = outer / p.outer_per_sample;
       const f32x2 t = *reinterpret_cast<const f32x2*>(p.gn_table + ((size_t)b * p.C + c) * 2);
       psc = t[0];
@@ -175,7 +182,7 @@ __global__ void __launch_bounds__(NWV * 64) k_sep(SepP p) {
     const long long grp = g0 + wave;
     const bool live = grp < ngroups;
     const long long outer = live ? grp / groups_per_outer : 0;
-    const long long inner0 = live ? (grp - outer * groups_per_outer) * 16 : 0;
+    const long long inner0 = live ? (grp - outer * groups_per_outer) * LPW : 0;
     if (live) {
       float usc[EPC], ush[EPC];
 #pragma unroll
@@ -199,15 +206,19 @@ __global__ void __launch_bounds__(NWV * 64) k_sep(SepP p) {
     }
     fetch(grp + gstep);          // in flight during this group's products and stores
 
-    Chunk xf[NKF1];
+    Chunk xfa[CT][NKF1];
 #pragma unroll
-    for (int kf = 0; kf < NKF1; ++kf) xf[kf] = ld16<Chunk>(tile + li * KPS + kf * KPF + lg * EPC);
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int kf = 0; kf < NKF1; ++kf) xfa[ct][kf] = ld16<Chunk>(tile + (16 * ct + li) * KPS + kf * KPF + lg * EPC);
+    Chunk (&xf)[NKF1] = xfa[0];
     T* dst = y + outer * p.out_outer_stride + inner0;
     // tile t of the result -> staging slot t & 1; every second tile (and the last) the staged rows are stored
-    auto put = [&](int t, const f32x4& v) {
+    auto putc = [&](int t, int ct, const f32x4& v) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sO[((t & 1) * 16 + 4 * lg + r) * 16 + li] = from_f32<T>(v[r]);
+      for (int r = 0; r < 4; ++r) sO[((t & 1) * 16 + 4 * lg + r) * LPW + 16 * ct + li] = from_f32<T>(v[r]);
     };
+    auto put = [&](int t, const f32x4& v) { putc(t, 0, v); };
     auto flush = [&](int t, int nt, int rows_total) {      // after tile t of nt
       if (!((t & 1) || t == nt - 1)) return;
       const int row0 = 16 * (t & ~1), nrows = 16 * ((t & 1) + 1);
@@ -215,19 +226,28 @@ __global__ void __launch_bounds__(NWV * 64) k_sep(SepP p) {
       for (int i = 0; i < 32 / RPI; ++i) {
         const int rr = i * RPI + orow;
         if (live && rr < nrows && row0 + rr < rows_total)
-          st16<Chunk>(dst + (long long)(row0 + rr) * p.out_k_stride + ocol, ld16<Chunk>(sO + rr * 16 + ocol));
+          st16<Chunk>(dst + (long long)(row0 + rr) * p.out_k_stride + ocol, ld16<Chunk>(sO + rr * LPW + ocol));
       }
     };
     if constexpr (R2 == 0) {
       for (int t = 0; t < RT; ++t) {
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 z[CT];
 #pragma unroll
-        for (int kf = 0; kf < NKF1; ++kf) MM::mma(z, ld16<Chunk>(Ms + (16 * t + li) * KPS + kf * KPF + lg * EPC), xf[kf]);
-        if (p.act) {
+        for (int ct = 0; ct < CT; ++ct) z[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) z[r] = silu_f(z[r]);
+        for (int kf = 0; kf < NKF1; ++kf) {
+          const Chunk a = ld16<Chunk>(Ms + (16 * t + li) * KPS + kf * KPF + lg * EPC);      // one matrix fragment, CT products
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) MM::mma(z[ct], a, xfa[ct][kf]);
         }
-        put(t, z);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          if (p.act) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[ct][r] = silu_f(z[ct][r]);
+          }
+          putc(t, ct, z[ct]);
+        }
         flush(t, RT, R);
       }
     } else if constexpr (UID) {
@@ -353,19 +373,28 @@ __global__ void __launch_bounds__(256) k_softmax_rows(const T* __restrict__ x, T
   for (int i = threadIdx.x; i < cols; i += 256) yr[i] = from_f32<T>(__expf(to_f32(xr[i]) * scale - m) * inv);
 }
 
-template <typename T, int K, int R, int R2, int NWV, bool UID = false>
+template <typename T, int K, int R, int R2, int NWV, bool UID = false, int CT = 1>
 static int launch_sep_w(const SepP& p, int per_cu, hipStream_t st) {
-  typedef SepCfg<T, K, R, R2, NWV, UID> CF;
+  typedef SepCfg<T, K, R, R2, NWV, UID, CT> CF;
+  static_assert(CF::LDS_BYTES <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_sep<T, K, R, R2, NWV, UID>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)k_sep<T, K, R, R2, NWV, UID, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
     attr_set = true;
   }
-  const long long ngroups = p.outer_count * (p.inner_count / 16);
+  const long long ngroups = p.outer_count * (p.inner_count / CF::LPW);
   long long grid = 256 * per_cu;
   if (grid * NWV > ngroups) grid = (ngroups + NWV - 1) / NWV;
-  k_sep<T, K, R, R2, NWV, UID><<<(int)grid, NWV * 64, CF::LDS_BYTES, st>>>(p);
+  k_sep<T, K, R, R2, NWV, UID, CT><<<(int)grid, NWV * 64, CF::LDS_BYTES, st>>>(p);
   return check_launch("afldm_sep_pass");
+}
+
+// plain pass with CT column tiles per wave (inner_count a multiple of 16 CT); one or two 4-wave workgroups per CU
+template <typename T, int K, int R, int CT>
+static int launch_sep_ct(const SepP& p, hipStream_t st) {
+  typedef SepCfg<T, K, R, 0, 4, false, CT> CF;
+  constexpr int n4 = (160 * 1024) / CF::LDS_BYTES;
+  return launch_sep_w<T, K, R, 0, 4, false, CT>(p, n4 >= 2 ? 2 : 1, st);
 }
 
 template <typename T, int K, int R, int R2, bool UID = false>
@@ -395,6 +424,18 @@ static int sep_dispatch(const SepP& p, int K, int R, int R2, int up_identity, hi
     if (up_identity == 2 && K == 64 && R == 128 && R2 == 64) return launch_sep<T, 64, 128, 64, true>(p, st);
     if constexpr (sizeof(T) == 2) {
       if (K == 128 && R == 256 && R2 == 128) return launch_sep<T, 128, 256, 128, true>(p, st);
+    }
+  }
+  // plain passes over lines that come in memory-adjacent runs of 32 / 64: wider groups (see SepCfg, CT)
+  static const bool no_ct = getenv("AFLDM_SEP_NO_CT") != nullptr;
+  if (R2 == 0 && !no_ct) {
+    if constexpr (sizeof(T) == 2) {
+      if (K == 128 && R == 256 && p.inner_count % 64 == 0) return launch_sep_ct<T, 128, 256, 4>(p, st);
+      if (K == 256 && R == 128 && p.inner_count % 32 == 0) return launch_sep_ct<T, 256, 128, 2>(p, st);
+      if (K == 64 && R == 128 && p.inner_count % 64 == 0) return launch_sep_ct<T, 64, 128, 4>(p, st);
+      if (K == 128 && R == 64 && p.inner_count % 32 == 0) return launch_sep_ct<T, 128, 64, 2>(p, st);
+      if (K == 32 && R == 64 && p.inner_count % 64 == 0) return launch_sep_ct<T, 32, 64, 4>(p, st);
+      if (K == 64 && R == 32 && p.inner_count % 64 == 0) return launch_sep_ct<T, 64, 32, 4>(p, st);
     }
   }
 #define AFLDM_SEP(K_, R_, R2_) \
