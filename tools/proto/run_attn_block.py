@@ -1,0 +1,112 @@
+#!/usr/bin/env python
+"""Prototype check + timing of the XCD-local fused attention block (tools/proto/attn_block.hip) against the product's
+launches for the same block (q|k|v projection, attention, to_out + residual + statistics), batch 64, bf16:
+4x4 level (T = 16, C = 768, 32 heads) and 8x8 level (T = 64, C = 384, 16 heads).  Output: gpurun_out/attn_block.txt."""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from afldm_amd import ops  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libattn_block.so")
+if not os.path.exists(SO) or "--build" in sys.argv:
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", SO,
+                           os.path.join(HERE, "attn_block.hip")])
+    if "--build" in sys.argv:
+        sys.exit(0)
+lib = ctypes.CDLL(SO)
+vp = ctypes.c_void_p
+lib.ab_attn_block.argtypes = [vp] * 11 + [ctypes.c_int] * 4 + [ctypes.c_float, vp]
+dev = torch.device("cuda")
+lines = []
+
+
+def say(s):
+    print(s, flush=True)
+    lines.append(s)
+
+
+def graph_time(fn, reps=200):
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(10):
+            fn()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps // 10):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (reps // 10 * 10) * 1e3
+
+
+def case(B, N, C, heads):
+    T = N * N
+    gen = torch.Generator().manual_seed(C + T)
+    bf = torch.bfloat16
+    hn = torch.randn(B, T, C, generator=gen).to(bf).to(dev)
+    x = torch.randn(B, T, C, generator=gen).to(bf).to(dev)
+    wqkv = (torch.randn(3 * C, C, generator=gen) / C ** 0.5).to(bf).to(dev)
+    bqkv = (0.1 * torch.randn(3 * C, generator=gen)).to(dev)
+    wo = (torch.randn(C, C, generator=gen) / C ** 0.5).to(bf).to(dev)
+    bo = (0.1 * torch.randn(C, generator=gen)).to(dev)
+    scale = 24 ** -0.5
+    w4, wo4 = wqkv.view(3 * C, 1, 1, C), wo.view(C, 1, 1, C)
+
+    def reference():
+        qk, vt = ops.linear_split(hn, w4, bqkv, 2 * C)
+        o = ops.attention(qk[:, :, :C], qk[:, :, C:], vt, heads, scale=scale)
+        return ops.conv2d(o.view(B, N, N, C), wo4, bo, residual=x.view(B, N, N, C), want_stats=True)
+
+    y_ref = reference()
+    st_ref = y_ref.gn_partial.sum(1)                 # [B, C, 2]
+    qkv = torch.empty(B, T, 3 * C, dtype=bf, device=dev)
+    o = torch.empty(B, T, C, dtype=bf, device=dev)
+    y = torch.empty(B, T, C, dtype=bf, device=dev)
+    st = torch.zeros(B, C, 2, dtype=torch.float32, device=dev)
+    sync = torch.zeros(512, dtype=torch.int32, device=dev)
+
+    def fused():
+        rc = lib.ab_attn_block(hn.data_ptr(), x.data_ptr(), wqkv.data_ptr(), bqkv.data_ptr(), wo.data_ptr(), bo.data_ptr(),
+                               qkv.data_ptr(), o.data_ptr(), y.data_ptr(), st.data_ptr(), sync.data_ptr(), B, T, C, heads,
+                               scale, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, rc
+
+    fused()
+    torch.cuda.synchronize()
+    sw = sync.cpu()
+    err = int(sw[256])
+    d = (y.float().view(-1) - y_ref.float().view(-1))
+    rel = float(d.pow(2).mean().sqrt() / y_ref.float().pow(2).mean().sqrt())
+    srel = float((st - st_ref).abs().max() / st_ref.abs().max())
+    # rerun many times under uneven conditions: results must be bit-identical and the sync words must come back to zero
+    y0 = y.clone()
+    same = True
+    for _ in range(50):
+        fused()
+    torch.cuda.synchronize()
+    same = bool(torch.equal(y, y0)) and int(sync[:256].abs().sum()) == 0 and int(sync[256]) == 0
+    t_ref = graph_time(reference)
+    t_fus = graph_time(fused)
+    say(f"B={B} {N}x{N} C={C} heads={heads}:  fused vs launches rel-RMS {rel:.2e}, statistics max-rel {srel:.2e}, barrier timeouts {err}, "
+        f"50 reruns bit-identical + sync words zero: {same}")
+    say(f"    product launches (q|k|v GEMM + attention + to_out GEMM, graph replay): {t_ref:7.2f} us     "
+        f"ONE XCD-local launch: {t_fus:7.2f} us     ratio {t_ref / t_fus:4.2f}x")
+
+
+say("XCD-local fused attention block (prototype) vs the product's launches, batch 64, bf16")
+case(64, 4, 768, 32)
+case(64, 8, 384, 16)
+os.makedirs("gpurun_out", exist_ok=True)
+open("gpurun_out/attn_block.txt", "w").write("\n".join(lines) + "\n")
