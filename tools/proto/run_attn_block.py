@@ -22,7 +22,7 @@ if not os.path.exists(SO) or "--build" in sys.argv:
         sys.exit(0)
 lib = ctypes.CDLL(SO)
 vp = ctypes.c_void_p
-lib.ab_attn_block.argtypes = [vp] * 11 + [ctypes.c_int] * 4 + [ctypes.c_float, vp]
+lib.ab_attn_block.argtypes = [vp] * 11 + [ctypes.c_int] * 4 + [ctypes.c_float, vp, vp, ctypes.c_int]
 dev = torch.device("cuda")
 lines = []
 
@@ -70,6 +70,8 @@ def case(B, N, C, heads):
         return ops.conv2d(o.view(B, N, N, C), wo4, bo, residual=x.view(B, N, N, C), want_stats=True)
 
     y_ref = reference()
+    torch.cuda.synchronize()
+    print("reference ran", flush=True)
     st_ref = y_ref.gn_partial.sum(1)                 # [B, C, 2]
     qkv = torch.empty(B, T, 3 * C, dtype=bf, device=dev)
     o = torch.empty(B, T, C, dtype=bf, device=dev)
@@ -77,10 +79,18 @@ def case(B, N, C, heads):
     st = torch.zeros(B, C, 2, dtype=torch.float32, device=dev)
     sync = torch.zeros(512, dtype=torch.int32, device=dev)
 
-    def fused():
-        rc = lib.ab_attn_block(hn.data_ptr(), x.data_ptr(), wqkv.data_ptr(), bqkv.data_ptr(), wo.data_ptr(), bo.data_ptr(),
+    dbg = torch.zeros(256 * 8, dtype=torch.int64, device=dev)
+
+    def frag_major(w):       # [N, K] -> [N / 16][K / 32][g = 4][i = 16][8]: element (16 nt + i, 32 ks + 8 g + e)
+        Nn, K = w.shape
+        return w.view(Nn // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+    wqkv_p, wo_p = frag_major(wqkv), frag_major(wo)
+
+    def fused(stamps=False, flags=0):
+        rc = lib.ab_attn_block(hn.data_ptr(), x.data_ptr(), wqkv_p.data_ptr(), bqkv.data_ptr(), wo_p.data_ptr(), bo.data_ptr(),
                                qkv.data_ptr(), o.data_ptr(), y.data_ptr(), st.data_ptr(), sync.data_ptr(), B, T, C, heads,
-                               scale, torch.cuda.current_stream().cuda_stream)
+                               scale, torch.cuda.current_stream().cuda_stream, dbg.data_ptr() if stamps else None, flags)
         assert rc == 0, rc
 
     fused()
@@ -97,6 +107,19 @@ def case(B, N, C, heads):
         fused()
     torch.cuda.synchronize()
     same = bool(torch.equal(y, y0)) and int(sync[:256].abs().sum()) == 0 and int(sync[256]) == 0
+    y_keep = y.clone()
+    for flags, what in ((0, "full"), (1, "no LDS-DMA"), (2, "no fragment reads / MFMAs"), (3, "neither"), (4, "no attention math")):
+        for _ in range(3):
+            fused(True, flags)
+        torch.cuda.synchronize()
+        d8 = dbg.view(256, 8).cpu().double()
+        t0 = d8[:, 0].min()
+        ph = [(d8[:, k] - t0).mean().item() / 100.0 for k in range(6)]       # 100 MHz ticks -> us
+        say("    %-26s phase ends, us after the first workgroup's start (mean over 256 workgroups): start %.1f | Q %.1f | barrier %.1f | "
+            "A %.1f | barrier %.1f | O %.1f" % ((what,) + tuple(ph)))
+    fused()
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_keep)
     t_ref = graph_time(reference)
     t_fus = graph_time(fused)
     say(f"B={B} {N}x{N} C={C} heads={heads}:  fused vs launches rel-RMS {rel:.2e}, statistics max-rel {srel:.2e}, barrier timeouts {err}, "
