@@ -405,6 +405,31 @@ def part_g():
     np.savez_compressed(os.path.join(OUT, "g13_r03.npz"), **g)
 
 
+def part_h():
+    """Round 3: BASELINE configs[4]'s sampler at FULL length on the FFHQ-size UNet (the 99 UNet evaluations of the 100-step I2SB
+    bridge, batch 1, fp32 oracle; reference loop i2sb_pipeline.py:48-56 with is_ode) and DDIM inversion at FFHQ size
+    (6-step schedule; reference ldm_pipeline.py:133-160)."""
+    from . import configs, i2sb, pipeline, unet
+    torch.set_num_threads(8)
+    cfg = configs.FFHQ_UNET
+    sd = unet.init_unet_params(cfg, seed=0, conv_out_scale=0.1)
+    gen = torch.Generator().manual_seed(4242)
+    g = {}
+    lat = 0.8 * torch.randn(1, 4, 32, 32, generator=gen)
+    g["i2sb_start"] = lat.numpy()
+    s2 = i2sb.I2SB()
+    s2.set_timesteps(100)
+    for k, t in enumerate(s2.timesteps[:99]):
+        lat = s2.step(unet.unet_forward(sd, cfg, lat, t), t, lat)
+        if k == 49:
+            g["i2sb_eval50"] = lat.numpy()
+    g["i2sb_final99"] = lat.numpy()
+    z0 = 0.5 * torch.randn(1, 4, 32, 32, generator=gen)
+    g["inv_in"] = z0.numpy()
+    g["inv_out_6"] = pipeline.ddim_inversion(sd, cfg, z0, 6).numpy()
+    np.savez_compressed(os.path.join(OUT, "g14_r03.npz"), **g)
+
+
 def idf_warp(x):
     from .ideal_filters import warped_nonlinearity
     return warped_nonlinearity(x)
@@ -427,5 +452,7 @@ if __name__ == "__main__":
         part_f()
     if which in ("g", "all"):
         part_g()
+    if which in ("h", "all"):
+        part_h()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

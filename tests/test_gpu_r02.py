@@ -386,3 +386,36 @@ def test_ffhq_equivariance_vs_oracle(golden, dtype, budget_db):
         db = 10 * np.log10(mse / want)
         print(f"[equivariance vs oracle] {dtype} tj={tj}: mask_mse {mse:.4e}, oracle {want:.4e} ({db:+.3f} dB)")
         assert abs(db) <= budget_db, (tj, mse, want)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 1e-1)])
+def test_ffhq_full_99_evaluation_i2sb_bridge_vs_oracle(golden, dtype, tol):
+    """BASELINE configs[4]'s sampler at FULL length on the GPU path: the 99 UNet evaluations of the 100-step I2SB bridge
+    (is_ode; reference i2sb_pipeline.py:48-56) on the FFHQ-size AF-UNet at batch 1 against the fp32 oracle
+    (tests/golden/g14_r03.npz, oracle/gen_golden.py part h).  fp32: the multi-step tolerance 1e-3; bf16 after 99
+    evaluations of the random-init network: 0.10 (the bf16-vs-fp32 figure of test_i2sb_per_gpu_share_of_c5)."""
+    from afldm_amd.configs import FFHQ_DDIM_CONFIG
+    from afldm_amd.pipelines.i2sb_pipeline import I2SBLDMPipeline
+    from afldm_amd.schedulers.i2sb import I2SBScheduler
+    g = golden("g14_r03.npz")
+    cfg = {k: v for k, v in FFHQ_DDIM_CONFIG.items() if k != "set_alpha_to_one"}
+    unet, _, _ = build_unet("ffhq", dtype)
+    pipe = I2SBLDMPipeline(None, unet, I2SBScheduler.from_config(cfg))
+    pipe.set_progress_bar_config(disable=True)
+    out = pipe._bridge(torch.from_numpy(g["i2sb_start"]).cuda().to(dtype), 100, True, None)
+    r = rel_rms(out.float(), g["i2sb_final99"])
+    print(f"[C5 99 evaluations] {dtype}: rel-RMS vs oracle {r:.3e}")
+    assert r <= tol, r
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+def test_ffhq_ddim_inversion_vs_oracle(golden, dtype, tol):
+    """MyLDMPipeline.ddim_inversion (reference ldm_pipeline.py:133-160) at FFHQ size, 6-step schedule, against the oracle."""
+    from afldm_amd.pipelines.ldm_pipeline import MyLDMPipeline
+    from afldm_amd.schedulers.ddim import ffhq_ddim_scheduler
+    g = golden("g14_r03.npz")
+    unet, _, _ = build_unet("ffhq", dtype)
+    pipe = MyLDMPipeline(None, unet, ffhq_ddim_scheduler())
+    pipe.scheduler.set_timesteps(6, device="cuda")
+    inv = pipe.ddim_inversion(torch.from_numpy(g["inv_in"]).cuda().to(dtype), bar=False)
+    assert rel_rms(inv.float(), g["inv_out_6"]) <= tol
