@@ -134,6 +134,12 @@ def roofline_pass(unet, batch, dtype):
                     frac=round(achieved / PEAK_HBM_GBS, 4), traffic=None,
                     launches_per_step=d["launches"] // 3, avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
                     bytes_per_launch=d["bytes"] / d["launches"])
+    # whole-step dense rate: the algorithmic MFMA-shaped work of one step (3x3 / 1x1 convolutions, linear layers, attention; the
+    # alias-free filters' dense separable form is kept apart) over the TIMED step - filled in by main()
+    dense = sum(agg[k]["flops"] for k in agg if k.startswith("conv") or k in ("linear", "attention")) / 3
+    af = sum(agg[k]["flops"] for k in agg if k.startswith("af_")) / 3
+    roof["step_dense_tflop"] = round(dense / 1e12, 4)
+    roof["step_af_filter_tflop"] = round(af / 1e12, 4)
     return roof, fam
 
 
@@ -457,6 +463,11 @@ def main():
         out["box"] = box_record(dev)
         if not args.no_roofline:
             roof, fam = roofline_pass(unet, B, dtype)
+            peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+            rate = roof.pop("step_dense_tflop") / (dt / args.steps)
+            out["step_dense"] = {"tflop_per_step": round(rate * dt / args.steps, 4), "tflops": round(rate, 1), "peak": peak,
+                                 "frac": round(rate / peak, 4), "af_filter_tflop_per_step": roof.pop("step_af_filter_tflop"),
+                                 "note": "algorithmic flops of the step's convolutions + linear layers + attention over the timed step"}
             out["roofline"] = roof
             out["kernel_families"] = fam
         del eng
