@@ -24,7 +24,7 @@ class ConvArgs(Structure):
         ("KS", c_int), ("temb_stride", c_int), ("res_ld", c_int), ("y_ld", c_int),
         ("out_mode", c_int), ("dtype", c_int), ("y2", c_void_p), ("split_n", c_int),
         ("stats_out", c_void_p), ("temb_mod", c_int), ("sync", c_void_p), ("sync_bytes", c_size_t),
-        ("defer_reduce", c_int),
+        ("defer_reduce", c_int), ("w_batch_stride", ctypes.c_longlong),
     ]
 
 

@@ -437,7 +437,8 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
   const long long w_bytes = (long long)p.Cout * p.KS * p.KS * Ct * ESZ;
   __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, (int)x1_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x1), 0, (int)x2_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)w_bytes, 0x00020000);
+  // (per-sample weights, afldm_conv_args.w_batch_stride: the tile lies inside sample m0 / HW)
+  __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.w + (size_t)(p.w_bstride ? m0 / HW : 0) * p.w_bstride), 0, (int)w_bytes, 0x00020000);
 
   // per-lane source coordinates.  Instruction j (0..XI-1) of a stage covers plane kc = j / XG, row
   // group g = j % XG; this wave issues j = wave + NW * i.  Lane l: row 16 g + (l >> 2), source
@@ -2038,6 +2039,7 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
   p.temb_mod = a->temb_mod > 0 ? a->temb_mod : a->Cout;
   p.M = a->B * a->H * a->W;
   p.splitk = 1; p.tiles_n = 1; p.ksteps = 0; p.sync = nullptr;
+  p.w_bstride = a->w_batch_stride;
   static const int s_dbg = getenv("AFLDM_CONV_DBG") ? atoi(getenv("AFLDM_CONV_DBG")) : 0;
   p.dbg = s_dbg;
   static const int s_tapin = getenv("AFLDM_CONV_TAPINNER") ? atoi(getenv("AFLDM_CONV_TAPINNER")) : 0;
@@ -2068,6 +2070,7 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
   p.stats_multi = 0;
   if (a->stats_out) smode = stats_mode<T>(a, ex, &p.stats_S);
   int rc = AFLDM_OK;
+  AFLDM_REQUIRE(!a->w_batch_stride || pl.kind == 0, AFLDM_ESHAPE, "afldm_conv2d: w_batch_stride needs the GEMM path (Cin a multiple of the K step)");
   if (lin_wreg_bm(a)) return lin_wreg_launch(a, st);
   if (skinny_stats_splits(a)) return skinny_launch(a, st);
   if (pl.kind == 1 && cin4_mfma_ok<T>(a)) {
@@ -2109,6 +2112,12 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
     }
     p.sync = ex.fused ? a->sync : nullptr;
     if (ex.fused && smode == ST_FUSED) p.stats_out = a->stats_out;
+    if (a->w_batch_stride) {      // per-sample weights: the LDS-DMA GEMM only, whole tiles inside a sample, K not split
+      const int ver = kVariants[ex.vid].ver;
+      AFLDM_REQUIRE(ver >= 2 && ver <= 4 && p.splitk == 1 && (a->H * a->W) % kVariants[ex.vid].bm == 0, AFLDM_ESHAPE,
+                    "afldm_conv2d: w_batch_stride needs H*W a multiple of the %d-row tile of variant %d and no split-K",
+                    kVariants[ex.vid].bm, ex.vid);
+    }
     launch_variant<T>(ex.vid, p, st);
     rc = check_launch("afldm_conv2d(igemm)");
     if (rc) return rc;
@@ -2154,6 +2163,9 @@ static int conv_validate(const afldm_conv_args* a) {
                 "afldm_conv2d: y_ld=%d too small for Cout=%d", a->y_ld, a->Cout);
   AFLDM_REQUIRE(!a->residual || a->res_ld >= a->Cout, AFLDM_ESHAPE, "afldm_conv2d: res_ld=%d < Cout=%d", a->res_ld, a->Cout);
   AFLDM_REQUIRE((long long)a->B * a->H * a->W < (1ll << 30), AFLDM_ESHAPE, "afldm_conv2d: M too large");
+  AFLDM_REQUIRE(a->w_batch_stride == 0 || (a->w_batch_stride > 0 && a->KS == 1 && a->out_mode == 0 && !a->y2 && !a->stats_out &&
+                                            a->C2 == 0 && a->w_batch_stride % 8 == 0 && !a->defer_reduce),
+                AFLDM_ESHAPE, "afldm_conv2d: w_batch_stride needs KS = 1, out_mode 0, no y2 / stats / concat, stride %% 8 == 0");
   AFLDM_REQUIRE(a->temb_mod == 0 || (a->temb_mod > 0 && a->temb_mod % 8 == 0 && a->Cout % a->temb_mod == 0), AFLDM_ESHAPE,
                 "afldm_conv2d: temb_mod=%d must divide Cout=%d and be a multiple of 8", a->temb_mod, a->Cout);
   AFLDM_REQUIRE(!a->stats_out || (a->out_mode == 0 && !a->y2 && a->y_ld == a->Cout && a->Cout % 4 == 0), AFLDM_ESHAPE,
@@ -2253,6 +2265,7 @@ extern "C" int afldm_conv2d(const afldm_conv_args* a, afldm_stream_t stream) {
     q.y2 = a->y2 ? (char*)a->y2 + (size_t)b0 * (size_t)(a->Cout - a->split_n) * HW * esz : nullptr;
     q.residual = a->residual ? (const char*)a->residual + (size_t)b0 * HW * a->res_ld * esz : nullptr;
     q.temb = a->temb ? (const char*)a->temb + (size_t)b0 * a->temb_stride * esz : nullptr;
+    q.w = (const char*)a->w + (size_t)b0 * (size_t)a->w_batch_stride * esz;
     q.stats_out = a->stats_out ? a->stats_out + (size_t)b0 * S * a->Cout * 2 : nullptr;
     rc = a->dtype == AFLDM_F32 ? conv_dispatch<float>(&q, st) : conv_dispatch<bf16>(&q, st);
     if (rc) return rc;

@@ -33,6 +33,7 @@ struct ConvP {
   int dbg;      // AFLDM_CONV_DBG (timing decomposition only): bit 0 skip the LDS-DMA, bit 1 skip the MFMA phase
   int xcd_gn;    // conv3h tile order: the XCDs as a (8 / xcd_gn) x xcd_gn grid over (m, n) tiles; 0 = contiguous runs, n fastest
   unsigned* sync;   // in-kernel split-K reduction: 2 zero-initialised words per output tile (arrivals, departures), or NULL
+  long long w_bstride;   // elements between the weight tensors of consecutive samples (0: shared weights); k_igemm2 only
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;

@@ -214,7 +214,7 @@ static int launch_lin(LinP p, hipStream_t st) {
 // Tile height of the weights-in-registers kernel for this call, 0 when it does not apply.
 int lin_wreg_bm(const afldm_conv_args* a) {
   static const bool off = getenv("AFLDM_NO_LIN_WREG") && atoi(getenv("AFLDM_NO_LIN_WREG")) != 0;
-  if (off || a->dtype != AFLDM_BF16 || a->KS != 1 || a->C2 != 0 || a->temb || a->out_mode != 0) return 0;
+  if (off || a->dtype != AFLDM_BF16 || a->KS != 1 || a->C2 != 0 || a->temb || a->out_mode != 0 || a->w_batch_stride) return 0;
   const int K = a->C1;
   if (K != 192 && K != 384) return 0;
   const int BM = 32, BN = K == 192 ? 192 : 128;

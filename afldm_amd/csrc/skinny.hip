@@ -191,7 +191,7 @@ static int skinny_slices(const afldm_conv_args* a) {
 // Statistics splits of the skinny kernel's output for this call (0: the kernel does not apply).
 int skinny_stats_splits(const afldm_conv_args* a) {
   static const bool off = getenv("AFLDM_NO_SKINNY") && atoi(getenv("AFLDM_NO_SKINNY")) != 0;
-  if (off || a->KS != 1 || a->out_mode != 0 || a->y2) return 0;
+  if (off || a->KS != 1 || a->out_mode != 0 || a->y2 || a->w_batch_stride) return 0;
   const long long M = (long long)a->B * a->H * a->W;
   const int HW = a->H * a->W, K = a->C1 + a->C2;
   const int esz = a->dtype == AFLDM_F32 ? 4 : 2;

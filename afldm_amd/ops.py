@@ -481,11 +481,20 @@ def softmax_rows(x, scale=1.0, out=None):
     return out
 
 
+_BATCHED_DENSE_ATTN = os.environ.get("AFLDM_NO_BATCHED_DENSE_ATTN", "0") != "1"
+
+
 def attention_dense(q, k, vt, scale):
     """Single-head attention with a large head_dim (the VAE mid block: d = 512, T = 1024) as two
     per-sample GEMMs around a row softmax.  q, k: [B, T, C] contiguous; vt: [B, C, T]."""
     B, T, C = q.shape
     out = torch.empty_like(q)
+    if _BATCHED_DENSE_ATTN and q.dtype == torch.bfloat16 and T % 128 == 0 and C % 64 == 0 and B * T * max(T, C) * 2 < (1 << 31):
+        # the whole batch in three launches: sample b's K_b / V_b^T are the "weights" of its rows (afldm_conv_args.w_batch_stride)
+        s = conv2d(q.view(B, T, 1, C), k[0].view(T, 1, 1, C), w_batch_stride=T * C)          # [B, T, 1, T] scores
+        p = softmax_rows(s.view(B * T, T), scale)
+        conv2d(p.view(B, T, 1, T), vt[0].view(C, 1, 1, T), w_batch_stride=C * T, out=out.view(B, T, 1, C))
+        return out
     for b in range(B):
         s = conv2d(q[b].view(1, T, 1, C), k[b].view(T, 1, 1, C))                # [1, T, 1, T] scores
         p = softmax_rows(s.view(T, T), scale)
@@ -636,7 +645,7 @@ def conv_args(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None
 
 
 def conv2d(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, out=None, out_mode=0,
-           workspace=None, want_stats=False, temb_mod=0):
+           workspace=None, want_stats=False, temb_mod=0, w_batch_stride=0):
     """stride-1 'same' conv (KS in {1,3}) / linear on NHWC input with packed OHWI weights.
     out_mode 1 returns the channel-major [B, Cout, H*W] tensor (V^T for attention).
     want_stats: also emit the per-channel GroupNorm partial sums of the output (from the GEMM
@@ -649,6 +658,7 @@ def conv2d(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, o
             B = x1.shape[0]
             out = torch.empty((B, Cout, x1.numel() // (B * x1.shape[-1])), dtype=x1.dtype, device=x1.device)
     a = conv_args(x1, w, bias, x2, temb, temb_stride, residual, out, out_mode, workspace, temb_mod=temb_mod)
+    a.w_batch_stride = int(w_batch_stride)   # per-sample weights (elements between samples' weight tensors; `w` = sample 0's)
     if out_mode == 1 and x1.ndim == 3:      # [B, T, C] tokens: treat T as the pixel axis
         a.B, a.H, a.W = x1.shape[0], x1.shape[1], 1
     if workspace is None:

@@ -261,6 +261,11 @@ typedef struct {
    * caller hands them to a consumer that finishes them itself (afldm_af_act_slabs).  y / stats_out are not written.
    * Ignored (the call completes as usual) when K is not split. */
   int defer_reduce;
+  /* 0, or the distance IN ELEMENTS between the weight tensors of consecutive samples: sample b is convolved with
+   * w + b * w_batch_stride (KS = 1, out_mode 0, no split-K; a tile never spans two samples).  This is the "per-sample weights"
+   * GEMM of the AF-VAE's single-head d = 512 attention (af_vae.py / diffusers AttnProcessor2_0): scores = Q_b K_b^T with K_b as
+   * the weights, then P_b V_b with V_b^T as the weights - one launch for the batch instead of one per sample. */
+  long long w_batch_stride;
 } afldm_conv_args;
 int afldm_conv2d(const afldm_conv_args* args, afldm_stream_t stream);
 /* Tuning hook (benchmarks only): force tile/pipeline variant `variant` (>= 0) and/or a split-K

@@ -108,6 +108,24 @@ def test_dense_attention(dtype, tol):
     assert rel_rms(o, ref) <= tol
 
 
+def test_dense_attention_batched_matches_per_sample_loop(monkeypatch):
+    """The VAE mid-block attention (1 head, d = 512, T = 1024) for the whole batch in three launches - sample b's K_b / V_b^T
+    are the per-sample "weights" of afldm_conv2d (w_batch_stride, round 3) - against the per-sample loop it replaces
+    (bit-identical: same kernels, same tiles) and against torch's SDPA in fp32."""
+    from afldm_amd import ops
+    g = torch.Generator().manual_seed(17)
+    B, T, C = 5, 1024, 512
+    q, k, v = (torch.randn(B, T, C, generator=g).to(torch.bfloat16) for _ in range(3))
+    qc, kc, vtc = q.cuda(), k.cuda(), v.transpose(1, 2).contiguous().cuda()
+    assert ops._BATCHED_DENSE_ATTN
+    o_batched = ops.attention_dense(qc, kc, vtc, C ** -0.5)
+    monkeypatch.setattr(ops, "_BATCHED_DENSE_ATTN", False)
+    o_loop = ops.attention_dense(qc, kc, vtc, C ** -0.5)
+    ref = F.scaled_dot_product_attention(q.float()[:, None], k.float()[:, None], v.float()[:, None])[:, 0]
+    assert rel_rms(o_batched, ref) <= 1.5e-2 and rel_rms(o_loop, ref) <= 1.5e-2
+    assert rel_rms(o_batched, o_loop.float().cpu()) <= 2e-3
+
+
 def build_vae(dtype):
     from afldm_amd.af_modules.af_api import make_af_vae_from_config
     from afldm_amd.models.vae import AutoencoderKL
