@@ -15,20 +15,28 @@ from ..models.blocks import Downsample2D, Upsample2D, conv_forward
 
 
 class WarpedNonlinearity(nn.Module):
+    """Any module can be wrapped, as in the reference (af_blocks.py:12-28).  nn.SiLU - the activation of every AF-LDM
+    UNet / VAE config - runs as ONE fused kernel (afldm_af_act; ResnetBlock2D additionally fuses its GroupNorm into it);
+    any other module runs as HIP x2 upsample -> the wrapped module itself (the caller's code, elementwise on the 2N x 2N
+    plane) -> HIP low-pass + decimate."""
+
     def __init__(self, nonlinearity):
         super().__init__()
-        if not isinstance(nonlinearity, nn.SiLU):
-            raise NotImplementedError("the fused alias-free activation kernel implements SiLU "
-                                      "(the only activation of the AF-LDM UNet / VAE configs)")
         self.up_layer = UpsampleRFFT()
         self.lpf = LPF_RFFT(1 / 2)
         self.nonlinearity = nonlinearity
 
+    @property
+    def fused_silu(self):
+        return type(self.nonlinearity) is nn.SiLU
+
     def forward(self, x):
-        """x: NHWC [B, N, N, C] (internal layout) or a <4-D tensor (plain SiLU, af_blocks.py:20-21)."""
+        """x: NHWC [B, N, N, C] (internal layout) or a <4-D tensor (the plain nonlinearity, af_blocks.py:20-21)."""
+        if self.fused_silu:
+            return ops.silu(x) if x.ndim < 4 else ops.af_act(x)
         if x.ndim < 4:
-            return ops.silu(x)
-        return ops.af_act(x)
+            return self.nonlinearity(x)
+        return ops.af_lpf_down2(self.nonlinearity(ops.af_up2(x)).contiguous())
 
 
 class AliasFreeUpsample2D(Upsample2D):

@@ -206,6 +206,11 @@ __global__ void __launch_bounds__(NWV * 64) k_sep(SepP p) {
     }
     fetch(grp + gstep);          // in flight during this group's products and stores
 
+    // the tile is exchanged ACROSS LANES of this wave through LDS with no workgroup barrier: pin the order of the stores
+    // above and the fragment reads below for the compiler (costs no instruction)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     Chunk xfa[CT][NKF1];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -222,12 +227,17 @@ __global__ void __launch_bounds__(NWV * 64) k_sep(SepP p) {
     auto flush = [&](int t, int nt, int rows_total) {      // after tile t of nt
       if (!((t & 1) || t == nt - 1)) return;
       const int row0 = 16 * (t & ~1), nrows = 16 * ((t & 1) + 1);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // put() -> other lanes' reads of the staged rows
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
       for (int i = 0; i < 32 / RPI; ++i) {
         const int rr = i * RPI + orow;
         if (live && rr < nrows && row0 + rr < rows_total)
           st16<Chunk>(dst + (long long)(row0 + rr) * p.out_k_stride + ocol, ld16<Chunk>(sO + rr * LPW + ocol));
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the staged rows are read before the next put() overwrites them
+      __builtin_amdgcn_wave_barrier();
     };
     if constexpr (R2 == 0) {
       for (int t = 0; t < RT; ++t) {

@@ -25,9 +25,15 @@ def model_state_key(model):
     attention processors (set_unet_attn_processor), and every parameter's storage + in-place version counter
     (load_state_dict copies in place -> _version moves; .to() / .half() re-allocate -> data_ptr moves).  ~1 ms for the
     FFHQ UNet; compared once per DenoiseEngine.reset()."""
+    def ver(p):
+        try:
+            return p._version
+        except RuntimeError:          # tensors created under torch.inference_mode() have no version counter
+            return -1
     mods = tuple((id(m), id(getattr(m, "processor", None))) for m in model.modules())
-    params = tuple((p.data_ptr(), p._version) for p in model.parameters())
-    return hash((mods, params))
+    params = tuple((p.data_ptr(), ver(p), p.dtype, str(p.device)) for p in model.parameters())
+    bufs = tuple((b.data_ptr(), ver(b), b.dtype, str(b.device)) for b in model.buffers())
+    return hash((mods, params, bufs))
 
 
 class DenoiseEngine:
@@ -125,6 +131,11 @@ class DenoiseEngine:
             return False
         from .models.blocks import invalidate_packed
         torch.cuda.synchronize()
+        if self.unet.dtype != self.x_nhwc.dtype or self.unet.device != self.x_nhwc.device:
+            # .to(dtype / device): every dtype-typed static buffer of the engine is stale, not just the table
+            invalidate_packed(self.unet)
+            self.__init__(self.unet, self.scheduler, self.B, self.n, self.use_graph, self.steps_per_graph, self.branches)
+            return True
         self.graph = self.graph_multi = None
         invalidate_packed(self.unet)       # in-place parameter edits do not pass through the modules' own hooks
         self.temb_table.copy_(torch.cat([self.unet.temb_projection(t) for t in self.timesteps], 0))

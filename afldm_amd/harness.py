@@ -84,7 +84,7 @@ def shift_ldm(pipeline, num_inference_steps=50, num_shift_steps=16, output_path=
         rec_img = vae_decode(vae, denoised) if vae is not None else None
 
         offsets = torch.linspace(1 / ratio, num_shift_steps / ratio, num_shift_steps)
-        mine = list(range(rank, num_shift_steps, world))
+        mine = parallel.interleaved(num_shift_steps, rank, world)
         frames, errors = {}, {}
         shifted = {i: latent_shifter.shift(init_latent, 0, float(offsets[i])) for i in mine}
         if batch_offsets and len(mine) > 1:
@@ -104,11 +104,7 @@ def shift_ldm(pipeline, num_inference_steps=50, num_shift_steps=16, output_path=
     finally:
         set_unet_attn_processor(unet, dict(previous))
 
-    if world > 1:
-        gathered = [None] * world
-        torch.distributed.all_gather_object(gathered, (frames, errors))
-        frames = {k: v for f, _ in gathered for k, v in f.items()}
-        errors = {k: v for _, e in gathered for k, v in e.items()}
+    frames, errors = parallel.gather_indexed(world, frames, errors)
     ordered = [frames[i] for i in sorted(frames)]
     if ordered and rank == 0 and output_path:
         save_gif_from_tensors(ordered, output_path, denorm=True)
@@ -165,7 +161,7 @@ def shift_ldm_sr(pipeline, num_inference_steps=50, num_shift_steps=16, output_pa
         rec_img = vae_decode(vae, denoised)
         offsets = torch.linspace(1 / ratio, num_shift_steps / ratio, num_shift_steps)
         frames, errors = {}, {}
-        mine = list(range(rank, num_shift_steps, world))
+        mine = parallel.interleaved(num_shift_steps, rank, world)
         shifts = {i: latent_shifter.shift(init_latent, 0, float(offsets[i])) for i in mine}
         if batch_offsets and len(mine) > 1:      # one batched LOAD pass for this rank's offsets (see shift_ldm)
             den_all = denoise(torch.cat([shifts[i][0] for i in mine], 0))
@@ -184,11 +180,7 @@ def shift_ldm_sr(pipeline, num_inference_steps=50, num_shift_steps=16, output_pa
     finally:
         set_unet_attn_processor(unet, dict(previous))
 
-    if world > 1:
-        gathered = [None] * world
-        torch.distributed.all_gather_object(gathered, (frames, errors))
-        frames = {k: v for f, _ in gathered for k, v in f.items()}
-        errors = {k: v for _, e in gathered for k, v in e.items()}
+    frames, errors = parallel.gather_indexed(world, frames, errors)
     ordered = [frames[i] for i in sorted(frames)]
     if ordered and rank == 0 and output_path:
         save_gif_from_tensors(ordered, output_path, denorm=True)

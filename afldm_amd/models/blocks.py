@@ -280,7 +280,10 @@ class ResnetBlock2D(nn.Module):
         gamma, beta = packed_norm(norm)
         stats = ops.gn_stats(x1, norm.num_groups, x2=x2)
         if isinstance(self.nonlinearity, WarpedNonlinearity):
-            return ops.af_act(x1, x2, stats, gamma, beta, norm.num_groups, norm.eps)
+            if self.nonlinearity.fused_silu:
+                return ops.af_act(x1, x2, stats, gamma, beta, norm.num_groups, norm.eps)
+            # a wrapped module other than SiLU: GroupNorm pass, then the module's own (unfused) alias-free form
+            return self.nonlinearity(ops.gn_apply(x1, stats, gamma, beta, norm.num_groups, norm.eps, act=0, x2=x2))
         return ops.gn_apply(x1, stats, gamma, beta, norm.num_groups, norm.eps, act=1, x2=x2)
 
     def _conv1_norm2_act_fused(self, h, temb_proj, temb_stride):
@@ -289,7 +292,7 @@ class ResnetBlock2D(nn.Module):
         intermediate.  Returns None when this shape / plan does not qualify (the caller runs the ordinary sequence)."""
         from ..af_modules.af_blocks import WarpedNonlinearity
         if (os.environ.get("AFLDM_NO_FUSED_ACT") or not isinstance(self.nonlinearity, WarpedNonlinearity)
-                or isinstance(h, tuple) or h.ndim != 4 or h.shape[1] != h.shape[2] or h.shape[1] not in (2, 4)):
+                or not self.nonlinearity.fused_silu or isinstance(h, tuple) or h.ndim != 4 or h.shape[1] != h.shape[2] or h.shape[1] not in (2, 4)):
             return None
         B, N, _, Cin = h.shape
         conv, norm = self.conv1, self.norm2

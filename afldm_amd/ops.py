@@ -488,17 +488,33 @@ def attention_dense(q, k, vt, scale):
     """Single-head attention with a large head_dim (the VAE mid block: d = 512, T = 1024) as two
     per-sample GEMMs around a row softmax.  q, k: [B, T, C] contiguous; vt: [B, C, T]."""
     B, T, C = q.shape
+    Tk = k.shape[1]
+    if k.shape[0] != B or tuple(k.shape) != (B, Tk, C) or tuple(vt.shape) != (B, C, Tk):
+        raise RuntimeError(f"afldm_amd: attention_dense needs k [B, Tk, C] and vt [B, C, Tk] with q's batch; got q "
+                           f"{tuple(q.shape)}, k {tuple(k.shape)}, vt {tuple(vt.shape)} (repeat shared K / V over the batch)")
+    _dev(q, "q"), _dev(k, "k"), _dev(vt, "vt")
     out = torch.empty_like(q)
-    if _BATCHED_DENSE_ATTN and q.dtype == torch.bfloat16 and T % 128 == 0 and C % 64 == 0 and B * T * max(T, C) * 2 < (1 << 31):
+    if (_BATCHED_DENSE_ATTN and q.dtype == torch.bfloat16 and Tk == T and T % 128 == 0 and C % 64 == 0
+            and B * T * max(T, C) * 2 < (1 << 31)):
         # the whole batch in three launches: sample b's K_b / V_b^T are the "weights" of its rows (afldm_conv_args.w_batch_stride)
-        s = conv2d(q.view(B, T, 1, C), k[0].view(T, 1, 1, C), w_batch_stride=T * C)          # [B, T, 1, T] scores
-        p = softmax_rows(s.view(B * T, T), scale)
-        conv2d(p.view(B, T, 1, T), vt[0].view(C, 1, 1, T), w_batch_stride=C * T, out=out.view(B, T, 1, C))
-        return out
+        try:
+            s = conv2d(q.view(B, T, 1, C), k[0].view(T, 1, 1, C), w_batch_stride=T * C)      # [B, T, 1, T] scores
+        except RuntimeError as e:
+            if "w_batch_stride" not in str(e):
+                raise
+            s = None       # the plan for this shape splits K / has a tile that straddles samples: per-sample launches below
+        if s is not None:
+            p = softmax_rows(s.view(B * T, T), scale)
+            try:
+                conv2d(p.view(B, T, 1, T), vt[0].view(C, 1, 1, T), w_batch_stride=C * T, out=out.view(B, T, 1, C))
+                return out
+            except RuntimeError as e:
+                if "w_batch_stride" not in str(e):
+                    raise
     for b in range(B):
-        s = conv2d(q[b].view(1, T, 1, C), k[b].view(T, 1, 1, C))                # [1, T, 1, T] scores
-        p = softmax_rows(s.view(T, T), scale)
-        conv2d(p.view(1, T, 1, T), vt[b].view(C, 1, 1, T), out=out[b].view(1, T, 1, C))
+        s = conv2d(q[b].view(1, T, 1, C), k[b].view(Tk, 1, 1, C))               # [1, T, 1, Tk] scores
+        p = softmax_rows(s.view(T, Tk), scale)
+        conv2d(p.view(1, T, 1, Tk), vt[b].view(C, 1, 1, Tk), out=out[b].view(1, T, 1, C))
     return out
 
 
@@ -588,6 +604,7 @@ def upfirdn2d(x, f, upx=1, upy=1, downx=1, downy=1, padx0=0, padx1=0, pady0=0, p
 
 # ----------------------------------------------------------------------------- conv / linear
 _SYNC = {}
+_SYNC_SPARE = {}
 
 
 def _sync_words(device):
@@ -596,7 +613,19 @@ def _sync_words(device):
     (DenoiseEngine branches) must not share tile counters."""
     key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     if key not in _SYNC:
-        _SYNC[key] = torch.zeros(16384, dtype=torch.int32, device=device)
+        # never allocate under graph capture (the buffer would live in that graph's private pool while this dict hands
+        # it to later graphs and eager launches, ADVICE r03): streams first seen during a capture - torch's capture
+        # stream, the engine's branch streams - take a buffer from a spare list filled on the first eager call
+        spares = _SYNC_SPARE.setdefault(str(device), [])
+        if torch.cuda.is_current_stream_capturing():
+            if not spares:
+                raise RuntimeError("afldm_amd: no pre-allocated sync buffer left for a stream first seen under graph "
+                                   "capture; run one eager step (warm-up) before capturing")
+            _SYNC[key] = spares.pop()
+        else:
+            _SYNC[key] = torch.zeros(16384, dtype=torch.int32, device=device)
+            while len(spares) < 8:
+                spares.append(torch.zeros(16384, dtype=torch.int32, device=device))
     return _SYNC[key]
 
 

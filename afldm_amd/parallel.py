@@ -66,6 +66,64 @@ def sample_sharded(denoise_fn, total, shape, seed, rank, world, device):
     return gather_rows(denoise_fn(local), total, rank, world)
 
 
+def interleaved(n, rank, world):
+    """Indices of `n` independent work items (the harness's shift offsets) taken by `rank`: rank, rank + world, ..."""
+    return list(range(rank, n, world))
+
+
+def gather_indexed(world, *dicts):
+    """Each rank holds {index: value} dicts for ITS items (harness: frames, errors); returns the dicts merged over all
+    ranks, on every rank (one all_gather_object: host-side objects - the frames are CPU tensors)."""
+    if world == 1:
+        return dicts
+    gathered = [None] * world
+    dist.all_gather_object(gathered, dicts)
+    return tuple({k: v for part in gathered for k, v in part[j].items()} for j in range(len(dicts)))
+
+
+def run_interleaved(n, rank, world, fn):
+    """fn(indices of this rank) -> tuple of {index: value} dicts; returns the merged dicts (every rank)."""
+    return gather_indexed(world, *fn(interleaved(n, rank, world)))
+
+
+def rccl_record(device, local_rank, payload=None):
+    """What bench.py prints about the process group so that a multi-GPU line proves N ranks ran: world size, backend,
+    every rank's device, and the time of the sampler's ONE collective (all-gather of the final latents) on its own."""
+    import time
+    if not dist.is_initialized():
+        return None
+    world, rank = dist.get_world_size(), dist.get_rank()
+    on_gpu = torch.device(device).type == "cuda"
+    me = {"rank": rank, "local_rank": local_rank, "pid": os.getpid(),
+          "device": torch.cuda.get_device_name(device) if on_gpu else "cpu",
+          "uuid": str(getattr(torch.cuda.get_device_properties(device), "uuid", "")) if on_gpu else ""}
+    ranks = [None] * world
+    dist.all_gather_object(ranks, me)
+    rec = {"world_size": world, "backend": dist.get_backend(), "ranks": ranks,
+           "distinct_devices": len({(r["local_rank"], r["uuid"]) for r in ranks})}
+    if payload is not None:
+        out = torch.empty((world * payload.shape[0],) + tuple(payload.shape[1:]), dtype=payload.dtype, device=payload.device)
+        dist.all_gather_into_tensor(out, payload)
+        sync = torch.cuda.synchronize if on_gpu else (lambda: None)
+        sync()
+        dist.barrier()
+        reps = 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dist.all_gather_into_tensor(out, payload)
+        sync()
+        dt = (time.perf_counter() - t0) / reps
+        # every rank's block must be that rank's payload: compare block checksums with the owners' own
+        mine = payload.double().sum().reshape(1)
+        sums = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(sums, mine)
+        n = payload.shape[0]
+        ok = all(bool(torch.equal(out[r * n:(r + 1) * n].double().sum().reshape(1), sums[r])) for r in range(world))
+        rec.update(all_gather_us=round(1e6 * dt, 1), all_gather_bytes=out.numel() * out.element_size(),
+                   all_gather_verified=ok)
+    return rec
+
+
 def barrier():
     if dist.is_initialized():
         dist.barrier()

@@ -30,7 +30,14 @@ class I2SBLDMPipeline(MyLDMPipeline):
         leaves before its last timestep (i2sb_pipeline.py:48-50)."""
         sched, unet = self.scheduler, self.unet
         sched.set_timesteps(steps)
+        # The latent is carried in fp32 BETWEEN evaluations whatever the UNet's dtype (as DenoiseEngine does for DDIM): a
+        # step of the 100-step bridge moves the latent by about one bf16 ulp, and a latent stored in bf16 - what the
+        # reference does with a bf16 UNet (i2sb_pipeline.py:41; scheduler.step returns the sample's dtype) - loses 0.11
+        # rel-RMS over the 99 evaluations to storage rounding alone (oracle measurement: tests/golden/g16_r04_floor.npz).
+        # The UNet still sees its own dtype; the result is returned in the caller's dtype.
+        dtype = latents.dtype
+        latents = latents.to(torch.float32)
         for t in self.progress_bar(sched._timesteps_host[:steps - 1]):
-            prediction = unet(sched.scale_model_input(latents, t), t).sample
+            prediction = unet(sched.scale_model_input(latents, t).to(unet.dtype), t).sample
             latents = sched.step(prediction, t, latents, is_ode=is_ode, generator=generator).prev_sample
-        return latents
+        return latents.to(dtype)

@@ -51,11 +51,18 @@ class MyLDMPipeline(DiffusionPipeline):
     def __call__(self, batch_size=1, generator=None, eta=0.0, num_inference_steps=50, latents=None,
                  output_type="pil", return_dict=True, use_graph=True, **kwargs):
         self.scheduler = DDIMScheduler.from_config(self.scheduler.config)
-        if eta != 0.0:
-            raise NotImplementedError("eta != 0 is not used by the reference scripts")
         if latents is None:
             latents = randn_tensor((batch_size, self.unet.config.in_channels, self.unet.config.sample_size,
                                     self.unet.config.sample_size), generator=generator)
+        if eta != 0.0:
+            # stochastic DDIM (reference ldm_pipeline.py:96-109 forwards eta to scheduler.step): the per-step noise comes
+            # from the caller's generator on the host, so this is the eager loop, not the captured graph
+            self.scheduler.set_timesteps(num_inference_steps)
+            latents = latents.to(device=self.unet.device, dtype=self.unet.dtype)
+            for t in self.progress_bar(self.scheduler._timesteps_host):
+                eps = self.unet(latents, t).sample
+                latents = self.scheduler.step(eps, t, latents, eta=eta, generator=generator).prev_sample
+            return self._deliver(latents, output_type, return_dict)
         eng = self._engine(latents.shape[0], num_inference_steps, use_graph)
         eng.scheduler = self.scheduler
         latents = eng.run(latents).to(self.unet.dtype)

@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from ..utils import randn_tensor
 from ..configs import FFHQ_DDIM_CONFIG, FrozenConfig
 
 
@@ -85,6 +86,14 @@ class DDIMScheduler:
         a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
         return (float(a_t ** 0.5), float((1 - a_t) ** 0.5), float(a_prev ** 0.5), float((1 - a_prev) ** 0.5))
 
+    def _variance(self, timestep):
+        """diffusers DDIMScheduler._get_variance: (1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev), as a float."""
+        t = int(timestep)
+        prev_t = t - self.config.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+        return float((1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev))
+
     def coefficient_table(self, device):
         """float32 [nsteps, 4] device table for the graph-replayed loop (afldm_ddim_step)."""
         rows = [self.coefficients(t) for t in self._timesteps_host]
@@ -94,15 +103,31 @@ class DDIMScheduler:
              variance_noise=None, return_dict=True):
         if self.num_inference_steps is None:
             raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' first")
-        if eta != 0.0 or self.config.clip_sample or self.config.prediction_type != "epsilon":
-            raise NotImplementedError("afldm_amd.DDIMScheduler implements the reference's setting: eta=0, "
+        if self.config.clip_sample or self.config.prediction_type != "epsilon":
+            raise NotImplementedError("afldm_amd.DDIMScheduler implements the reference's setting: "
                                       "epsilon prediction, clip_sample=False")
         if not sample.is_cuda:
             raise RuntimeError("afldm_amd.DDIMScheduler.step runs on MI355X tensors only (no CPU path)")
         c = self.coefficients(timestep)
         x = sample.to(torch.float32).contiguous()
         e = model_output.to(torch.float32).contiguous()
-        prev = ops.ddim_step_flat(x, e, c).to(sample.dtype)
+        if eta == 0.0:
+            prev = ops.ddim_step_flat(x, e, c).to(sample.dtype)
+        else:
+            # diffusers DDIMScheduler.step with eta > 0 (the reference forwards `eta`, ldm_pipeline.py:38,96-101):
+            # sigma_t = eta sqrt((1 - a_prev) / (1 - a_t) (1 - a_t / a_prev)); the direction coefficient becomes
+            # sqrt(1 - a_prev - sigma_t^2) and sigma_t * noise is added (noise drawn like diffusers: randn_tensor with the
+            # caller's generator, on the CPU for a CPU generator)
+            sigma = float(eta) * self._variance(timestep) ** 0.5
+            a_prev = c[2] * c[2]
+            prev = ops.ddim_step_flat(x, e, (c[0], c[1], c[2], float(max(1.0 - a_prev - sigma * sigma, 0.0) ** 0.5)))
+            if variance_noise is not None and generator is not None:
+                raise ValueError("Cannot pass both generator and variance_noise. Please make sure that either `generator` "
+                                 "or `variance_noise` stays `None`.")
+            if variance_noise is None:
+                variance_noise = randn_tensor(model_output.shape, generator=generator, device=model_output.device,
+                                              dtype=model_output.dtype)
+            prev = (prev + sigma * variance_noise.to(torch.float32)).to(sample.dtype)
         if not return_dict:
             return (prev,)
         return DDIMSchedulerOutput(prev_sample=prev)

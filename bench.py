@@ -300,6 +300,9 @@ def side_config(batch, dtype, steps=20, regions=3):
         ts.append(time.perf_counter() - t0)
     dt = median(ts)
     finite = bool(torch.isfinite(eng.lat).all().item())
+    # the process group as it actually ran (every rank takes part): world size, backend, each rank's device, and the
+    # sampler's one collective timed on its own + verified block by block
+    rccl = parallel.rccl_record(dev, local, payload=eng.lat) if world > 1 else None
     del eng, unet
     torch.cuda.empty_cache()
     return dict(batch=batch, dtype="bf16" if dtype == torch.bfloat16 else "fp32", steps=steps, regions=regions,
@@ -434,6 +437,9 @@ def main():
     regions = timed_regions(run_steps, args.steps, max(1, args.regions), world, dev)
     dt = median(regions)
     finite = bool(torch.isfinite(eng.lat).all().item())
+    # the process group as it actually ran (every rank takes part): world size, backend, each rank's device, and the
+    # sampler's one collective timed on its own + verified block by block
+    rccl = parallel.rccl_record(dev, local, payload=eng.lat) if world > 1 else None
 
     if rank == 0:
         out = {
@@ -460,6 +466,8 @@ def main():
                                  "synchronize, MAX over ranks",
                        "regions_ms_per_step": [round(1e3 * r / args.steps, 4) for r in regions]},
         }
+        out["rccl"] = rccl if rccl is not None else {"world_size": 1, "backend": None,
+                                                     "note": "single process: no process group, no collective"}
         out["box"] = box_record(dev)
         if not args.no_roofline:
             roof, fam = roofline_pass(unet, B, dtype)

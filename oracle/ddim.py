@@ -40,16 +40,23 @@ class DDIM:
     def scale_model_input(self, sample, t=None):
         return sample
 
-    def step(self, eps, t, sample, eta=0.0):
+    def step(self, eps, t, sample, eta=0.0, generator=None):
         t = int(t)
         prev_t = t - self.cfg["num_train_timesteps"] // self.num_inference_steps
         a_t = self.alphas_cumprod[t]
         a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
         beta_t = 1 - a_t
         x0 = (sample - beta_t ** 0.5 * eps) / a_t ** 0.5
-        assert not self.cfg["clip_sample"] and eta == 0.0
-        direction = (1 - a_prev) ** 0.5 * eps
-        return a_prev ** 0.5 * x0 + direction
+        assert not self.cfg["clip_sample"]
+        # diffusers 0.32.1 scheduling_ddim.py step(): sigma_t = eta sqrt(variance), direction sqrt(1 - a_prev - sigma_t^2) eps,
+        # + sigma_t * randn(generator) for eta > 0 (parity unpinned like the rest of the diffusers restatement)
+        variance = (1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev)
+        std_dev_t = eta * variance ** 0.5
+        direction = (1 - a_prev - std_dev_t ** 2) ** 0.5 * eps
+        prev = a_prev ** 0.5 * x0 + direction
+        if eta > 0:
+            prev = prev + std_dev_t * torch.randn(eps.shape, generator=generator, dtype=eps.dtype)
+        return prev
 
     def coefficients(self, t):
         """(sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)) as python floats."""

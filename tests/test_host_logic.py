@@ -159,6 +159,49 @@ print("OK", rank)
 """
 
 
+_WORKER_OFFSETS = r"""
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from afldm_amd import parallel
+rank, world, _ = parallel.init_distributed("gloo")
+n = int(sys.argv[2])
+# the harness's offset sharding (harness.shift_ldm / shift_ldm_sr) on a stub "denoiser": per-offset frames
+# (CPU tensors) and errors (floats), interleaved over ranks, merged by ONE all_gather_object
+def per_rank(mine):
+    frames = {i: torch.full((1, 3, 4, 4), float(i)) * torch.arange(4.).view(1, 1, 4, 1) for i in mine}
+    errors = {i: 0.5 * i + 0.25 for i in mine}
+    return frames, errors
+frames, errors = parallel.run_interleaved(n, rank, world, per_rank)
+f1, e1 = per_rank(list(range(n)))
+assert sorted(frames) == list(range(n)) == sorted(errors), (rank, sorted(frames))
+assert all(torch.equal(frames[i], f1[i]) for i in range(n)) and errors == e1
+assert parallel.interleaved(n, rank, world) == list(range(rank, n, world))
+rec = parallel.rccl_record("cpu", rank, payload=torch.full((3, 4), float(rank)))
+assert rec["world_size"] == 2 and rec["backend"] == "gloo" and rec["all_gather_verified"] and len(rec["ranks"]) == 2
+assert sorted(r["rank"] for r in rec["ranks"]) == [0, 1] and rec["all_gather_bytes"] == 2 * 3 * 4 * 4
+parallel.barrier()
+print("OK", rank)
+"""
+
+
+@pytest.mark.parametrize("n", [16, 5])
+def test_two_process_gloo_harness_offset_sharding(tmp_path, n):
+    """harness.shift_ldm's multi-GPU leg (SURVEY.md 8e 'Harness variant'): offsets interleaved over ranks, results merged
+    once; plus the process-group record bench.py prints (world size, backend, ranks, the all-gather verified)."""
+    import inspect
+    from afldm_amd import harness
+    src = inspect.getsource(harness)
+    assert src.count("parallel.interleaved(") == 2 and src.count("parallel.gather_indexed(") == 2
+    script = tmp_path / "worker_offsets.py"
+    script.write_text(_WORKER_OFFSETS)
+    port = 29950 + (os.getpid() % 40) + n
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(script), ROOT, str(n)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("OK") == 2
+
+
 @pytest.mark.parametrize("total", [8, 7])
 def test_two_process_gloo_sharded_sampling(tmp_path, total):
     script = tmp_path / "worker.py"

@@ -231,3 +231,118 @@ def test_image_samplers_and_general_cutoff_oracle_vs_reference(golden):
     np.testing.assert_allclose(idf.lpf_recon_rfft(xz.clone(), 0.5).numpy(), g["recon_fft"], rtol=0, atol=2e-6)
     assert np.array_equal(idf.upsample_rfft(xz[:, :, :12, :12].clone(), 4).numpy(), g["up4"])
     assert np.array_equal(idf.upsample_rfft(xz[:, :, :12, :12].clone(), 2, factor=0.5).numpy(), g["up2_f2"])
+
+
+# ----------------------------------------------------------------------------- round 4: pins of reference-resident files
+def test_i2sb_oracle_vs_reference_file(golden):
+    """oracle/i2sb.py against fixtures recorded by importing /root/reference/afldm/schedulers/i2sb_scheduler.py under a
+    plumbing-only diffusers stub (oracle/gen_golden.py part i): tables, timesteps, ODE and seeded stochastic steps with
+    clip_sample off / on, add_noise, compute_label - bit-equal."""
+    from oracle.i2sb import I2SB
+    g = golden("g15_r04_refpins.npz")
+    o = I2SB()
+    for name in ("betas", "std_fwd", "std_bwd", "std_sb", "mu_x0", "mu_x1"):
+        assert torch.equal(getattr(o, name), t(g[f"i2sb_{name}"])), name
+    for n in (50, 100):
+        o.set_timesteps(n)
+        assert torch.equal(o.timesteps, t(g[f"i2sb_timesteps_{n}"]))
+    x, e = t(g["i2sb_step_x"]), t(g["i2sb_step_eps"])
+
+    def same(a, b):       # bit-equal, NaN == NaN: at t = 1 of the 100-step schedule prev_t = -9 indexes std_fwd from the
+        return torch.equal(torch.nan_to_num(a, nan=12345.0), torch.nan_to_num(b, nan=12345.0))   # END of the table and the
+    #                       reference itself returns NaN (std_delta = sqrt(negative)); its pipeline never takes that step
+    #                       (i2sb_pipeline.py:48 iterates timesteps[:-1]) - the oracle must reproduce that, too
+    assert np.isnan(g["i2sb_step_ode_noclip_1"]).all()
+    for clip, tag in ((False, "noclip"), (True, "clip")):
+        o = I2SB(clip_sample=clip)
+        o.set_timesteps(100)
+        for ts in (991, 501, 11, 1):
+            prev, x0 = o.step(e, ts, x, is_ode=True, return_x0=True)
+            assert same(prev, t(g[f"i2sb_step_ode_{tag}_{ts}"])), (tag, ts)
+            assert torch.equal(x0, t(g[f"i2sb_step_x0_{tag}_{ts}"]))
+            sde = o.step(e, ts, x, is_ode=False, generator=torch.Generator().manual_seed(1000 + ts))
+            assert same(sde, t(g[f"i2sb_step_sde_{tag}_{ts}"])), (tag, ts)
+            assert ts == 1 or not torch.equal(sde, prev)
+            assert o.previous_timestep(ts) == int(g[f"i2sb_prev_t_{ts}"])
+    # the clamp must have been exercised by the fixture (|x0| > 1 somewhere without it)
+    assert np.abs(g["i2sb_step_x0_noclip_991"]).max() > 1.0 and np.abs(g["i2sb_step_x0_clip_991"]).max() <= 1.0
+    o = I2SB()
+    x0, x1, nz, ts = t(g["i2sb_x0"]), t(g["i2sb_x1"]), t(g["i2sb_noise"]), t(g["i2sb_ts"])
+    assert torch.equal(o.add_noise(x0, x1, ts, is_ode=True), t(g["i2sb_add_noise_ode"]))
+    xt = o.add_noise(x0, x1, ts, noise=nz, is_ode=False)
+    assert torch.equal(xt, t(g["i2sb_add_noise_sde"]))
+    assert torch.equal(o.compute_label(ts, x0, xt), t(g["i2sb_label"]))
+
+
+def test_product_i2sb_host_tables_vs_reference_file(golden):
+    """The product scheduler's host-side tables / timesteps / add_noise / compute_label are the reference file's, bit for
+    bit (its `step` runs on the GPU: tests/test_gpu_r04.py)."""
+    from afldm_amd.configs import FFHQ_DDIM_CONFIG
+    from afldm_amd.schedulers.i2sb import I2SBScheduler
+    g = golden("g15_r04_refpins.npz")
+    s = I2SBScheduler.from_config({k: v for k, v in FFHQ_DDIM_CONFIG.items() if k != "set_alpha_to_one"})
+    for name in ("betas", "std_fwd", "std_bwd", "std_sb", "mu_x0", "mu_x1"):
+        assert torch.equal(getattr(s, name), t(g[f"i2sb_{name}"])), name
+    for n in (50, 100):
+        s.set_timesteps(n)
+        assert torch.equal(s.timesteps, t(g[f"i2sb_timesteps_{n}"]))
+    for ts in (991, 501, 11, 1):
+        assert s.previous_timestep(ts) == int(g[f"i2sb_prev_t_{ts}"])
+    x0, x1, nz, ts = t(g["i2sb_x0"]), t(g["i2sb_x1"]), t(g["i2sb_noise"]), t(g["i2sb_ts"])
+    assert torch.equal(s.add_noise(x0, x1, ts, is_ode=True), t(g["i2sb_add_noise_ode"]))
+    xt = s.add_noise(x0, x1, ts, is_ode=False, noise=nz)
+    assert torch.equal(xt, t(g["i2sb_add_noise_sde"]))
+    assert torch.equal(s.compute_label(ts, x0, xt), t(g["i2sb_label"]))
+
+
+@pytest.mark.parametrize("N", [8, 16])
+def test_af_block_forward_bodies_vs_reference_file(golden, N):
+    """oracle.ideal_filters.af_downsample / af_upsample / warped_nonlinearity against the forward() bodies of
+    /root/reference/afldm/af_modules/af_blocks.py run under stub base classes (part i): padding 1 and the padding == 0
+    branch (explicit (1,1,1,1) pad, af_blocks.py:143-145), the bf16 -> fp32 cast around the resampler (:80-96)."""
+    g = golden("g15_r04_refpins.npz")
+    x = t(g[f"afb_x_{N}"])
+    for pad in (1, 0):
+        got = idf.af_downsample(x, t(g[f"afb_down_w_{N}_{pad}"]), t(g[f"afb_down_b_{N}_{pad}"]), padding=pad)
+        ref = t(g[f"afb_down_{N}_{pad}"])
+        assert got.shape == ref.shape == (2, x.shape[1], N // 2, N // 2)
+        assert torch.equal(got, ref), pad
+    w, b = t(g[f"afb_up_w_{N}"]), t(g[f"afb_up_b_{N}"])
+    assert torch.equal(idf.af_upsample(x, w, b), t(g[f"afb_up_{N}"]))
+    # bf16: resample in fp32, round, convolve in bf16
+    xb = x.to(torch.bfloat16)
+    up = idf.upsample_rfft(xb.float(), 2).to(torch.bfloat16)
+    got = F.conv2d(up, w.to(torch.bfloat16), b.to(torch.bfloat16), padding=1).float()
+    assert torch.equal(got, t(g[f"afb_up_bf16_{N}"]))
+
+
+def test_warped_nonlinearity_module_vs_reference_file(golden):
+    """WarpedNonlinearity.forward (af_blocks.py:19-28): ndim < 4 -> the plain nonlinearity; any wrapped module works."""
+    g = golden("g15_r04_refpins.npz")
+    assert torch.equal(idf.warped_nonlinearity(t(g["afb_wn_2d_in"])), t(g["afb_wn_2d_out"]))
+    x = t(g["afb_wn_4d_in"])
+    assert torch.equal(idf.warped_nonlinearity(x), t(g["afb_wn_4d_out"]))
+    assert torch.equal(idf.warped_nonlinearity(x, torch.tanh), t(g["afb_wn_tanh_out"]))
+
+
+def test_cross_frame_control_flow_vs_reference_file(golden):
+    """oracle.unet.attention_block's STORE / LOAD / batch-repeat / enable_interp logic against
+    /root/reference/afldm/pipelines/cross_frame_attn.py:66-130 driven on the same layers (part i; the base
+    AttnProcessor2_0 both sides call is the oracle's diffusers restatement, which stays unpinned)."""
+    g = golden("g15_r04_refpins.npz")
+    sd = {"a." + k[len("cfa_sd_"):]: t(g[k]) for k in g.files if k.startswith("cfa_sd_")}
+    cfg = dict(attention_head_dim=16, norm_num_groups=8, norm_eps=1e-5)
+    cache = unet.AttnCache(enable_interp=True)
+    c = unet._Ctx(sd, cfg, True, cache, None)
+    xa, xb, xq = t(g["cfa_xa"]), t(g["cfa_xb"]), t(g["cfa_xq"])
+    cache.state, cache.timestep = unet.AttnCache.STORE, 7
+    assert torch.equal(unet.attention_block(c, "a", xa), t(g["cfa_store0"]))
+    cache.store_id = 1
+    assert torch.equal(unet.attention_block(c, "a", xb), t(g["cfa_store1"]))
+    cache.state, cache.alpha = unet.AttnCache.LOAD, 0.3
+    assert torch.equal(unet.attention_block(c, "a", xq), t(g["cfa_load_interp"]))
+    cache.enable_interp = False
+    assert torch.equal(unet.attention_block(c, "a", xq), t(g["cfa_load"]))
+    cache.state = unet.AttnCache.IDLE
+    assert torch.equal(unet.attention_block(c, "a", xq), t(g["cfa_idle"]))
+    assert not torch.equal(t(g["cfa_load"]), t(g["cfa_idle"]))
