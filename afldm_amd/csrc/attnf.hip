@@ -1,0 +1,406 @@
+// attnf.hip — the attention block's front end as ONE launch (round 4):
+//   GroupNorm-apply -> per-head q | k | v projection -> softmax(q k^T * scale) v
+// for the self-attention blocks of the 32^2 / 16^2 levels (AttnProcessor2_0 on the deprecated attention-block
+// configuration; reference cross_frame_attn.py:66-130 IDLE branch = diffusers AttnProcessor2_0).  bf16 only.
+//
+// The three-launch form (k_gn_apply, k_lin_wreg, k_attn) exists to move data: at batch 64 the projection writes 634 MB
+// of q | k | v^T per step that attention reads straight back (641 MB), and the attention kernel re-stages every K / V^T
+// chunk once per 256 queries behind a workgroup barrier.  Here a workgroup owns ONE (sample, head):
+//
+//   phase A  each wave projects ITS tokens (32-token tiles): the raw token rows come straight from global memory as
+//            MFMA fragments (lane (token, half) streams one contiguous half row: the K index of the contraction is
+//            permuted accordingly, the weight fragments follow), GroupNorm is applied in registers from the producer's
+//            partial sums (scale / shift per channel in LDS), q / k / v are three 32x32x16 MFMA chains against the head's
+//            72 weight rows held in LDS.  K and V^T are written to LDS ONCE, in the fragment order the attention loop
+//            reads; Q never leaves the registers (the projection's accumulator layout IS the B-fragment layout after a
+//            fixed permutation of the weight rows).
+//   phase B  flash attention over the resident K / V^T: no global loads, no staging, NO workgroup barrier - the waves
+//            run free.  S^T = K Q^T so the softmax is lane-local, the running reference is subtracted by the MFMA
+//            (K carries a 1, Q carries -m in the padding channel head_dim -> 32), the row sums come from a row of ones
+//            in V^T, rescaling is lazy (only when a score outgrows the reference by 2^10).  The next tile's S^T MFMAs
+//            are issued before the current tile's exponentials so that matrix and vector pipes overlap inside a wave.
+//
+// x is read once per head from the XCD's L2 (the heads of a sample run on one XCD), q | k | v never exist in HBM.
+#include "common.hpp"
+
+namespace afldm {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct AttnFP {
+  const bf16* x;       // [B][T][C] raw (pre-norm) tokens
+  const bf16* w;       // [3C][C]: to_q | to_k | to_v rows
+  const float* bias;   // [3C]
+  const float* gamma;  // [C]
+  const float* beta;   // [C]
+  GnStats gs;          // per-channel partial sums of x (st1 [B][S][C][2])
+  bf16* o;             // [B][T][C]
+  int B, heads, C, G;
+  float eps, qscale;   // qscale = softmax scale * log2(e)
+};
+
+__device__ __forceinline__ f32x16 mfma32(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+constexpr float ATT_TAU = 10.0f;   // lazy rescale threshold (log2 units)
+
+// D = head_dim (16 / 24), NW = waves, TPW = 32-token tiles per wave (T = 32 NW TPW), CK = C / 16 (K steps).
+template <int D, int NW, int TPW, int CK>
+struct AttnFCfg {
+  static constexpr int T = NW * TPW * 32, NT = T / 32, C = CK * 16;
+  static constexpr int RK = D * 2;                      // K row bytes (real channels only)
+  static constexpr int K_BYTES = T * RK;
+  static constexpr int V_BYTES = NT * 2 * 2 * D * 16;   // [tile][j][hi][d] x 16 B
+  static constexpr int CST_BYTES = 64;                  // [0,16) K pad chunk {1,0,..}; [16,32) ones; [32,48) zeros
+  static constexpr int RW = C * 2 + 16;                 // weight row stride (bank-conflict-free ds_read_b128)
+  static constexpr int W_BYTES = 3 * D * RW;
+  static constexpr int AS_BYTES = C * 8;                // a[C], s[C] fp32
+  static constexpr int BIAS_BYTES = 3 * 32 * 4;         // q | k | v biases of this head, padded to 32, fp32
+  static constexpr int OFF_K = 0, OFF_V = OFF_K + K_BYTES, OFF_CST = OFF_V + V_BYTES, OFF_W = OFF_CST + CST_BYTES,
+                       OFF_AS = OFF_W + W_BYTES, OFF_BIAS = OFF_AS + AS_BYTES, LDS_BYTES = OFF_BIAS + BIAS_BYTES;
+  static constexpr int NU = TPW >= 2 ? 2 : 1;           // query tiles per attention pass
+  static constexpr int PADC = D / 16, PADHI = (D % 16) / 8;   // where slot D sits: chunk, lane half (element 0)
+};
+
+template <int D, int NW, int TPW, int CK>
+__global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
+  typedef AttnFCfg<D, NW, TPW, CK> CF;
+  constexpr int T = CF::T, NT = CF::NT, C = CF::C, RK = CF::RK, RW = CF::RW, NU = CF::NU, NTHR = NW * 64;
+  static_assert(D == 16 || D == 24, "head_dim 16 / 24");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem + CF::OFF_K;
+  char* sV = smem + CF::OFF_V;
+  char* sC = smem + CF::OFF_CST;
+  char* sW = smem + CF::OFF_W;
+  float* sA = reinterpret_cast<float*>(smem + CF::OFF_AS);
+  float* sS = sA + C;
+  float* sB = reinterpret_cast<float*>(smem + CF::OFF_BIAS);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 31, hi = lane >> 5;
+  // the heads of a sample (and neighbouring samples) on one XCD: x is re-read from that XCD's L2
+  const int wi = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = wi / p.heads, h = wi - b * p.heads;
+
+  // ------------------------------------------------------------------ prologue
+  // (1) this wave's first token tile: lane (token, half) streams half a row, CK x 16 B (in flight during the rest)
+  const bf16* xrow0 = p.x + ((size_t)b * T + (size_t)wave * TPW * 32 + ln) * C + hi * (C / 2);
+  bf16x8 xr[CK];
+#pragma unroll
+  for (int kk = 0; kk < CK; ++kk) xr[kk] = ld16<bf16x8>(xrow0 + kk * 8);
+
+  // (2) the head's 3 D weight rows -> LDS (padded rows), biases, constants
+  constexpr int WPR = C / 8;                                   // 16-byte pieces per weight row
+  for (int id = tid; id < 3 * D * WPR; id += NTHR) {
+    const int row = id / WPR, pc = id - row * WPR;
+    const int m = row / D, r = row - m * D;
+    const bf16x8 v = ld16<bf16x8>(p.w + ((size_t)m * C + h * D + r) * C + pc * 8);
+    st16<bf16x8>(sW + row * RW + pc * 16, v);
+  }
+  if (tid < 96) {
+    const int m = tid >> 5, r = tid & 31;
+    sB[tid] = r < D ? p.bias[m * C + h * D + r] : 0.f;
+  }
+  if (tid < 3) {
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16)((tid == 1 || (tid == 0 && e == 0)) ? 1.0f : 0.0f);
+    st16<bf16x8>(sC + tid * 16, v);
+  }
+  // (3) GroupNorm scale / shift per channel: quarter-waves take one group each (cpg <= 16)
+  {
+    const int cpg = C / p.G, S = p.gs.S1, q4 = lane >> 4, ql = lane & 15;
+    for (int g0 = 0; g0 < p.G; g0 += NW * 4) {
+      const int g = g0 + wave * 4 + q4;
+      double s1 = 0.0, s2 = 0.0;
+      if (g < p.G) {
+        const float* st = p.gs.st1 + (size_t)b * S * C * 2;
+        for (int j = ql; j < cpg * S; j += 16) {
+          const int cc = j % cpg, sp = j / cpg;          // consecutive lanes: consecutive channels of one split (one run)
+          const f32x2 v = *reinterpret_cast<const f32x2*>(st + ((size_t)sp * C + g * cpg + cc) * 2);
+          s1 += (double)v[0];
+          s2 += (double)v[1];
+        }
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+      }
+      if (g < p.G && ql < cpg) {
+        float mean, rstd;
+        gn_mean_rstd(s1, s2, (double)T * cpg, p.eps, mean, rstd);
+        const int c = g * cpg + ql;
+        const float k = rstd * p.gamma[c];
+        sA[c] = k;
+        sS[c] = p.beta[c] - mean * k;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ phase A: projection
+  // weight fragment rows: q / k use the row permutation sigma (swap bits 2, 3) so that accumulator register 8c + e of
+  // lane (token, half) is channel 16c + 8 half + e: registers 8c .. 8c+7 ARE the B fragment chunk c of Q and one
+  // 16-byte piece of K's row.  Rows >= D read another row (their results are never used).
+  const int sig = (ln & 0x13) | ((ln & 4) << 1) | ((ln & 8) >> 1);
+  // (padding lanes read row - 16: finite data, and a row no other lane of their ds_read_b128 group maps onto)
+  const char* wq_base = sW + (0 * D + (sig < D ? sig : sig - 16)) * RW + hi * C;       // + kk * 16
+  const char* wk_base = sW + (1 * D + (sig < D ? sig : sig - 16)) * RW + hi * C;
+  const char* wv_base = sW + (2 * D + (ln < D ? ln : ln - 16)) * RW + hi * C;
+  const float* a_base = sA + hi * (C / 2);
+  const float* s_base = sS + hi * (C / 2);
+
+  bf16x8 qf[TPW][2];     // Q as B fragments (scaled by scale * log2 e), chunk c = channels 16c + 8 half + e
+#pragma unroll
+  for (int tt = 0; tt < TPW; ++tt) {
+    const int tok0 = (wave * TPW + tt) * 32;               // first token of the tile (within the sample)
+    f32x16 aq, ak, av;
+    {
+      // accumulators start at the bias: q / k lane (token, half): register r = 8c + e -> channel 16c + 8 half + e
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const f32x4 bq0 = ld16<f32x4>(sB + 0 * 32 + 16 * c + 8 * hi), bq1 = ld16<f32x4>(sB + 0 * 32 + 16 * c + 8 * hi + 4);
+        const f32x4 bk0 = ld16<f32x4>(sB + 1 * 32 + 16 * c + 8 * hi), bk1 = ld16<f32x4>(sB + 1 * 32 + 16 * c + 8 * hi + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          aq[8 * c + e] = bq0[e];
+          aq[8 * c + 4 + e] = bq1[e];
+          ak[8 * c + e] = bk0[e];
+          ak[8 * c + 4 + e] = bk1[e];
+        }
+      }
+      const float bv = sB[2 * 32 + ln];                    // v: lane (channel d, half), every register is channel d
+#pragma unroll
+      for (int r = 0; r < 16; ++r) av[r] = bv;
+    }
+    bf16x8 xn[CK];                                          // next tile's rows (prefetched under this tile's products)
+    if (tt + 1 < TPW) {
+#pragma unroll
+      for (int kk = 0; kk < CK; ++kk) xn[kk] = ld16<bf16x8>(xrow0 + (size_t)(tt + 1) * 32 * C + kk * 8);
+    }
+#pragma unroll
+    for (int kk = 0; kk < CK; ++kk) {
+      const f32x4 a0 = ld16<f32x4>(a_base + kk * 8), a1 = ld16<f32x4>(a_base + kk * 8 + 4);
+      const f32x4 s0 = ld16<f32x4>(s_base + kk * 8), s1 = ld16<f32x4>(s_base + kk * 8 + 4);
+      bf16x8 xb;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xb[e] = (bf16)((float)xr[kk][e] * a0[e] + s0[e]);
+        xb[4 + e] = (bf16)((float)xr[kk][4 + e] * a1[e] + s1[e]);
+      }
+      const bf16x8 wq = ld16<bf16x8>(wq_base + kk * 16);
+      const bf16x8 wk = ld16<bf16x8>(wk_base + kk * 16);
+      const bf16x8 wv = ld16<bf16x8>(wv_base + kk * 16);
+      aq = mfma32(wq, xb, aq);            // [channel x token]
+      ak = mfma32(wk, xb, ak);            // [channel x token]
+      av = mfma32(xb, wv, av);            // [token x channel]: lane = channel, registers = tokens
+    }
+    // ---- tile epilogue: Q -> registers, K / V^T -> LDS
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      bf16x8 qv, kv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        qv[e] = (bf16)(aq[8 * c + e] * p.qscale);
+        kv[e] = (bf16)ak[8 * c + e];
+      }
+      const bool real = 16 * c + 8 * hi + 8 <= D;          // this lane's chunk c holds real channels
+      if (!real) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] = (bf16)0.0f;     // slot D (-m) is written by the attention loop
+      }
+      qf[tt][c] = qv;
+      if (real) st16<bf16x8>(sK + (tok0 + ln) * RK + (2 * c + hi) * 16, kv);
+    }
+    if (ln < D) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bf16x8 vv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vv[e] = (bf16)av[8 * j + e];
+        st16<bf16x8>(sV + ((((tok0 >> 5) * 2 + j) * 2 + hi) * D + ln) * 16, vv);
+      }
+    }
+    if (tt + 1 < TPW) {
+#pragma unroll
+      for (int kk = 0; kk < CK; ++kk) xr[kk] = xn[kk];
+    }
+  }
+  __syncthreads();      // K / V^T of every token resident
+
+  // ------------------------------------------------------------------ phase B: attention over the resident K / V^T
+  // per-lane fragment addresses (constants for padding lanes: step 0)
+  const char* k0p = sK + ln * RK + hi * 16;                       // chunk 0: channels 8 half + e (D >= 16)
+  const bool k1real = 16 + 8 * hi + 8 <= D;
+  const char* k1p = k1real ? sK + ln * RK + 32 : sC + (hi == CF::PADHI ? 0 : 32);
+  const int k1step = k1real ? 32 * RK : 0;
+  const bool vreal = ln < D;
+  const char* vp = vreal ? sV + (hi * D + ln) * 16 : sC + (ln == D ? 16 : 32);
+  const int vstep_j = vreal ? 2 * D * 16 : 0, vstep_t = 2 * vstep_j;
+  constexpr int LR = (D / 8) * 4;                                  // accumulator register of row D (the row sums), half 0
+
+#pragma unroll
+  for (int pass = 0; pass < TPW / NU; ++pass) {
+    bf16x8 q[NU][2];
+    f32x16 oacc[NU];
+    float m_run[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      q[u][0] = qf[pass * NU + u][0];
+      q[u][1] = qf[pass * NU + u][1];
+      m_run[u] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[u][r] = 0.f;
+    }
+    auto qk = [&](int t, f32x16 (&s)[NU]) {
+      const bf16x8 kf0 = ld16<bf16x8>(k0p + t * 32 * RK);
+      const bf16x8 kf1 = ld16<bf16x8>(k1p + t * k1step);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        z = mfma32(kf0, q[u][0], z);
+        s[u] = mfma32(kf1, q[u][1], z);
+      }
+    };
+    // move the reference of query tile u to m_new (rounded to bf16: it travels in Q).  `cur` / `nxt`: score tiles already
+    // computed against the old reference (the next tile's MFMAs are issued one step ahead)
+    auto rescale = [&](int u, float mnew_raw, f32x16& cur, f32x16* nxt, bool first) {
+      const float m_new = (float)(bf16)mnew_raw;
+      const float delta = m_new - m_run[u];
+      m_run[u] = m_new;
+      if (hi == CF::PADHI) q[u][CF::PADC][0] = (bf16)(-m_new);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        cur[r] -= delta;
+        if (nxt) (*nxt)[r] -= delta;
+      }
+      if (!first) {                                     // (tile 0: O is still zero, and 2^-delta may overflow)
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[u][r] *= alpha;
+      }
+    };
+    // one key tile: `cur` holds S^T - m of tile t; tile t + 1 is produced into `nxt` FIRST (matrix pipe) so that it
+    // runs under the exponentials of tile t (vector pipe); then O^T += V^T P^T
+    auto step = [&](int t, f32x16 (&cur)[NU], f32x16 (&nxt)[NU]) {
+      const bool more = t + 1 < NT;
+      if (more) qk(t + 1, nxt);
+      float mx[NU];
+      bool grow = false;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        float m = cur[u][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m = fmaxf(m, cur[u][r]);
+        mx[u] = m;
+        grow |= m > ATT_TAU;
+      }
+      if (__any(grow)) {                                 // wave-uniform, rare after tile 0
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const float m = fmaxf(mx[u], __shfl_xor(mx[u], 32, 64));
+          rescale(u, m_run[u] + fmaxf(m, 0.f), cur[u], more ? &nxt[u] : nullptr, false);
+        }
+      }
+      const bf16x8 vf0 = ld16<bf16x8>(vp + t * vstep_t);
+      const bf16x8 vf1 = ld16<bf16x8>(vp + t * vstep_t + vstep_j);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        bf16x8 pb0, pb1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          pb0[e] = (bf16)__builtin_amdgcn_exp2f(cur[u][e]);
+          pb1[e] = (bf16)__builtin_amdgcn_exp2f(cur[u][8 + e]);
+        }
+        oacc[u] = mfma32(vf0, pb0, oacc[u]);
+        oacc[u] = mfma32(vf1, pb1, oacc[u]);
+      }
+    };
+    f32x16 sa[NU], sb[NU];
+    qk(0, sa);
+    // tile 0: the reference is the row maximum of the first tile
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      float m = sa[u][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) m = fmaxf(m, sa[u][r]);
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      rescale(u, m, sa[u], nullptr, true);
+    }
+    static_assert(NT % 2 == 0, "key tiles are walked in pairs (score registers ping-pong)");
+    for (int t = 0; t < NT; t += 2) {
+      step(t, sa, sb);
+      step(t + 1, sb, sa);
+    }
+    // ---- finish: row D of O^T is the softmax denominator (half 0 holds it); normalise, store 4 channels per piece
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      float l = oacc[u][LR];
+      const float lo = __shfl_xor(l, 32, 64);
+      if (hi != 0) l = lo;
+      const float inv = 1.0f / l;
+      const int qrow = (wave * TPW + pass * NU + u) * 32 + ln;
+      bf16* op = p.o + ((size_t)b * T + qrow) * C + h * D;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int d0 = 8 * g4 + 4 * hi;
+        if (d0 + 4 <= D)
+          store4<bf16>(op + d0, oacc[u][4 * g4] * inv, oacc[u][4 * g4 + 1] * inv, oacc[u][4 * g4 + 2] * inv,
+                       oacc[u][4 * g4 + 3] * inv);
+      }
+    }
+  }
+}
+
+template <int D, int NW, int TPW, int CK>
+static int attnf_launch(const AttnFP& p, hipStream_t st) {
+  typedef AttnFCfg<D, NW, TPW, CK> CF;
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute((const void*)k_attn_fused<D, NW, TPW, CK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              CF::LDS_BYTES);
+    once = true;
+  }
+  k_attn_fused<D, NW, TPW, CK><<<p.B * p.heads, NW * 64, CF::LDS_BYTES, st>>>(p);
+  return check_launch("afldm_attn_block_fused");
+}
+
+}  // namespace afldm
+
+using namespace afldm;
+
+// 1 when afldm_attn_block_fused has a kernel for this shape
+extern "C" int afldm_attn_block_fused_supported(int T, int C, int head_dim, int G) {
+  if (G <= 0 || C % G || C / G > 16 || C % head_dim) return 0;
+  if (head_dim == 24) return (T == 1024 && C == 192) || (T == 256 && C == 384);
+  if (head_dim == 16) return (T == 256 && C == 64) || (T == 64 && C == 128);
+  return 0;
+}
+
+extern "C" int afldm_attn_block_fused(const void* x, const float* stats, int S, const float* gamma, const float* beta,
+                                      int G, float eps, const void* w_qkv, const float* bias_qkv, void* o, int B, int T,
+                                      int C, int heads, float scale, int dtype, afldm_stream_t stream) {
+  AFLDM_REQUIRE(x && stats && gamma && beta && w_qkv && bias_qkv && o, AFLDM_ENULL, "afldm_attn_block_fused: NULL pointer");
+  AFLDM_REQUIRE(dtype == AFLDM_BF16, AFLDM_EDTYPE, "afldm_attn_block_fused: bf16 only (fp32 runs gn_apply + linear + attention)");
+  AFLDM_REQUIRE(B > 0 && heads > 0 && C % heads == 0 && S > 0, AFLDM_ESHAPE, "afldm_attn_block_fused: bad shape B=%d heads=%d C=%d S=%d", B, heads, C, S);
+  const int d = C / heads;
+  AFLDM_REQUIRE(afldm_attn_block_fused_supported(T, C, d, G), AFLDM_ESHAPE,
+                "afldm_attn_block_fused: no kernel for T=%d C=%d head_dim=%d groups=%d", T, C, d, G);
+  AFLDM_REQUIRE(aligned16(x) && aligned16(w_qkv) && aligned16(o), AFLDM_EALIGN, "afldm_attn_block_fused: pointers must be 16-byte aligned");
+  AttnFP p;
+  p.x = (const bf16*)x; p.w = (const bf16*)w_qkv; p.bias = bias_qkv; p.gamma = gamma; p.beta = beta;
+  p.gs.st1 = stats; p.gs.st2 = nullptr; p.gs.C1 = C; p.gs.C2 = 0; p.gs.S1 = S; p.gs.S2 = 0;
+  p.o = (bf16*)o; p.B = B; p.heads = heads; p.C = C; p.G = G; p.eps = eps;
+  p.qscale = scale * 1.4426950408889634f;
+  hipStream_t st = (hipStream_t)stream;
+  if (d == 24 && T == 1024) return attnf_launch<24, 8, 4, 12>(p, st);
+  if (d == 24 && T == 256) return attnf_launch<24, 8, 1, 24>(p, st);
+  if (d == 16 && T == 256) return attnf_launch<16, 8, 1, 4>(p, st);
+  if (d == 16 && T == 64) return attnf_launch<16, 2, 1, 8>(p, st);
+  set_error("afldm_attn_block_fused: unreachable shape");
+  return AFLDM_ESHAPE;
+}

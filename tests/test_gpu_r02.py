@@ -231,7 +231,9 @@ def test_i2sb_per_gpu_share_of_c5():
         del unet, pipe
     r = rel_rms(outs[torch.bfloat16], outs[torch.float32])
     print(f"[C5] 99-evaluation I2SB bridge, batch 32: bf16 vs fp32 rel-RMS {r:.3e}")
-    assert r <= 0.15
+    # round 4: the bridge carries the latent in fp32 between evaluations (0.10 before, 2.7e-3 now); bound = 3x the oracle's
+    # bf16-weight noise floor of this chain (tests/golden/g16_r04_floor.npz: 2.0e-3; see test_gpu_r04.py)
+    assert r <= 6e-3
 
 
 # ------------------------------------------------------------------------------------------------ item 9
@@ -388,13 +390,14 @@ def test_ffhq_equivariance_vs_oracle(golden, dtype, budget_db):
         assert abs(db) <= budget_db, (tj, mse, want)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 1.5e-1)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-3)])
 def test_ffhq_full_99_evaluation_i2sb_bridge_vs_oracle(golden, dtype, tol):
     """BASELINE configs[4]'s sampler at FULL length on the GPU path: the 99 UNet evaluations of the 100-step I2SB bridge
     (is_ode; reference i2sb_pipeline.py:48-56) on the FFHQ-size AF-UNet at batch 1 against the fp32 oracle
     (tests/golden/g14_r03.npz, oracle/gen_golden.py part h).  fp32: the multi-step tolerance 1e-3; bf16 after 99
-    evaluations of the random-init network: the 0.15 bound of test_i2sb_per_gpu_share_of_c5 (measured 0.108 here, 0.10 there:
-    99 chained evaluations of a random-init network amplify bf16 rounding; SURVEY.md 8d states no bf16 figure for this run)."""
+    evaluations: 3x the oracle's own bf16-weight noise floor of this chain (2.0e-3, tests/golden/g16_r04_floor.npz; measured
+    2.9e-3).  Round 3's 0.108 was the latent being STORED in bf16 between evaluations (the oracle reproduces 0.1075 with
+    bf16 storage): the bridge now carries it in fp32 (test_gpu_r04.py holds the derivation)."""
     from afldm_amd.configs import FFHQ_DDIM_CONFIG
     from afldm_amd.pipelines.i2sb_pipeline import I2SBLDMPipeline
     from afldm_amd.schedulers.i2sb import I2SBScheduler

@@ -88,10 +88,10 @@ def test_ffhq_i2sb_bridge_midpoint_and_derived_bf16_bound(golden, dtype):
       * `floor_*_bf16lat` - the ORACLE with bf16-rounded weights and the latent stored in bf16 between evaluations, which
         is what the reference does with a bf16 UNet (0.059 / 0.108: the bridge moves the latent by ~1 bf16 ulp per step, so
         storage rounding dominates; round 3's measured 0.108 was exactly this).  A reference-style loop on the GPU
-        (`sched.step` on bf16 latents) must stay within 1.5x of it;
+        (`sched.step` on bf16 latents) must stay within 1.25x of it (measured: 1.001x);
       * `floor_*` - the oracle with bf16-rounded weights only (1.8e-3 / 2.0e-3).  The product's bridge
         (I2SBLDMPipeline._bridge) carries the latent in fp32 between evaluations: what remains is weight rounding plus
-        the rounding of every activation tensor (~6 bf16 tensors per weight tensor on the path), bounded here by 6x."""
+        the rounding of the activation tensors, bounded here by 3x (measured 1.46x)."""
     from afldm_amd.configs import FFHQ_DDIM_CONFIG
     from afldm_amd.pipelines.i2sb_pipeline import I2SBLDMPipeline
     from afldm_amd.schedulers.i2sb import I2SBScheduler
@@ -120,8 +120,8 @@ def test_ffhq_i2sb_bridge_midpoint_and_derived_bf16_bound(golden, dtype):
     if dtype == torch.float32:
         assert r99 <= 1e-3 and s50 <= 1e-3 and s99 <= 1e-3
     else:
-        assert s50 <= 1.5 * fs50 and s99 <= 1.5 * fs99, (s50, fs50, s99, fs99)
-        assert r99 <= 6.0 * fw99, (r99, fw99)
+        assert s50 <= 1.25 * fs50 and s99 <= 1.25 * fs99, (s50, fs50, s99, fs99)      # measured 1.0005x / 1.001x
+        assert r99 <= 3.0 * fw99, (r99, fw99)                                          # measured 1.46x (2.9e-3)
 
 
 # ------------------------------------------------------------------------------------------------ item 5
