@@ -21,6 +21,8 @@
 //            are issued before the current tile's exponentials so that matrix and vector pipes overlap inside a wave.
 //
 // x is read once per head from the XCD's L2 (the heads of a sample run on one XCD), q | k | v never exist in HBM.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace afldm {
@@ -37,6 +39,7 @@ struct AttnFP {
   bf16* o;             // [B][T][C]
   int B, heads, C, G;
   float eps, qscale;   // qscale = softmax scale * log2(e)
+  int force_slow;      // testing / A-B: always take the loop that tracks the row maxima
 };
 
 __device__ __forceinline__ f32x16 mfma32(const bf16x8& a, const bf16x8& b, const f32x16& c) {
@@ -57,13 +60,16 @@ struct AttnFCfg {
   static constexpr int W_BYTES = 3 * D * RW;
   static constexpr int AS_BYTES = C * 8;                // a[C], s[C] fp32
   static constexpr int BIAS_BYTES = 3 * 32 * 4;         // q | k | v biases of this head, padded to 32, fp32
+  static constexpr int KN_BYTES = 64;                   // per-wave max |k|^2 (fp32)
   static constexpr int OFF_K = 0, OFF_V = OFF_K + K_BYTES, OFF_CST = OFF_V + V_BYTES, OFF_W = OFF_CST + CST_BYTES,
-                       OFF_AS = OFF_W + W_BYTES, OFF_BIAS = OFF_AS + AS_BYTES, LDS_BYTES = OFF_BIAS + BIAS_BYTES;
+                       OFF_AS = OFF_W + W_BYTES, OFF_BIAS = OFF_AS + AS_BYTES, OFF_KN = OFF_BIAS + BIAS_BYTES,
+                       LDS_BYTES = OFF_KN + KN_BYTES;
   static constexpr int NU = TPW >= 2 ? 2 : 1;           // query tiles per attention pass
   static constexpr int PADC = D / 16, PADHI = (D % 16) / 8;   // where slot D sits: chunk, lane half (element 0)
 };
 
-template <int D, int NW, int TPW, int CK>
+// DBG (AFLDM_ATTNF_DBG, timing decomposition, garbage results): 1 no attention phase, 2 no exponentials, 4 no projection MFMAs
+template <int D, int NW, int TPW, int CK, int DBG = 0>
 __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
   typedef AttnFCfg<D, NW, TPW, CK> CF;
   constexpr int T = CF::T, NT = CF::NT, C = CF::C, RK = CF::RK, RW = CF::RW, NU = CF::NU, NTHR = NW * 64;
@@ -76,6 +82,7 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
   float* sA = reinterpret_cast<float*>(smem + CF::OFF_AS);
   float* sS = sA + C;
   float* sB = reinterpret_cast<float*>(smem + CF::OFF_BIAS);
+  float* sKN = reinterpret_cast<float*>(smem + CF::OFF_KN);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ln = lane & 31, hi = lane >> 5;
@@ -153,6 +160,8 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
   const float* s_base = sS + hi * (C / 2);
 
   bf16x8 qf[TPW][2];     // Q as B fragments (scaled by scale * log2 e), chunk c = channels 16c + 8 half + e
+  float qn2[TPW];        // |q|^2 of this lane's query (of the bf16 values that enter the MFMA), per tile
+  float kn2 = 0.f;       // max |k|^2 over this lane's keys
 #pragma unroll
   for (int tt = 0; tt < TPW; ++tt) {
     const int tok0 = (wave * TPW + tt) * 32;               // first token of the tile (within the sample)
@@ -193,11 +202,19 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
       const bf16x8 wq = ld16<bf16x8>(wq_base + kk * 16);
       const bf16x8 wk = ld16<bf16x8>(wk_base + kk * 16);
       const bf16x8 wv = ld16<bf16x8>(wv_base + kk * 16);
-      aq = mfma32(wq, xb, aq);            // [channel x token]
-      ak = mfma32(wk, xb, ak);            // [channel x token]
-      av = mfma32(xb, wv, av);            // [token x channel]: lane = channel, registers = tokens
+      if (!(DBG & 4)) {
+        aq = mfma32(wq, xb, aq);          // [channel x token]
+        ak = mfma32(wk, xb, ak);          // [channel x token]
+        av = mfma32(xb, wv, av);          // [token x channel]: lane = channel, registers = tokens
+      } else {
+        aq[0] += (float)wq[0] + (float)xb[0];
+        ak[0] += (float)wk[0];
+        av[0] += (float)wv[0];
+      }
     }
-    // ---- tile epilogue: Q -> registers, K / V^T -> LDS
+    // ---- tile epilogue: Q -> registers, K / V^T -> LDS; squared norms of the rounded rows (Cauchy-Schwarz bound on
+    // the scores: decides, per wave, whether the attention loop has to track row maxima at all)
+    float qs = 0.f, ks = 0.f;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       bf16x8 qv, kv;
@@ -210,10 +227,18 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
       if (!real) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) qv[e] = (bf16)0.0f;     // slot D (-m) is written by the attention loop
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          qs += (float)qv[e] * (float)qv[e];
+          ks += (float)kv[e] * (float)kv[e];
+        }
       }
       qf[tt][c] = qv;
       if (real) st16<bf16x8>(sK + (tok0 + ln) * RK + (2 * c + hi) * 16, kv);
     }
+    qn2[tt] = qs + __shfl_xor(qs, 32, 64);
+    kn2 = fmaxf(kn2, ks + __shfl_xor(ks, 32, 64));
     if (ln < D) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -228,7 +253,13 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
       for (int kk = 0; kk < CK; ++kk) xr[kk] = xn[kk];
     }
   }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) kn2 = fmaxf(kn2, __shfl_xor(kn2, o, 64));
+  if (lane == 0) sKN[wave] = kn2;
   __syncthreads();      // K / V^T of every token resident
+  float kmax2 = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) kmax2 = fmaxf(kmax2, sKN[w]);
 
   // ------------------------------------------------------------------ phase B: attention over the resident K / V^T
   // per-lane fragment addresses (constants for padding lanes: step 0)
@@ -268,7 +299,7 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
     };
     // move the reference of query tile u to m_new (rounded to bf16: it travels in Q).  `cur` / `nxt`: score tiles already
     // computed against the old reference (the next tile's MFMAs are issued one step ahead)
-    auto rescale = [&](int u, float mnew_raw, f32x16& cur, f32x16* nxt, bool first) {
+    auto rescale = [&](int u, float mnew_raw, f32x16& cur, f32x16& nxt, bool first) {
       const float m_new = (float)(bf16)mnew_raw;
       const float delta = m_new - m_run[u];
       m_run[u] = m_new;
@@ -276,7 +307,7 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         cur[r] -= delta;
-        if (nxt) (*nxt)[r] -= delta;
+        nxt[r] -= delta;                                 // (without a next tile: dead values)
       }
       if (!first) {                                     // (tile 0: O is still zero, and 2^-delta may overflow)
         const float alpha = __builtin_amdgcn_exp2f(-delta);
@@ -284,11 +315,26 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
         for (int r = 0; r < 16; ++r) oacc[u][r] *= alpha;
       }
     };
-    // one key tile: `cur` holds S^T - m of tile t; tile t + 1 is produced into `nxt` FIRST (matrix pipe) so that it
-    // runs under the exponentials of tile t (vector pipe); then O^T += V^T P^T
+    // O^T += V^T P^T for key tile t, P = 2^(S^T - m) of `cur`
+    auto softmax_pv = [&](int t, f32x16 (&cur)[NU]) {
+      const bf16x8 vf0 = ld16<bf16x8>(vp + t * vstep_t);
+      const bf16x8 vf1 = ld16<bf16x8>(vp + t * vstep_t + vstep_j);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        bf16x8 pb0, pb1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          pb0[e] = (bf16)((DBG & 2) ? cur[u][e] : __builtin_amdgcn_exp2f(cur[u][e]));
+          pb1[e] = (bf16)((DBG & 2) ? cur[u][8 + e] : __builtin_amdgcn_exp2f(cur[u][8 + e]));
+        }
+        oacc[u] = mfma32(vf0, pb0, oacc[u]);
+        oacc[u] = mfma32(vf1, pb1, oacc[u]);
+      }
+    };
+    // one key tile of the loop that tracks the row maxima: tile t + 1 is produced into `nxt` FIRST (matrix pipe), then
+    // the lazy-rescale test of tile t, its exponentials and products
     auto step = [&](int t, f32x16 (&cur)[NU], f32x16 (&nxt)[NU]) {
-      const bool more = t + 1 < NT;
-      if (more) qk(t + 1, nxt);
+      if (t + 1 < NT) qk(t + 1, nxt);
       float mx[NU];
       bool grow = false;
 #pragma unroll
@@ -303,38 +349,49 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
           const float m = fmaxf(mx[u], __shfl_xor(mx[u], 32, 64));
-          rescale(u, m_run[u] + fmaxf(m, 0.f), cur[u], more ? &nxt[u] : nullptr, false);
+          rescale(u, m_run[u] + fmaxf(m, 0.f), cur[u], nxt[u], false);
         }
       }
-      const bf16x8 vf0 = ld16<bf16x8>(vp + t * vstep_t);
-      const bf16x8 vf1 = ld16<bf16x8>(vp + t * vstep_t + vstep_j);
-#pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        bf16x8 pb0, pb1;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          pb0[e] = (bf16)__builtin_amdgcn_exp2f(cur[u][e]);
-          pb1[e] = (bf16)__builtin_amdgcn_exp2f(cur[u][8 + e]);
-        }
-        oacc[u] = mfma32(vf0, pb0, oacc[u]);
-        oacc[u] = mfma32(vf1, pb1, oacc[u]);
-      }
+      softmax_pv(t, cur);
     };
     f32x16 sa[NU], sb[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sb[u][r] = 0.f;
     qk(0, sa);
-    // tile 0: the reference is the row maximum of the first tile
+    // tile 0: the reference is the row maximum of the first tile.  Scores can never exceed |q| max|k| (Cauchy-Schwarz on
+    // the very bf16 rows the MFMAs contract): when that bound is within 2^80 of the reference for every query of the
+    // wave - any realistic input - NOTHING can overflow and the loop needs neither maxima nor rescaling
+    bool safe = !p.force_slow;
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       float m = sa[u][0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) m = fmaxf(m, sa[u][r]);
       m = fmaxf(m, __shfl_xor(m, 32, 64));
-      rescale(u, m, sa[u], nullptr, true);
+      rescale(u, m, sa[u], sb[u], true);
+      const float bound = __builtin_sqrtf(qn2[pass * NU + u] * kmax2) * 1.002f + 0.01f;
+      safe = safe && (bound - m_run[u] <= 80.0f);
     }
-    static_assert(NT % 2 == 0, "key tiles are walked in pairs (score registers ping-pong)");
-    for (int t = 0; t < NT; t += 2) {
-      step(t, sa, sb);
-      step(t + 1, sb, sa);
+    static_assert(NT % 2 == 0 && NT >= 2, "key tiles are walked in pairs (score registers ping-pong)");
+    if (DBG & 1) {
+      softmax_pv(0, sa);
+    } else if (__all(safe)) {
+      for (int t = 0; t + 2 < NT; t += 2) {
+        qk(t + 1, sb);
+        softmax_pv(t, sa);
+        qk(t + 2, sa);
+        softmax_pv(t + 1, sb);
+      }
+      qk(NT - 1, sb);
+      softmax_pv(NT - 2, sa);
+      softmax_pv(NT - 1, sb);
+    } else {
+      for (int t = 0; t < NT; t += 2) {
+        step(t, sa, sb);
+        step(t + 1, sb, sa);
+      }
     }
     // ---- finish: row D of O^T is the softmax denominator (half 0 holds it); normalise, store 4 channels per piece
 #pragma unroll
@@ -356,17 +413,29 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
   }
 }
 
-template <int D, int NW, int TPW, int CK>
+template <int D, int NW, int TPW, int CK, int DBG = 0>
 static int attnf_launch(const AttnFP& p, hipStream_t st) {
   typedef AttnFCfg<D, NW, TPW, CK> CF;
   static bool once = false;
   if (!once) {
-    (void)hipFuncSetAttribute((const void*)k_attn_fused<D, NW, TPW, CK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)k_attn_fused<D, NW, TPW, CK, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               CF::LDS_BYTES);
     once = true;
   }
-  k_attn_fused<D, NW, TPW, CK><<<p.B * p.heads, NW * 64, CF::LDS_BYTES, st>>>(p);
+  k_attn_fused<D, NW, TPW, CK, DBG><<<p.B * p.heads, NW * 64, CF::LDS_BYTES, st>>>(p);
   return check_launch("afldm_attn_block_fused");
+}
+
+template <int D, int NW, int TPW, int CK>
+static int attnf_launch_dbg(const AttnFP& p, hipStream_t st) {
+  static const int dbg = getenv("AFLDM_ATTNF_DBG") ? atoi(getenv("AFLDM_ATTNF_DBG")) : 0;
+  switch (dbg) {
+    case 1: return attnf_launch<D, NW, TPW, CK, 1>(p, st);
+    case 2: return attnf_launch<D, NW, TPW, CK, 2>(p, st);
+    case 4: return attnf_launch<D, NW, TPW, CK, 4>(p, st);
+    case 5: return attnf_launch<D, NW, TPW, CK, 5>(p, st);
+    default: return attnf_launch<D, NW, TPW, CK, 0>(p, st);
+  }
 }
 
 }  // namespace afldm
@@ -396,9 +465,13 @@ extern "C" int afldm_attn_block_fused(const void* x, const float* stats, int S, 
   p.gs.st1 = stats; p.gs.st2 = nullptr; p.gs.C1 = C; p.gs.C2 = 0; p.gs.S1 = S; p.gs.S2 = 0;
   p.o = (bf16*)o; p.B = B; p.heads = heads; p.C = C; p.G = G; p.eps = eps;
   p.qscale = scale * 1.4426950408889634f;
+  {
+    const char* e = getenv("AFLDM_ATTNF_SLOW");      // read per call: tests flip it (row-maxima loop instead of the bounded one)
+    p.force_slow = e && atoi(e) != 0;
+  }
   hipStream_t st = (hipStream_t)stream;
-  if (d == 24 && T == 1024) return attnf_launch<24, 8, 4, 12>(p, st);
-  if (d == 24 && T == 256) return attnf_launch<24, 8, 1, 24>(p, st);
+  if (d == 24 && T == 1024) return attnf_launch_dbg<24, 8, 4, 12>(p, st);
+  if (d == 24 && T == 256) return attnf_launch_dbg<24, 8, 1, 24>(p, st);
   if (d == 16 && T == 256) return attnf_launch<16, 8, 1, 4>(p, st);
   if (d == 16 && T == 64) return attnf_launch<16, 2, 1, 8>(p, st);
   set_error("afldm_attn_block_fused: unreachable shape");

@@ -394,6 +394,14 @@ class AttnProcessor2_0:
         gamma, beta = packed_norm(attn.group_norm)
         gn = attn.group_norm
         pre = getattr(hidden_states, "gn_applied", None)
+        if (pre is None and encoder_hidden_states is None and C // attn.heads <= 32
+                and ops.attn_block_fused_ok(hidden_states.view(B, H * W, C), attn.heads, gn.num_groups)):
+            # 32^2 / 16^2 levels, bf16: GroupNorm-apply + q | k | v projection + attention in ONE launch (csrc/attnf.hip)
+            stats = ops.gn_stats(hidden_states, gn.num_groups)
+            w, b = packed_qkv(attn, hidden_states.dtype, ("q", "k", "v"))
+            o = ops.attn_block_fused(hidden_states.view(B, H * W, C), stats, gamma, beta, gn.num_groups, gn.eps, w, b,
+                                     attn.heads, attn.scale)
+            return linear_forward(attn.to_out[0], o.view(B, H, W, C), residual=hidden_states, want_stats=True)
         if pre is not None and pre[1] is gn:
             hn = pre[0]                                   # the producing resnet block already applied this GroupNorm
         else:

@@ -839,6 +839,40 @@ def attention(q, k, vt, heads, scale=None, out=None):
     return out
 
 
+_FUSED_ATTN = os.environ.get("AFLDM_NO_FUSED_ATTN", "0") != "1"
+# below this many (sample, head) workgroups the chip is not filled by one workgroup per pair: the three-launch path wins
+_FUSED_ATTN_MIN_WGS = int(os.environ.get("AFLDM_FUSED_ATTN_MIN_WGS", "256"))
+
+
+def attn_block_fused_ok(x, heads, G):
+    """True when afldm_attn_block_fused has a kernel for tokens x [B, T, C] (bf16) and the policy wants it."""
+    if not _FUSED_ATTN or x.dtype != torch.bfloat16:
+        return False
+    B, T, C = x.shape
+    if B * heads < _FUSED_ATTN_MIN_WGS:
+        return False
+    return bool(lib.afldm_attn_block_fused_supported(T, C, C // heads, int(G)))
+
+
+def attn_block_fused(x, stats, gamma, beta, G, eps, w_qkv, bias_qkv, heads, scale, out=None):
+    """GroupNorm-apply -> q | k | v projection -> attention of one attention block in ONE launch.  x [B, T, C] raw
+    tokens; stats = GNStats of x; w_qkv [3C, 1, 1, C] / bias_qkv [3C] = packed (to_q | to_k | to_v).  Returns the input
+    of to_out, [B, T, C]."""
+    _dev(x, "x")
+    B, T, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    assert stats.st2 is None and stats.st1.shape[2] == C
+    tok = _begin()
+    check(lib.afldm_attn_block_fused(ptr(x), ptr(stats.st1), stats.S1, ptr(gamma), ptr(beta), int(G), float(eps),
+                                     ptr(w_qkv), ptr(bias_qkv), ptr(out), B, T, C, heads, float(scale), _code(x),
+                                     stream_ptr()), "attn_block_fused")
+    d = C // heads
+    _end(tok, "attn_fused", 2.0 * B * T * 3 * C * C + 4.0 * B * heads * T * T * d,
+         (2 * B * T * C + 3 * C * C) * x.element_size())
+    return out
+
+
 # ----------------------------------------------------------------------------- DDIM
 def ddim_step(x, eps_nhwc, coef, step_idx, advance=False, out=None):
     """x NCHW fp32, eps NHWC dtype; coef float[4*nsteps] and step_idx int32[1] on device."""

@@ -293,6 +293,21 @@ int afldm_attention(const void* q, int ldq, const void* k, int ldk, const void* 
                     int B, int Bk, int heads, int Tq, int Tk, int d, float scale, int dtype,
                     afldm_stream_t stream);
 
+/* ---- attention block front end, fused ------------------------------------------------------
+ * group_norm -> to_q | to_k | to_v -> scaled_dot_product_attention of diffusers' AttnProcessor2_0 on the deprecated
+ * attention-block configuration (the self-attention path of reference cross_frame_attn.py:66-77 in IDLE / STORE state;
+ * diffusers attention_processor.py AttnProcessor2_0.__call__) as ONE launch: a workgroup owns a (sample, head), normalises
+ * the raw tokens x [B,T,C] from the producer's per-channel partial sums `stats` [B,S,C,2] (as afldm_gn_apply does),
+ * projects its head's q / k / v with w_qkv [3C,C] (to_q | to_k | to_v rows) + bias_qkv [3C] and runs the attention
+ * against K / V^T resident in LDS; o [B,T,C] = the input of to_out.  q | k | v never exist in memory.
+ * bf16 only; shapes: see afldm_attn_block_fused_supported (1 = there is a kernel for T tokens, C channels, head_dim,
+ * G groups).  Same rounding points as afldm_gn_apply + afldm_conv2d + afldm_attention (normalised tokens, q, k, v and the
+ * softmax weights in bf16) except that the softmax scale is applied to q before its rounding. */
+int afldm_attn_block_fused_supported(int T, int C, int head_dim, int G);
+int afldm_attn_block_fused(const void* x, const float* stats, int S, const float* gamma, const float* beta, int G,
+                           float eps, const void* w_qkv, const float* bias_qkv, void* o, int B, int T, int C,
+                           int heads, float scale, int dtype, afldm_stream_t stream);
+
 /* ---- DDIM update -------------------------------------------------------------------------
  * DDIMScheduler.step, eta = 0, epsilon prediction, no clipping:
  *   x0 = (x - sqrt(1-a_t) eps) / sqrt(a_t);  x_prev = sqrt(a_prev) x0 + sqrt(1-a_prev) eps

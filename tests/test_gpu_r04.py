@@ -230,3 +230,108 @@ def test_cross_frame_processor_vs_reference_file(golden):
     assert close32(_nchw(attn(xq)), g["cfa_load"], 5e-5)
     st.to_idle()
     assert close32(_nchw(attn(xq)), g["cfa_idle"], 5e-5)
+
+
+# ------------------------------------------------------------------------------------------------ fused attention front end
+def _attn_block_reference(x, gamma, beta, G, eps, wq, wk, wv, bq, bk, bv, heads):
+    """fp32 CPU restatement of group_norm -> to_q / to_k / to_v -> SDPA (oracle/unet.py::_attention_core up to to_out)."""
+    import torch.nn.functional as F
+    B, T, C = x.shape
+    h = F.group_norm(x.transpose(1, 2), G, gamma, beta, eps).transpose(1, 2)
+    q, k, v = F.linear(h, wq, bq), F.linear(h, wk, bk), F.linear(h, wv, bv)
+    d = C // heads
+    q, k, v = (z.view(B, T, heads, d).transpose(1, 2) for z in (q, k, v))
+    return F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, T, C)
+
+
+@pytest.mark.parametrize("T,C,heads,B,hot", [(1024, 192, 8, 3, 1.0), (256, 384, 16, 5, 1.0), (256, 64, 4, 2, 1.0),
+                                             (64, 128, 8, 3, 1.0), (1024, 192, 8, 2, 6.0), (256, 384, 16, 2, 5.0)])
+def test_attn_block_fused_vs_three_launch_path_and_reference(T, C, heads, B, hot):
+    """afldm_attn_block_fused (GroupNorm-apply + per-head q|k|v projection + attention with K / V^T resident in LDS, one
+    launch) against (a) the fp32 restatement of diffusers' AttnProcessor2_0 front end and (b) the three-launch path it
+    replaces (afldm_gn_apply, afldm_conv2d, afldm_attention) on the same bf16 inputs.  `hot` scales to_q / to_k so that the
+    scores have a standard deviation of tens of log2 units: the row maxima then outgrow the first tile's reference by
+    more than 2^10 and the lazy-rescale branch (incl. the fix-up of the score tile computed one step ahead) runs.
+    Asymmetric random data throughout (a transposed or permuted fragment cannot pass)."""
+    from afldm_amd import ops
+    gen = torch.Generator().manual_seed(T + C)
+    G, eps = 32, 1e-5
+    x = (torch.randn(B, T, C, generator=gen) * (1.0 + torch.rand(1, 1, C, generator=gen)) + 0.5 * torch.randn(1, 1, C, generator=gen))
+    gamma, beta = 0.5 + torch.rand(C, generator=gen), 0.3 * torch.randn(C, generator=gen)
+    ws = [torch.randn(C, C, generator=gen) / C ** 0.5 for _ in range(3)]
+    ws[0], ws[1] = ws[0] * hot, ws[1] * hot
+    bs = [0.2 * torch.randn(C, generator=gen) for _ in range(3)]
+    xb = x.to(torch.bfloat16)
+    wb = [w.to(torch.bfloat16) for w in ws]
+    ref = _attn_block_reference(xb.float(), gamma, beta, G, eps, *[w.float() for w in wb], *bs, heads)
+    xg = xb.cuda()
+    side = int(T ** 0.5)
+    stats = ops.gn_stats(xg.view(B, side, side, C), G)
+    gg, bg = gamma.cuda(), beta.cuda()
+    wpack = ops.pack_weight(torch.cat(wb, 0).float().cuda(), torch.bfloat16)
+    bpack = torch.cat(bs, 0).cuda()
+    got = ops.attn_block_fused(xg, stats, gg, bg, G, eps, wpack, bpack, heads, (C // heads) ** -0.5)
+    torch.cuda.synchronize()
+    # (b) the path it replaces
+    hn = ops.gn_apply(xg.view(B, side, side, C), stats, gg, bg, G, eps, act=0).view(B, T, C)
+    qk, vt = ops.linear_split(hn, wpack, bpack, 2 * C)
+    old = ops.attention(qk[:, :, :C], qk[:, :, C:], vt, heads, scale=(C // heads) ** -0.5)
+    r_ref, r_old, r_old_ref = rel_rms(got.float(), ref), rel_rms(got.float(), old.float().cpu()), rel_rms(old.float(), ref)
+    print(f"[attn fused] T={T} C={C} heads={heads} hot={hot}: vs fp32 reference {r_ref:.3e} (three-launch path {r_old_ref:.3e}), "
+          f"vs three-launch path {r_old:.3e}")
+    # (hot: the softmax is nearly one-hot, bf16 rounding of q / k moves scores by ~0.1 log2 units and both paths sit at ~2e-2)
+    assert r_ref <= (2e-2 if hot == 1.0 else 5e-2) and r_ref <= 1.5 * r_old_ref + 1e-3 and r_old <= (2e-2 if hot == 1.0 else 5e-2)
+    assert torch.equal(got, ops.attn_block_fused(xg, stats, gg, bg, G, eps, wpack, bpack, heads, (C // heads) ** -0.5))
+    # the two attention loops of the kernel: the bounded one (Cauchy-Schwarz says no score can outgrow the first tile's
+    # reference by 2^80: no maxima, no rescaling) and the one that tracks row maxima with lazy rescaling.  `hot` inputs
+    # take the second by themselves (the forced run is then bit-identical); ordinary inputs take the first, and forcing
+    # the second must give the same result up to the rounding of the (different) references
+    import os
+    os.environ["AFLDM_ATTNF_SLOW"] = "1"
+    try:
+        slow = ops.attn_block_fused(xg, stats, gg, bg, G, eps, wpack, bpack, heads, (C // heads) ** -0.5)
+    finally:
+        del os.environ["AFLDM_ATTNF_SLOW"]
+    r_slow = rel_rms(slow.float(), ref)
+    print(f"             row-maxima loop forced: vs fp32 reference {r_slow:.3e}, vs default {rel_rms(slow.float(), got.float().cpu()):.3e}")
+    assert r_slow <= (2e-2 if hot == 1.0 else 5e-2) and r_slow <= 1.5 * r_old_ref + 1e-3
+    if hot > 1.0:
+        assert torch.equal(slow, got)
+
+
+def test_attn_block_fused_rejects_what_it_has_no_kernel_for():
+    from afldm_amd import _lib, ops
+    x = torch.zeros(2, 64, 384, dtype=torch.bfloat16, device="cuda")
+    st = ops.gn_stats(x.view(2, 8, 8, 384), 32)
+    z = torch.zeros(384, device="cuda")
+    w = torch.zeros(3 * 384, 1, 1, 384, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(_lib.AfldmError, match="no kernel"):
+        ops.attn_block_fused(x, st, z, z, 32, 1e-5, w, torch.zeros(3 * 384, device="cuda"), 16, 0.2)
+    with pytest.raises(_lib.AfldmError, match="bf16 only"):
+        xf = x.float()
+        ops.attn_block_fused(xf, ops.gn_stats(xf.view(2, 8, 8, 384), 32), z, z, 32, 1e-5, w.float(),
+                             torch.zeros(3 * 384, device="cuda"), 16, 0.2)
+    assert not ops.attn_block_fused_ok(x, 16, 32)
+
+
+@pytest.mark.parametrize("cfg_name", ["tiny", "ffhq"])
+def test_unet_forward_through_fused_attention_blocks(golden, cfg_name, monkeypatch):
+    """The UNet forward with every eligible attention block on the fused launch (the policy's workgroup floor lifted so
+    that a batch of 1-2 takes it) against the oracle fixtures, and against the three-launch path of the same model."""
+    from afldm_amd import ops
+    g = golden("g6_tiny_unet.npz" if cfg_name == "tiny" else "g6_ffhq_unet.npz")
+    unet, _, _ = build_unet(cfg_name, torch.bfloat16)
+    x = t(g["x"]).cuda()
+    ts, key = (501, "y_af") if cfg_name == "tiny" else (981, "y_t981")
+    monkeypatch.setattr(ops, "_FUSED_ATTN_MIN_WGS", 0)
+    calls = []
+    real = ops.attn_block_fused
+    monkeypatch.setattr(ops, "attn_block_fused", lambda *a, **k: (calls.append(a[0].shape), real(*a, **k))[1])
+    y_f = unet(x, ts).sample
+    assert len(calls) >= (2 if cfg_name == "tiny" else 10), calls
+    monkeypatch.setattr(ops, "_FUSED_ATTN", False)
+    y_o = unet(x, ts).sample
+    r_f, r_o = rel_rms(y_f.float(), g[key]), rel_rms(y_o.float(), g[key])
+    print(f"[UNet through fused attention] {cfg_name}: {len(calls)} fused blocks; vs oracle {r_f:.3e} (three-launch {r_o:.3e}); "
+          f"fused vs three-launch {rel_rms(y_f.float(), y_o.float().cpu()):.3e}")
+    assert r_f <= 2e-2 and r_f <= 2.0 * r_o + 1e-3

@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""Attention block front end at batch 64: the fused launch (csrc/attnf.hip) against the three launches it replaces, per level;
+AFLDM_ATTNF_DBG decomposition (1 no attention phase, 2 no exponentials, 4 no projection MFMAs, 5 = 1 + 4) in subprocesses."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    from afldm_amd import ops
+    from bench_kernels import timeit
+    B = int(os.environ.get("B", "64"))
+    for T, C, heads in ((1024, 192, 8), (256, 384, 16)):
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(B, T, C, generator=g).to(torch.bfloat16).cuda()
+        side = int(T ** 0.5)
+        st = ops.gn_stats(x.view(B, side, side, C), 32)
+        gamma, beta = torch.ones(C).cuda(), torch.zeros(C).cuda()
+        w = ops.pack_weight((torch.randn(3 * C, C, generator=g) / C ** 0.5).cuda(), torch.bfloat16)
+        b = torch.zeros(3 * C).cuda()
+        scale = (C // heads) ** -0.5
+        out = torch.empty_like(x)
+        t_f = timeit(lambda: ops.attn_block_fused(x, st, gamma, beta, 32, 1e-5, w, b, heads, scale, out=out), iters=50)
+        if os.environ.get("AFLDM_ATTNF_DBG"):
+            print(f"  dbg={os.environ['AFLDM_ATTNF_DBG']} T={T} C={C}: fused {t_f:7.1f} us", flush=True)
+            continue
+        hn = torch.empty_like(x)
+        t_gn = timeit(lambda: ops.gn_apply(x.view(B, side, side, C), st, gamma, beta, 32, 1e-5, act=0, out=hn.view(B, side, side, C)), iters=50)
+        t_lin = timeit(lambda: ops.linear_split(hn, w, b, 2 * C), iters=50)
+        qk, vt = ops.linear_split(hn, w, b, 2 * C)
+        t_at = timeit(lambda: ops.attention(qk[:, :, :C], qk[:, :, C:], vt, heads, scale=scale, out=out), iters=50)
+        os.environ["AFLDM_ATTNF_SLOW"] = "1"
+        t_s = timeit(lambda: ops.attn_block_fused(x, st, gamma, beta, 32, 1e-5, w, b, heads, scale, out=out), iters=50)
+        del os.environ["AFLDM_ATTNF_SLOW"]
+        print(f"T={T} C={C} heads={heads} B={B}: fused {t_f:7.1f} us (row-maxima loop {t_s:7.1f}) | gn_apply {t_gn:6.1f} + qkv {t_lin:6.1f} + attention "
+              f"{t_at:6.1f} = {t_gn + t_lin + t_at:7.1f} us", flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "decomp":
+        for dbg in ("1", "2", "4", "5"):
+            subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, AFLDM_ATTNF_DBG=dbg))
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        main()
