@@ -40,7 +40,11 @@ struct AttnFP {
   int B, heads, C, G;
   float eps, qscale;   // qscale = softmax scale * log2(e)
   int force_slow;      // testing / A-B: always take the loop that tracks the row maxima
+  int stagger;         // s_sleep units (64 cycles) the second half of the waves waits before the attention phase
+  unsigned long long* trace;   // diagnostic: [workgroup][wave][8] s_memtime stamps (afldm_attn_block_fused_trace), or NULL
 };
+
+static unsigned long long* g_attnf_trace = nullptr;
 
 __device__ __forceinline__ f32x16 mfma32(const bf16x8& a, const bf16x8& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -61,9 +65,13 @@ struct AttnFCfg {
   static constexpr int AS_BYTES = C * 8;                // a[C], s[C] fp32
   static constexpr int BIAS_BYTES = 3 * 32 * 4;         // q | k | v biases of this head, padded to 32, fp32
   static constexpr int KN_BYTES = 64;                   // per-wave max |k|^2 (fp32)
+  static constexpr int CB = C % 64 == 0 ? 64 : 32;      // channels per staged block of a token tile
+  static constexpr int NB = C / CB, KPB = CB / 16;      // blocks per tile, K steps per block
+  static constexpr int XS_WAVE = 32 * CB * 2;           // per-wave staging tile [32 tokens][CB channels] bf16 (swizzled)
+  static constexpr int XS_BYTES = NW * XS_WAVE;
   static constexpr int OFF_K = 0, OFF_V = OFF_K + K_BYTES, OFF_CST = OFF_V + V_BYTES, OFF_W = OFF_CST + CST_BYTES,
                        OFF_AS = OFF_W + W_BYTES, OFF_BIAS = OFF_AS + AS_BYTES, OFF_KN = OFF_BIAS + BIAS_BYTES,
-                       LDS_BYTES = OFF_KN + KN_BYTES;
+                       OFF_XS = OFF_KN + KN_BYTES, LDS_BYTES = OFF_XS + XS_BYTES;
   static constexpr int NU = TPW >= 2 ? 2 : 1;           // query tiles per attention pass
   static constexpr int PADC = D / 16, PADHI = (D % 16) / 8;   // where slot D sits: chunk, lane half (element 0)
 };
@@ -89,63 +97,128 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
   // the heads of a sample (and neighbouring samples) on one XCD: x is re-read from that XCD's L2
   const int wi = xcd_remap(blockIdx.x, gridDim.x);
   const int b = wi / p.heads, h = wi - b * p.heads;
+  auto stamp = [&](int i) {
+    if (p.trace && lane == 0) p.trace[((size_t)blockIdx.x * NW + wave) * 8 + i] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
 
   // ------------------------------------------------------------------ prologue
-  // (1) this wave's first token tile: lane (token, half) streams half a row, CK x 16 B (in flight during the rest)
-  const bf16* xrow0 = p.x + ((size_t)b * T + (size_t)wave * TPW * 32 + ln) * C + hi * (C / 2);
-  bf16x8 xr[CK];
+  // Every global load of the prologue is ISSUED before anything waits on one (loads return in order: the statistics and
+  // the GroupNorm affine first, then the weights, then the first token tile): one memory round trip instead of the four
+  // dependent ones of the first form (weights -> statistics in two batches -> gamma / beta: 6 of a workgroup's 60 us).
+  // (a) GroupNorm partial sums: quarter-waves take one group each (cpg <= 16); consecutive lanes read consecutive
+  //     channels of one split (one run), up to SV partials per lane in flight
+  constexpr int SV = 16;
+  const int cpg = C / p.G, S = p.gs.S1, q4 = lane >> 4, ql = lane & 15, nst = cpg * S;
+  const float* stb = p.gs.st1 + (size_t)b * S * C * 2;
+  f32x2 sv[SV];
+  float gam = 0.f, bet = 0.f;
+  auto stats_issue = [&](int g, int j0) {
 #pragma unroll
-  for (int kk = 0; kk < CK; ++kk) xr[kk] = ld16<bf16x8>(xrow0 + kk * 8);
-
-  // (2) the head's 3 D weight rows -> LDS (padded rows), biases, constants
+    for (int u = 0; u < SV; ++u) {
+      const int j = j0 + 16 * u;
+      const int jj = (g < p.G && j < nst) ? j : 0, gg = g < p.G ? g : 0;
+      const int sp = jj / cpg, cc = jj - sp * cpg;
+      sv[u] = *reinterpret_cast<const f32x2*>(stb + ((size_t)sp * C + gg * cpg + cc) * 2);
+    }
+  };
+  {
+    const int g = wave * 4 + q4;
+    if (g < p.G && ql < cpg) {
+      gam = p.gamma[g * cpg + ql];
+      bet = p.beta[g * cpg + ql];
+    }
+    stats_issue(g, ql);
+  }
+  // (b) the head's 3 D weight rows (-> LDS, padded rows)
   constexpr int WPR = C / 8;                                   // 16-byte pieces per weight row
-  for (int id = tid; id < 3 * D * WPR; id += NTHR) {
+  constexpr int WNP = (3 * D * WPR + NTHR - 1) / NTHR;         // pieces per thread
+  bf16x8 wr[WNP];
+#pragma unroll
+  for (int i = 0; i < WNP; ++i) {
+    const int id = tid + i * NTHR;
     const int row = id / WPR, pc = id - row * WPR;
     const int m = row / D, r = row - m * D;
-    const bf16x8 v = ld16<bf16x8>(p.w + ((size_t)m * C + h * D + r) * C + pc * 8);
-    st16<bf16x8>(sW + row * RW + pc * 16, v);
+    if (id < 3 * D * WPR) wr[i] = ld16<bf16x8>(p.w + ((size_t)m * C + h * D + r) * C + pc * 8);
   }
+  float bias_r = 0.f;
   if (tid < 96) {
     const int m = tid >> 5, r = tid & 31;
-    sB[tid] = r < D ? p.bias[m * C + h * D + r] : 0.f;
+    if (r < D) bias_r = p.bias[m * C + h * D + r];
   }
+  // (c) this wave's token tiles travel as blocks of CB channels: 32 tokens x CB*2 bytes, read as WHOLE row pieces (the
+  // PPR lanes of a row piece are adjacent: every line is fetched once, by one instruction) - a direct-to-fragment load
+  // touches 64 lines per instruction for 16 bytes each.  A whole tile (NB blocks) is in flight: block cb of tile t + 1 is
+  // requested as soon as block cb of tile t has been normalised and staged through the wave-private swizzled LDS tile
+  // (XPF = 3 blocks in flight).
+  constexpr int CB = CF::CB, NB = CF::NB, KPB = CF::KPB, PPR = CB / 8, RPI = 64 / PPR, XI = 32 / RPI;
+  static_assert(CB == 64, "the staging tile's swizzle is laid out for 128-byte row blocks");
+  const int xpc = lane % PPR, xrw = lane / PPR;          // this lane's 16-byte piece of the row block, first row
+  const bf16* xsrc = p.x + ((size_t)b * T + (size_t)wave * TPW * 32 + xrw) * C + xpc * 8;
+  constexpr int XPF = NB < 3 ? NB : 3;                     // blocks in flight (3 x 16 registers)
+  bf16x8 xl[XPF][XI];
+  auto xload = [&](int g) {                                // block g = (tile g / NB, channel block g % NB) -> slot g % XPF
+    const int tt = g / NB, cb = g - tt * NB;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) xl[g % XPF][i] = ld16<bf16x8>(xsrc + (size_t)(tt * 32 + i * RPI) * C + cb * CB);
+  };
+#pragma unroll
+  for (int g = 0; g < XPF; ++g) xload(g);
+
+  // ---- consume: scale / shift per channel
+  for (int g0 = 0; g0 < p.G; g0 += NW * 4) {
+    const int g = g0 + wave * 4 + q4;
+    if (g0 > 0) {                                          // (more than 4 NW groups: the small test shapes)
+      gam = bet = 0.f;
+      if (g < p.G && ql < cpg) {
+        gam = p.gamma[g * cpg + ql];
+        bet = p.beta[g * cpg + ql];
+      }
+      stats_issue(g, ql);
+    }
+    double s1 = 0.0, s2 = 0.0;
+    for (int j0 = ql;; j0 += 16 * SV) {
+#pragma unroll
+      for (int u = 0; u < SV; ++u) {
+        if (g < p.G && j0 + 16 * u < nst) {
+          s1 += (double)sv[u][0];
+          s2 += (double)sv[u][1];
+        }
+      }
+      if (j0 + 16 * SV >= nst) break;                       // (wave-uniform: nst and ql's stride are)
+      stats_issue(g, j0 + 16 * SV);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      s1 += __shfl_xor(s1, o, 64);
+      s2 += __shfl_xor(s2, o, 64);
+    }
+    if (g < p.G && ql < cpg) {
+      float mean, rstd;
+      gn_mean_rstd(s1, s2, (double)T * cpg, p.eps, mean, rstd);
+      const int c = g * cpg + ql;
+      const float k = rstd * gam;
+      sA[c] = k;
+      sS[c] = bet - mean * k;
+    }
+  }
+  // ---- weights, biases, constants -> LDS
+#pragma unroll
+  for (int i = 0; i < WNP; ++i) {
+    const int id = tid + i * NTHR;
+    const int row = id / WPR, pc = id - row * WPR;
+    if (id < 3 * D * WPR) st16<bf16x8>(sW + row * RW + pc * 16, wr[i]);
+  }
+  if (tid < 96) sB[tid] = bias_r;
   if (tid < 3) {
     bf16x8 v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (bf16)((tid == 1 || (tid == 0 && e == 0)) ? 1.0f : 0.0f);
     st16<bf16x8>(sC + tid * 16, v);
   }
-  // (3) GroupNorm scale / shift per channel: quarter-waves take one group each (cpg <= 16)
-  {
-    const int cpg = C / p.G, S = p.gs.S1, q4 = lane >> 4, ql = lane & 15;
-    for (int g0 = 0; g0 < p.G; g0 += NW * 4) {
-      const int g = g0 + wave * 4 + q4;
-      double s1 = 0.0, s2 = 0.0;
-      if (g < p.G) {
-        const float* st = p.gs.st1 + (size_t)b * S * C * 2;
-        for (int j = ql; j < cpg * S; j += 16) {
-          const int cc = j % cpg, sp = j / cpg;          // consecutive lanes: consecutive channels of one split (one run)
-          const f32x2 v = *reinterpret_cast<const f32x2*>(st + ((size_t)sp * C + g * cpg + cc) * 2);
-          s1 += (double)v[0];
-          s2 += (double)v[1];
-        }
-      }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        s1 += __shfl_xor(s1, o, 64);
-        s2 += __shfl_xor(s2, o, 64);
-      }
-      if (g < p.G && ql < cpg) {
-        float mean, rstd;
-        gn_mean_rstd(s1, s2, (double)T * cpg, p.eps, mean, rstd);
-        const int c = g * cpg + ql;
-        const float k = rstd * p.gamma[c];
-        sA[c] = k;
-        sS[c] = p.beta[c] - mean * k;
-      }
-    }
-  }
+  stamp(1);
   __syncthreads();
+  stamp(2);
 
   // ------------------------------------------------------------------ phase A: projection
   // weight fragment rows: q / k use the row permutation sigma (swap bits 2, 3) so that accumulator register 8c + e of
@@ -153,11 +226,16 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
   // 16-byte piece of K's row.  Rows >= D read another row (their results are never used).
   const int sig = (ln & 0x13) | ((ln & 4) << 1) | ((ln & 8) >> 1);
   // (padding lanes read row - 16: finite data, and a row no other lane of their ds_read_b128 group maps onto)
-  const char* wq_base = sW + (0 * D + (sig < D ? sig : sig - 16)) * RW + hi * C;       // + kk * 16
-  const char* wk_base = sW + (1 * D + (sig < D ? sig : sig - 16)) * RW + hi * C;
-  const char* wv_base = sW + (2 * D + (ln < D ? ln : ln - 16)) * RW + hi * C;
-  const float* a_base = sA + hi * (C / 2);
-  const float* s_base = sS + hi * (C / 2);
+  const char* wq_base = sW + (0 * D + (sig < D ? sig : sig - 16)) * RW + hi * 16;       // + kk * 32
+  const char* wk_base = sW + (1 * D + (sig < D ? sig : sig - 16)) * RW + hi * 16;
+  const char* wv_base = sW + (2 * D + (ln < D ? ln : ln - 16)) * RW + hi * 16;
+  char* xs = smem + CF::OFF_XS + wave * CF::XS_WAVE;
+  // staging tile: token t, 16-byte piece pc -> row swap03(t) (bits 0 and 3 exchanged), piece pc ^ (t & (PPR - 1)): the 16
+  // lanes of a ds_read_b128 group (tokens distinct mod 16, one piece) then fall on 16 different bank quads
+  auto xs_off = [&](int t, int pc) {
+    const int row = (t & ~9) | ((t & 1) << 3) | ((t >> 3) & 1);
+    return row * (CB * 2) + ((pc ^ (t & (PPR - 1))) << 4);
+  };
 
   bf16x8 qf[TPW][2];     // Q as B fragments (scaled by scale * log2 e), chunk c = channels 16c + 8 half + e
   float qn2[TPW];        // |q|^2 of this lane's query (of the bf16 values that enter the MFMA), per tile
@@ -184,33 +262,47 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) av[r] = bv;
     }
-    bf16x8 xn[CK];                                          // next tile's rows (prefetched under this tile's products)
-    if (tt + 1 < TPW) {
 #pragma unroll
-      for (int kk = 0; kk < CK; ++kk) xn[kk] = ld16<bf16x8>(xrow0 + (size_t)(tt + 1) * 32 * C + kk * 8);
-    }
+    for (int cb = 0; cb < NB; ++cb) {
+      const int g = tt * NB + cb;
+      // ---- normalise the landed block (this lane: one channel octet, XI rows) and stage it
+      const f32x4 a0 = ld16<f32x4>(sA + cb * CB + xpc * 8), a1 = ld16<f32x4>(sA + cb * CB + xpc * 8 + 4);
+      const f32x4 s0 = ld16<f32x4>(sS + cb * CB + xpc * 8), s1 = ld16<f32x4>(sS + cb * CB + xpc * 8 + 4);
 #pragma unroll
-    for (int kk = 0; kk < CK; ++kk) {
-      const f32x4 a0 = ld16<f32x4>(a_base + kk * 8), a1 = ld16<f32x4>(a_base + kk * 8 + 4);
-      const f32x4 s0 = ld16<f32x4>(s_base + kk * 8), s1 = ld16<f32x4>(s_base + kk * 8 + 4);
-      bf16x8 xb;
+      for (int i = 0; i < XI; ++i) {
+        bf16x8 xb;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        xb[e] = (bf16)((float)xr[kk][e] * a0[e] + s0[e]);
-        xb[4 + e] = (bf16)((float)xr[kk][4 + e] * a1[e] + s1[e]);
+        for (int e = 0; e < 4; ++e) {
+          xb[e] = (bf16)((float)xl[g % XPF][i][e] * a0[e] + s0[e]);
+          xb[4 + e] = (bf16)((float)xl[g % XPF][i][4 + e] * a1[e] + s1[e]);
+        }
+        st16<bf16x8>(xs + xs_off(xrw + i * RPI, xpc), xb);
       }
-      const bf16x8 wq = ld16<bf16x8>(wq_base + kk * 16);
-      const bf16x8 wk = ld16<bf16x8>(wk_base + kk * 16);
-      const bf16x8 wv = ld16<bf16x8>(wv_base + kk * 16);
-      if (!(DBG & 4)) {
-        aq = mfma32(wq, xb, aq);          // [channel x token]
-        ak = mfma32(wk, xb, ak);          // [channel x token]
-        av = mfma32(xb, wv, av);          // [token x channel]: lane = channel, registers = tokens
-      } else {
-        aq[0] += (float)wq[0] + (float)xb[0];
-        ak[0] += (float)wk[0];
-        av[0] += (float)wv[0];
+      if (g + XPF < TPW * NB) xload(g + XPF);              // block g + XPF takes the freed registers
+      // (the tile is exchanged across the lanes of THIS wave only: LDS operations of a wave execute in order; the fences
+      //  pin the compiler's order of the stores above and the fragment reads below)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int k4 = 0; k4 < KPB; ++k4) {
+        const int kk = cb * KPB + k4;
+        const bf16x8 xb = ld16<bf16x8>(xs + xs_off(ln, 2 * k4 + hi));
+        const bf16x8 wq = ld16<bf16x8>(wq_base + kk * 32);
+        const bf16x8 wk = ld16<bf16x8>(wk_base + kk * 32);
+        const bf16x8 wv = ld16<bf16x8>(wv_base + kk * 32);
+        if (!(DBG & 4)) {
+          aq = mfma32(wq, xb, aq);          // [channel x token]
+          ak = mfma32(wk, xb, ak);          // [channel x token]
+          av = mfma32(xb, wv, av);          // [token x channel]: lane = channel, registers = tokens
+        } else {
+          aq[0] += (float)wq[0] + (float)xb[0];
+          ak[0] += (float)wk[0];
+          av[0] += (float)wv[0];
+        }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // fragment reads done before the next block overwrites the tile
+      __builtin_amdgcn_wave_barrier();
     }
     // ---- tile epilogue: Q -> registers, K / V^T -> LDS; squared norms of the rounded rows (Cauchy-Schwarz bound on
     // the scores: decides, per wave, whether the attention loop has to track row maxima at all)
@@ -248,18 +340,21 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
         st16<bf16x8>(sV + ((((tok0 >> 5) * 2 + j) * 2 + hi) * D + ln) * 16, vv);
       }
     }
-    if (tt + 1 < TPW) {
-#pragma unroll
-      for (int kk = 0; kk < CK; ++kk) xr[kk] = xn[kk];
-    }
   }
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) kn2 = fmaxf(kn2, __shfl_xor(kn2, o, 64));
   if (lane == 0) sKN[wave] = kn2;
+  stamp(3);
   __syncthreads();      // K / V^T of every token resident
+  stamp(4);
   float kmax2 = 0.f;
 #pragma unroll
   for (int w = 0; w < NW; ++w) kmax2 = fmaxf(kmax2, sKN[w]);
+  // the barrier releases the two waves of every SIMD in step: their matrix and vector segments would then coincide
+  // instead of interleaving until the waves drift apart on their own (the first pass measured 21 us against 12 for the
+  // second).  The second-dispatched half starts half a key tile late.
+  if (wave >= NW / 2)
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
 
   // ------------------------------------------------------------------ phase B: attention over the resident K / V^T
   // per-lane fragment addresses (constants for padding lanes: step 0)
@@ -375,24 +470,78 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
       safe = safe && (bound - m_run[u] <= 80.0f);
     }
     static_assert(NT % 2 == 0 && NT >= 2, "key tiles are walked in pairs (score registers ping-pong)");
+    // The bounded loop, hand-ordered: per key tile 4 NU matrix instructions (S^T of tile t + 1, P V of tile t) of 32
+    // cycles each against 16 NU exponentials (~8.5 cycles) + 8 NU conversions - the vector pipe is the longer one, so
+    // every MFMA is followed by ITS share of vector work (independent of it: the exponentials of tile t, while the
+    // MFMA runs) and the scheduler is told to keep that order (sched_group_barrier): left to itself it clusters the
+    // S^T MFMAs right in front of their first use and the wave then waits out the matrix pipe with nothing to issue.
+    auto fast_step = [&](int t, f32x16 (&cur)[NU], f32x16 (&nxt)[NU], bool more) {
+      bf16x8 kf0, kf1;
+      if (more) {
+        kf0 = ld16<bf16x8>(k0p + (t + 1) * 32 * RK);
+        kf1 = ld16<bf16x8>(k1p + (t + 1) * k1step);
+      }
+      const bf16x8 vf0 = ld16<bf16x8>(vp + t * vstep_t);
+      const bf16x8 vf1 = ld16<bf16x8>(vp + t * vstep_t + vstep_j);
+      auto expc = [&](const f32x16& sc, int j) {          // P chunk j of one query tile
+        bf16x8 pb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pb[e] = (bf16)((DBG & 2) ? sc[8 * j + e] : __builtin_amdgcn_exp2f(sc[8 * j + e]));
+        return pb;
+      };
+      f32x16 z;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#define AF_FENCE() __builtin_amdgcn_sched_barrier(0)
+      // (each MFMA and the vector work issued under it form one scheduling region, in this order)
+      if constexpr (NU == 2) {
+        AF_FENCE();
+        if (more) nxt[0] = mfma32(kf0, q[0][0], z);
+        const bf16x8 p00 = expc(cur[0], 0);
+        AF_FENCE();
+        if (more) nxt[0] = mfma32(kf1, q[0][1], nxt[0]);
+        const bf16x8 p01 = expc(cur[0], 1);
+        AF_FENCE();
+        oacc[0] = mfma32(vf0, p00, oacc[0]);
+        const bf16x8 p10 = expc(cur[1], 0);
+        AF_FENCE();
+        oacc[0] = mfma32(vf1, p01, oacc[0]);
+        if (more) nxt[1] = mfma32(kf0, q[1][0], z);
+        const bf16x8 p11 = expc(cur[1], 1);
+        AF_FENCE();
+        oacc[1] = mfma32(vf0, p10, oacc[1]);
+        if (more) nxt[1] = mfma32(kf1, q[1][1], nxt[1]);
+        oacc[1] = mfma32(vf1, p11, oacc[1]);
+      } else {
+        AF_FENCE();
+        if (more) nxt[0] = mfma32(kf0, q[0][0], z);
+        const bf16x8 p00 = expc(cur[0], 0);
+        AF_FENCE();
+        if (more) nxt[0] = mfma32(kf1, q[0][1], nxt[0]);
+        const bf16x8 p01 = expc(cur[0], 1);
+        AF_FENCE();
+        oacc[0] = mfma32(vf0, p00, oacc[0]);
+        oacc[0] = mfma32(vf1, p01, oacc[0]);
+      }
+#undef AF_FENCE
+      __builtin_amdgcn_sched_barrier(0);                   // a step is one scheduling region: nothing moves across
+    };
     if (DBG & 1) {
       softmax_pv(0, sa);
     } else if (__all(safe)) {
       for (int t = 0; t + 2 < NT; t += 2) {
-        qk(t + 1, sb);
-        softmax_pv(t, sa);
-        qk(t + 2, sa);
-        softmax_pv(t + 1, sb);
+        fast_step(t, sa, sb, true);
+        fast_step(t + 1, sb, sa, true);
       }
-      qk(NT - 1, sb);
-      softmax_pv(NT - 2, sa);
-      softmax_pv(NT - 1, sb);
+      fast_step(NT - 2, sa, sb, true);
+      fast_step(NT - 1, sb, sa, false);
     } else {
       for (int t = 0; t < NT; t += 2) {
         step(t, sa, sb);
         step(t + 1, sb, sa);
       }
     }
+    stamp(5 + (pass > 0 ? 1 : 0));
     // ---- finish: row D of O^T is the softmax denominator (half 0 holds it); normalise, store 4 channels per piece
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -411,6 +560,7 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
       }
     }
   }
+  stamp(7);
 }
 
 template <int D, int NW, int TPW, int CK, int DBG = 0>
@@ -433,7 +583,6 @@ static int attnf_launch_dbg(const AttnFP& p, hipStream_t st) {
     case 1: return attnf_launch<D, NW, TPW, CK, 1>(p, st);
     case 2: return attnf_launch<D, NW, TPW, CK, 2>(p, st);
     case 4: return attnf_launch<D, NW, TPW, CK, 4>(p, st);
-    case 5: return attnf_launch<D, NW, TPW, CK, 5>(p, st);
     default: return attnf_launch<D, NW, TPW, CK, 0>(p, st);
   }
 }
@@ -441,6 +590,14 @@ static int attnf_launch_dbg(const AttnFP& p, hipStream_t st) {
 }  // namespace afldm
 
 using namespace afldm;
+
+// diagnostic: device buffer of [workgroups][waves][8] uint64 that the next launches fill with s_memtime stamps
+// (0 start, 1 / 2 before / after the prologue barrier, 3 / 4 before / after the barrier that ends the projection,
+//  5 / 6 end of the first / second attention pass); NULL switches it off
+extern "C" int afldm_attn_block_fused_trace(void* buf) {
+  g_attnf_trace = (unsigned long long*)buf;
+  return AFLDM_OK;
+}
 
 // 1 when afldm_attn_block_fused has a kernel for this shape
 extern "C" int afldm_attn_block_fused_supported(int T, int C, int head_dim, int G) {
@@ -463,8 +620,13 @@ extern "C" int afldm_attn_block_fused(const void* x, const float* stats, int S, 
   AttnFP p;
   p.x = (const bf16*)x; p.w = (const bf16*)w_qkv; p.bias = bias_qkv; p.gamma = gamma; p.beta = beta;
   p.gs.st1 = stats; p.gs.st2 = nullptr; p.gs.C1 = C; p.gs.C2 = 0; p.gs.S1 = S; p.gs.S2 = 0;
+  p.trace = g_attnf_trace;
   p.o = (bf16*)o; p.B = B; p.heads = heads; p.C = C; p.G = G; p.eps = eps;
   p.qscale = scale * 1.4426950408889634f;
+  {
+    static const int stg = getenv("AFLDM_ATTNF_STAGGER") ? atoi(getenv("AFLDM_ATTNF_STAGGER")) : 3;
+    p.stagger = stg;
+  }
   {
     const char* e = getenv("AFLDM_ATTNF_SLOW");      // read per call: tests flip it (row-maxima loop instead of the bounded one)
     p.force_slow = e && atoi(e) != 0;

@@ -25,8 +25,32 @@ def main():
         scale = (C // heads) ** -0.5
         out = torch.empty_like(x)
         t_f = timeit(lambda: ops.attn_block_fused(x, st, gamma, beta, 32, 1e-5, w, b, heads, scale, out=out), iters=50)
-        if os.environ.get("AFLDM_ATTNF_DBG"):
-            print(f"  dbg={os.environ['AFLDM_ATTNF_DBG']} T={T} C={C}: fused {t_f:7.1f} us", flush=True)
+        if os.environ.get("TRACE"):
+            from afldm_amd import _lib
+            nwg, nw = B * heads, 8
+            tr = torch.zeros(nwg * nw * 8, dtype=torch.int64, device="cuda")
+            _lib.lib.afldm_attn_block_fused_trace(tr.data_ptr())
+            ops.attn_block_fused(x, st, gamma, beta, 32, 1e-5, w, b, heads, scale, out=out)
+            torch.cuda.synchronize()
+            _lib.lib.afldm_attn_block_fused_trace(None)
+            tr = tr.view(nwg, nw, 8).cpu().double()
+            # (the stamp counters of the 8 XCDs are not aligned: only differences inside a workgroup mean anything; the tick
+            #  is calibrated on launch time / rounds of workgroups, one workgroup per CU)
+            names = ["start", "prologue", "barrier", "projection", "barrier", "pass 1", "pass 2", "epilogue"]
+            rel = tr - tr[:, :, :1]
+            total = float(rel[:, :, 7].mean())
+            rounds = -(-nwg // 256)
+            tick_us = t_f / rounds / total
+            seg, prev = [], 0
+            for i in range(1, 8):
+                if float(tr[:, :, i].max()) == 0:
+                    continue
+                d = float((rel[:, :, i] - rel[:, :, prev]).mean())
+                seg.append(f"{names[i]} {d * tick_us:.1f} us ({100 * d / total:.0f} %)")
+                prev = i
+            print(f"   per workgroup ({rounds} rounds, {total:.0f} ticks = {total * tick_us:.1f} us): " + " | ".join(seg), flush=True)
+        if os.environ.get("AFLDM_ATTNF_DBG") or os.environ.get("QUICK"):
+            print(f"  dbg={os.environ.get('AFLDM_ATTNF_DBG')} stagger={os.environ.get('AFLDM_ATTNF_STAGGER')} T={T} C={C}: fused {t_f:7.1f} us", flush=True)
             continue
         hn = torch.empty_like(x)
         t_gn = timeit(lambda: ops.gn_apply(x.view(B, side, side, C), st, gamma, beta, 32, 1e-5, act=0, out=hn.view(B, side, side, C)), iters=50)
@@ -42,7 +66,7 @@ def main():
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "decomp":
-        for dbg in ("1", "2", "4", "5"):
+        for dbg in ("1", "2", "4"):
             subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, AFLDM_ATTNF_DBG=dbg))
     else:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
