@@ -7,13 +7,12 @@
 // of q | k | v^T per step that attention reads straight back (641 MB), and the attention kernel re-stages every K / V^T
 // chunk once per 256 queries behind a workgroup barrier.  Here a workgroup owns ONE (sample, head):
 //
-//   phase A  each wave projects ITS tokens (32-token tiles): the raw token rows come straight from global memory as
-//            MFMA fragments (lane (token, half) streams one contiguous half row: the K index of the contraction is
-//            permuted accordingly, the weight fragments follow), GroupNorm is applied in registers from the producer's
-//            partial sums (scale / shift per channel in LDS), q / k / v are three 32x32x16 MFMA chains against the head's
-//            72 weight rows held in LDS.  K and V^T are written to LDS ONCE, in the fragment order the attention loop
-//            reads; Q never leaves the registers (the projection's accumulator layout IS the B-fragment layout after a
-//            fixed permutation of the weight rows).
+//   phase A  GroupNorm is FOLDED into the head's 72 weight rows once per workgroup (W' = bf16(W a), the shift goes into the
+//            bias, formed with the rounded W': see the prologue), so each wave projects ITS tokens (32-token tiles) with
+//            the raw token rows going from global memory straight into the MFMA as B / A fragments: q / k / v are three
+//            32x32x16 MFMA chains against W' held in LDS.  K and V^T are written to LDS ONCE, in the fragment order
+//            the attention loop reads; Q never leaves the registers (the projection's accumulator layout IS the
+//            B-fragment layout after a fixed permutation of the weight rows).
 //   phase B  flash attention over the resident K / V^T: no global loads, no staging, NO workgroup barrier - the waves
 //            run free.  S^T = K Q^T so the softmax is lane-local, the running reference is subtracted by the MFMA
 //            (K carries a 1, Q carries -m in the padding channel head_dim -> 32), the row sums come from a row of ones
@@ -62,21 +61,20 @@ struct AttnFCfg {
   static constexpr int CST_BYTES = 64;                  // [0,16) K pad chunk {1,0,..}; [16,32) ones; [32,48) zeros
   static constexpr int RW = C * 2 + 16;                 // weight row stride (bank-conflict-free ds_read_b128)
   static constexpr int W_BYTES = 3 * D * RW;
-  static constexpr int AS_BYTES = C * 8;                // a[C], s[C] fp32
-  static constexpr int BIAS_BYTES = 3 * 32 * 4;         // q | k | v biases of this head, padded to 32, fp32
-  static constexpr int KN_BYTES = 64;                   // per-wave max |k|^2 (fp32)
-  static constexpr int CB = C % 64 == 0 ? 64 : 32;      // channels per staged block of a token tile
-  static constexpr int NB = C / CB, KPB = CB / 16;      // blocks per tile, K steps per block
-  static constexpr int XS_WAVE = 32 * CB * 2;           // per-wave staging tile [32 tokens][CB channels] bf16 (swizzled)
-  static constexpr int XS_BYTES = NW * XS_WAVE;
+  static constexpr int AS_BYTES = C * 12;               // a[C], mu[C], beta[C] fp32 (GroupNorm folded into the weights)
+  static constexpr int BIAS_BYTES = 3 * 32 * 4;         // folded q | k | v biases of this head, padded to 32, fp32
+  static constexpr int KN_BYTES = 64 + 96 * 4;          // per-wave max |k|^2 (fp32) [16 floats] + the layer's own biases [96]
   static constexpr int OFF_K = 0, OFF_V = OFF_K + K_BYTES, OFF_CST = OFF_V + V_BYTES, OFF_W = OFF_CST + CST_BYTES,
                        OFF_AS = OFF_W + W_BYTES, OFF_BIAS = OFF_AS + AS_BYTES, OFF_KN = OFF_BIAS + BIAS_BYTES,
-                       OFF_XS = OFF_KN + KN_BYTES, LDS_BYTES = OFF_XS + XS_BYTES;
+                       LDS_BYTES = OFF_KN + KN_BYTES;
+  static constexpr int PART_BYTES = 3 * D * (C / 8) * 4;   // per-(row, 16-byte piece) bias partials: aliases the K / V^T region
+  static_assert(PART_BYTES <= K_BYTES + V_BYTES, "bias partials must fit the (not yet written) K / V^T region");
   static constexpr int NU = TPW >= 2 ? 2 : 1;           // query tiles per attention pass
   static constexpr int PADC = D / 16, PADHI = (D % 16) / 8;   // where slot D sits: chunk, lane half (element 0)
 };
 
-// DBG (AFLDM_ATTNF_DBG, timing decomposition, garbage results): 1 no attention phase, 2 no exponentials, 4 no projection MFMAs
+// DBG (AFLDM_ATTNF_DBG, timing decomposition, garbage results): 1 no attention phase, 2 no exponentials, 4 no projection MFMAs,
+// 8 no token-tile reloads in the projection, 16 no W' fragment reads in the projection
 template <int D, int NW, int TPW, int CK, int DBG = 0>
 __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
   typedef AttnFCfg<D, NW, TPW, CK> CF;
@@ -88,7 +86,6 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
   char* sC = smem + CF::OFF_CST;
   char* sW = smem + CF::OFF_W;
   float* sA = reinterpret_cast<float*>(smem + CF::OFF_AS);
-  float* sS = sA + C;
   float* sB = reinterpret_cast<float*>(smem + CF::OFF_BIAS);
   float* sKN = reinterpret_cast<float*>(smem + CF::OFF_KN);
 
@@ -103,14 +100,23 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
   stamp(0);
 
   // ------------------------------------------------------------------ prologue
-  // Every global load of the prologue is ISSUED before anything waits on one (loads return in order: the statistics and
-  // the GroupNorm affine first, then the weights, then the first token tile): one memory round trip instead of the four
-  // dependent ones of the first form (weights -> statistics in two batches -> gamma / beta: 6 of a workgroup's 60 us).
+  // GroupNorm is FOLDED into the head's weights, per workgroup (= per sample and head):
+  //   y = W (a x + s) + bias,  a_c = rstd_g gamma_c,  s_c = beta_c - mu_g a_c
+  //     = W' x + bias',        W'_oc = bf16(W_oc a_c),  bias'_o = bias_o + sum_c (W_oc beta_c - W'_oc mu_g(c))
+  // so that the raw token rows go from global memory straight into the MFMA - no normalisation pass over the tile, no
+  // staging through LDS (the second form of this kernel spent 16 of a workgroup's 60 us on them, LDS-bound).  The shift is
+  // formed with the ROUNDED W': the rounding error of W' then multiplies the CENTRED x - the same error class as
+  // rounding the normalised tokens (what afldm_gn_apply's bf16 output does), with no amplification by |mean| / std.
+  //
+  // Every global load of the prologue is ISSUED before anything waits on one (loads return in order): one memory round
+  // trip instead of four dependent ones.
   // (a) GroupNorm partial sums: quarter-waves take one group each (cpg <= 16); consecutive lanes read consecutive
   //     channels of one split (one run), up to SV partials per lane in flight
   constexpr int SV = 16;
   const int cpg = C / p.G, S = p.gs.S1, q4 = lane >> 4, ql = lane & 15, nst = cpg * S;
   const float* stb = p.gs.st1 + (size_t)b * S * C * 2;
+  float* sMu = sA + C;
+  float* sBt = sA + 2 * C;
   f32x2 sv[SV];
   float gam = 0.f, bet = 0.f;
   auto stats_issue = [&](int g, int j0) {
@@ -130,7 +136,7 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
     }
     stats_issue(g, ql);
   }
-  // (b) the head's 3 D weight rows (-> LDS, padded rows)
+  // (b) the head's 3 D weight rows
   constexpr int WPR = C / 8;                                   // 16-byte pieces per weight row
   constexpr int WNP = (3 * D * WPR + NTHR - 1) / NTHR;         // pieces per thread
   bf16x8 wr[WNP];
@@ -141,31 +147,23 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
     const int m = row / D, r = row - m * D;
     if (id < 3 * D * WPR) wr[i] = ld16<bf16x8>(p.w + ((size_t)m * C + h * D + r) * C + pc * 8);
   }
-  float bias_r = 0.f;
-  if (tid < 96) {
-    const int m = tid >> 5, r = tid & 31;
-    if (r < D) bias_r = p.bias[m * C + h * D + r];
+  constexpr int BRN = (96 + NTHR - 1) / NTHR;
+  float bias_r[BRN];
+#pragma unroll
+  for (int i = 0; i < BRN; ++i) {
+    const int o = tid + i * NTHR;
+    bias_r[i] = (o < 96 && (o & 31) < D) ? p.bias[(o >> 5) * C + h * D + (o & 31)] : 0.f;
   }
-  // (c) this wave's token tiles travel as blocks of CB channels: 32 tokens x CB*2 bytes, read as WHOLE row pieces (the
-  // PPR lanes of a row piece are adjacent: every line is fetched once, by one instruction) - a direct-to-fragment load
-  // touches 64 lines per instruction for 16 bytes each.  A whole tile (NB blocks) is in flight: block cb of tile t + 1 is
-  // requested as soon as block cb of tile t has been normalised and staged through the wave-private swizzled LDS tile
-  // (XPF = 3 blocks in flight).
-  constexpr int CB = CF::CB, NB = CF::NB, KPB = CF::KPB, PPR = CB / 8, RPI = 64 / PPR, XI = 32 / RPI;
-  static_assert(CB == 64, "the staging tile's swizzle is laid out for 128-byte row blocks");
-  const int xpc = lane % PPR, xrw = lane / PPR;          // this lane's 16-byte piece of the row block, first row
-  const bf16* xsrc = p.x + ((size_t)b * T + (size_t)wave * TPW * 32 + xrw) * C + xpc * 8;
-  constexpr int XPF = NB < 3 ? NB : 3;                     // blocks in flight (3 x 16 registers)
-  bf16x8 xl[XPF][XI];
-  auto xload = [&](int g) {                                // block g = (tile g / NB, channel block g % NB) -> slot g % XPF
-    const int tt = g / NB, cb = g - tt * NB;
-#pragma unroll
-    for (int i = 0; i < XI; ++i) xl[g % XPF][i] = ld16<bf16x8>(xsrc + (size_t)(tt * 32 + i * RPI) * C + cb * CB);
-  };
-#pragma unroll
-  for (int g = 0; g < XPF; ++g) xload(g);
+  // (c) this wave's first token tile, as MFMA fragments: lane (token, half) reads the 16 bytes of K step kk at
+  //     channel 16 kk + 8 half (the two halves of a token are adjacent: 32-byte runs, 4 K steps per 128-byte line;
+  //     the loads of a tile are issued back to back so that a line is re-used while it is still in the L1)
+  //     (requested after the statistics have been consumed: at launch every workgroup of the chip is in its prologue
+  //      and the burst is bandwidth-bound; the tile is not needed before the projection)
+  constexpr int XPF = CK < 12 ? CK : 12;                       // K steps in flight (48 registers)
+  const bf16* xrow0 = p.x + ((size_t)b * T + (size_t)wave * TPW * 32 + ln) * C + hi * 8;
+  bf16x8 xr[XPF];
 
-  // ---- consume: scale / shift per channel
+  // ---- consume: per-channel scale a, group mean mu, beta -> LDS
   for (int g0 = 0; g0 < p.G; g0 += NW * 4) {
     const int g = g0 + wave * 4 + q4;
     if (g0 > 0) {                                          // (more than 4 NW groups: the small test shapes)
@@ -185,7 +183,7 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
           s2 += (double)sv[u][1];
         }
       }
-      if (j0 + 16 * SV >= nst) break;                       // (wave-uniform: nst and ql's stride are)
+      if (j0 + 16 * SV >= nst) break;                       // (wave-uniform)
       stats_issue(g, j0 + 16 * SV);
     }
 #pragma unroll
@@ -197,26 +195,62 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
       float mean, rstd;
       gn_mean_rstd(s1, s2, (double)T * cpg, p.eps, mean, rstd);
       const int c = g * cpg + ql;
-      const float k = rstd * gam;
-      sA[c] = k;
-      sS[c] = bet - mean * k;
+      sA[c] = rstd * gam;
+      sMu[c] = mean;
+      sBt[c] = bet;
     }
   }
-  // ---- weights, biases, constants -> LDS
-#pragma unroll
-  for (int i = 0; i < WNP; ++i) {
-    const int id = tid + i * NTHR;
-    const int row = id / WPR, pc = id - row * WPR;
-    if (id < 3 * D * WPR) st16<bf16x8>(sW + row * RW + pc * 16, wr[i]);
-  }
-  if (tid < 96) sB[tid] = bias_r;
   if (tid < 3) {
     bf16x8 v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (bf16)((tid == 1 || (tid == 0 && e == 0)) ? 1.0f : 0.0f);
     st16<bf16x8>(sC + tid * 16, v);
   }
+  float* sB0 = sKN + 16;                                     // the layer's own q | k | v biases of this head (see KN_BYTES)
+#pragma unroll
+  for (int i = 0; i < BRN; ++i)
+    if (tid + i * NTHR < 96) sB0[tid + i * NTHR] = bias_r[i];
   stamp(1);
+  __syncthreads();
+#pragma unroll
+  for (int kk = 0; kk < XPF; ++kk) xr[kk] = ld16<bf16x8>(xrow0 + kk * 16);
+  // ---- W' = bf16(W a) -> LDS (padded rows); per (row, piece) partial of the folded bias -> scratch (aliases K)
+  float* sPart = reinterpret_cast<float*>(smem + CF::OFF_K);
+#pragma unroll
+  for (int i = 0; i < WNP; ++i) {
+    const int id = tid + i * NTHR;
+    const int row = id / WPR, pc = id - row * WPR;
+    if (id < 3 * D * WPR) {
+      const f32x4 a0 = ld16<f32x4>(sA + pc * 8), a1 = ld16<f32x4>(sA + pc * 8 + 4);
+      const f32x4 m0 = ld16<f32x4>(sMu + pc * 8), m1 = ld16<f32x4>(sMu + pc * 8 + 4);
+      const f32x4 b0 = ld16<f32x4>(sBt + pc * 8), b1 = ld16<f32x4>(sBt + pc * 8 + 4);
+      bf16x8 wf;
+      float part = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float w = (float)wr[i][e];
+        const float av = e < 4 ? a0[e] : a1[e - 4], mv = e < 4 ? m0[e] : m1[e - 4], bv = e < 4 ? b0[e] : b1[e - 4];
+        wf[e] = (bf16)(w * av);
+        part += w * bv - (float)wf[e] * mv;
+      }
+      st16<bf16x8>(sW + row * RW + pc * 16, wf);
+      sPart[id] = part;
+    }
+  }
+  __syncthreads();
+  for (int t4 = tid; t4 < 96 * 4; t4 += NTHR) {              // folded biases: 4 lanes per row, fixed order of additions
+    const int o = t4 >> 2, part = t4 & 3, m = o >> 5, r = o & 31;
+    constexpr int PPL = WPR / 4;
+    float v[PPL];
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) v[i] = r < D ? sPart[(m * D + r) * WPR + part * PPL + i] : 0.f;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) acc += v[i];
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (part == 0) sB[o] = acc + sB0[o];                       // + the layer's own bias (staged before the first barrier)
+  }
   __syncthreads();
   stamp(2);
 
@@ -229,91 +263,60 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
   const char* wq_base = sW + (0 * D + (sig < D ? sig : sig - 16)) * RW + hi * 16;       // + kk * 32
   const char* wk_base = sW + (1 * D + (sig < D ? sig : sig - 16)) * RW + hi * 16;
   const char* wv_base = sW + (2 * D + (ln < D ? ln : ln - 16)) * RW + hi * 16;
-  char* xs = smem + CF::OFF_XS + wave * CF::XS_WAVE;
-  // staging tile: token t, 16-byte piece pc -> row swap03(t) (bits 0 and 3 exchanged), piece pc ^ (t & (PPR - 1)): the 16
-  // lanes of a ds_read_b128 group (tokens distinct mod 16, one piece) then fall on 16 different bank quads
-  auto xs_off = [&](int t, int pc) {
-    const int row = (t & ~9) | ((t & 1) << 3) | ((t >> 3) & 1);
-    return row * (CB * 2) + ((pc ^ (t & (PPR - 1))) << 4);
-  };
 
   bf16x8 qf[TPW][2];     // Q as B fragments (scaled by scale * log2 e), chunk c = channels 16c + 8 half + e
   float qn2[TPW];        // |q|^2 of this lane's query (of the bf16 values that enter the MFMA), per tile
   float kn2 = 0.f;       // max |k|^2 over this lane's keys
+  const float bv = sB[2 * 32 + ln];                        // v: lane (channel d, half), every register is channel d
 #pragma unroll
   for (int tt = 0; tt < TPW; ++tt) {
     const int tok0 = (wave * TPW + tt) * 32;               // first token of the tile (within the sample)
     f32x16 aq, ak, av;
-    {
-      // accumulators start at the bias: q / k lane (token, half): register r = 8c + e -> channel 16c + 8 half + e
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const f32x4 bq0 = ld16<f32x4>(sB + 0 * 32 + 16 * c + 8 * hi), bq1 = ld16<f32x4>(sB + 0 * 32 + 16 * c + 8 * hi + 4);
-        const f32x4 bk0 = ld16<f32x4>(sB + 1 * 32 + 16 * c + 8 * hi), bk1 = ld16<f32x4>(sB + 1 * 32 + 16 * c + 8 * hi + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          aq[8 * c + e] = bq0[e];
-          aq[8 * c + 4 + e] = bq1[e];
-          ak[8 * c + e] = bk0[e];
-          ak[8 * c + 4 + e] = bk1[e];
-        }
-      }
-      const float bv = sB[2 * 32 + ln];                    // v: lane (channel d, half), every register is channel d
-#pragma unroll
-      for (int r = 0; r < 16; ++r) av[r] = bv;
+    for (int r = 0; r < 16; ++r) {
+      aq[r] = 0.f;
+      ak[r] = 0.f;
+      av[r] = bv;
     }
+    // (W' fragments one K step ahead of their MFMAs: two waves per SIMD do not cover an LDS round trip per step)
+    bf16x8 wq = ld16<bf16x8>(wq_base), wk = ld16<bf16x8>(wk_base), wv = ld16<bf16x8>(wv_base);
 #pragma unroll
-    for (int cb = 0; cb < NB; ++cb) {
-      const int g = tt * NB + cb;
-      // ---- normalise the landed block (this lane: one channel octet, XI rows) and stage it
-      const f32x4 a0 = ld16<f32x4>(sA + cb * CB + xpc * 8), a1 = ld16<f32x4>(sA + cb * CB + xpc * 8 + 4);
-      const f32x4 s0 = ld16<f32x4>(sS + cb * CB + xpc * 8), s1 = ld16<f32x4>(sS + cb * CB + xpc * 8 + 4);
-#pragma unroll
-      for (int i = 0; i < XI; ++i) {
-        bf16x8 xb;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          xb[e] = (bf16)((float)xl[g % XPF][i][e] * a0[e] + s0[e]);
-          xb[4 + e] = (bf16)((float)xl[g % XPF][i][4 + e] * a1[e] + s1[e]);
-        }
-        st16<bf16x8>(xs + xs_off(xrw + i * RPI, xpc), xb);
+    for (int kk = 0; kk < CK; ++kk) {
+      const bf16x8 xb = xr[kk % XPF];
+      const bf16x8 wq_c = wq, wk_c = wk, wv_c = wv;
+      if (kk + 1 < CK && !(DBG & 16)) {
+        wq = ld16<bf16x8>(wq_base + (kk + 1) * 32);
+        wk = ld16<bf16x8>(wk_base + (kk + 1) * 32);
+        wv = ld16<bf16x8>(wv_base + (kk + 1) * 32);
       }
-      if (g + XPF < TPW * NB) xload(g + XPF);              // block g + XPF takes the freed registers
-      // (the tile is exchanged across the lanes of THIS wave only: LDS operations of a wave execute in order; the fences
-      //  pin the compiler's order of the stores above and the fragment reads below)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-      for (int k4 = 0; k4 < KPB; ++k4) {
-        const int kk = cb * KPB + k4;
-        const bf16x8 xb = ld16<bf16x8>(xs + xs_off(ln, 2 * k4 + hi));
-        const bf16x8 wq = ld16<bf16x8>(wq_base + kk * 32);
-        const bf16x8 wk = ld16<bf16x8>(wk_base + kk * 32);
-        const bf16x8 wv = ld16<bf16x8>(wv_base + kk * 32);
-        if (!(DBG & 4)) {
-          aq = mfma32(wq, xb, aq);          // [channel x token]
-          ak = mfma32(wk, xb, ak);          // [channel x token]
-          av = mfma32(xb, wv, av);          // [token x channel]: lane = channel, registers = tokens
-        } else {
-          aq[0] += (float)wq[0] + (float)xb[0];
-          ak[0] += (float)wk[0];
-          av[0] += (float)wv[0];
-        }
+      // the freed register takes K step kk + XPF: of this tile, or of the next one
+      if (!(DBG & 8)) {
+        if (kk + XPF < CK) xr[kk % XPF] = ld16<bf16x8>(xrow0 + (size_t)tt * 32 * C + (kk + XPF) * 16);
+        else if (tt + 1 < TPW) xr[kk % XPF] = ld16<bf16x8>(xrow0 + (size_t)(tt + 1) * 32 * C + (kk + XPF - CK) * 16);
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // fragment reads done before the next block overwrites the tile
-      __builtin_amdgcn_wave_barrier();
+      if (!(DBG & 4)) {
+        aq = mfma32(wq_c, xb, aq);        // [channel x token]
+        ak = mfma32(wk_c, xb, ak);        // [channel x token]
+        av = mfma32(xb, wv_c, av);        // [token x channel]: lane = channel, registers = tokens
+      } else {
+        aq[0] += (float)wq_c[0] + (float)xb[0];
+        ak[0] += (float)wk_c[0];
+        av[0] += (float)wv_c[0];
+      }
     }
     // ---- tile epilogue: Q -> registers, K / V^T -> LDS; squared norms of the rounded rows (Cauchy-Schwarz bound on
     // the scores: decides, per wave, whether the attention loop has to track row maxima at all)
     float qs = 0.f, ks = 0.f;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
+      // folded biases: q / k register r = 8c + e -> channel 16c + 8 half + e
+      const f32x4 bq0 = ld16<f32x4>(sB + 0 * 32 + 16 * c + 8 * hi), bq1 = ld16<f32x4>(sB + 0 * 32 + 16 * c + 8 * hi + 4);
+      const f32x4 bk0 = ld16<f32x4>(sB + 1 * 32 + 16 * c + 8 * hi), bk1 = ld16<f32x4>(sB + 1 * 32 + 16 * c + 8 * hi + 4);
       bf16x8 qv, kv;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        qv[e] = (bf16)(aq[8 * c + e] * p.qscale);
-        kv[e] = (bf16)ak[8 * c + e];
+        qv[e] = (bf16)((aq[8 * c + e] + (e < 4 ? bq0[e] : bq1[e - 4])) * p.qscale);
+        kv[e] = (bf16)(ak[8 * c + e] + (e < 4 ? bk0[e] : bk1[e - 4]));
       }
       const bool real = 16 * c + 8 * hi + 8 <= D;          // this lane's chunk c holds real channels
       if (!real) {
@@ -350,9 +353,10 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
   float kmax2 = 0.f;
 #pragma unroll
   for (int w = 0; w < NW; ++w) kmax2 = fmaxf(kmax2, sKN[w]);
-  // the barrier releases the two waves of every SIMD in step: their matrix and vector segments would then coincide
-  // instead of interleaving until the waves drift apart on their own (the first pass measured 21 us against 12 for the
-  // second).  The second-dispatched half starts half a key tile late.
+  // (experiment switch AFLDM_ATTNF_STAGGER: the second-dispatched half of the waves starts the attention phase late so
+  //  that the two waves of a SIMD do not run their matrix / vector segments in step - measured: no effect; the first pass
+  //  of a wave pair looks 1.6x longer than the second in the stamps only because the older wave of a SIMD wins the
+  //  arbitration and finishes both passes first, the sum is what it would be either way)
   if (wave >= NW / 2)
     for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
 
@@ -583,6 +587,9 @@ static int attnf_launch_dbg(const AttnFP& p, hipStream_t st) {
     case 1: return attnf_launch<D, NW, TPW, CK, 1>(p, st);
     case 2: return attnf_launch<D, NW, TPW, CK, 2>(p, st);
     case 4: return attnf_launch<D, NW, TPW, CK, 4>(p, st);
+    case 8: return attnf_launch<D, NW, TPW, CK, 8>(p, st);
+    case 16: return attnf_launch<D, NW, TPW, CK, 16>(p, st);
+    case 24: return attnf_launch<D, NW, TPW, CK, 24>(p, st);
     default: return attnf_launch<D, NW, TPW, CK, 0>(p, st);
   }
 }
@@ -624,7 +631,7 @@ extern "C" int afldm_attn_block_fused(const void* x, const float* stats, int S, 
   p.o = (bf16*)o; p.B = B; p.heads = heads; p.C = C; p.G = G; p.eps = eps;
   p.qscale = scale * 1.4426950408889634f;
   {
-    static const int stg = getenv("AFLDM_ATTNF_STAGGER") ? atoi(getenv("AFLDM_ATTNF_STAGGER")) : 3;
+    static const int stg = getenv("AFLDM_ATTNF_STAGGER") ? atoi(getenv("AFLDM_ATTNF_STAGGER")) : 0;      // (measured: no effect)
     p.stagger = stg;
   }
   {

@@ -842,6 +842,8 @@ def attention(q, k, vt, heads, scale=None, out=None):
 _FUSED_ATTN = os.environ.get("AFLDM_NO_FUSED_ATTN", "0") != "1"
 # below this many (sample, head) workgroups the chip is not filled by one workgroup per pair: the three-launch path wins
 _FUSED_ATTN_MIN_WGS = int(os.environ.get("AFLDM_FUSED_ATTN_MIN_WGS", "256"))
+# fewest tokens per sample the fused launch is used for (in-step A/B decides between the 32^2 level only and 32^2 + 16^2)
+_FUSED_ATTN_MIN_T = int(os.environ.get("AFLDM_FUSED_ATTN_MIN_T", "256"))
 
 
 def attn_block_fused_ok(x, heads, G):
@@ -849,7 +851,7 @@ def attn_block_fused_ok(x, heads, G):
     if not _FUSED_ATTN or x.dtype != torch.bfloat16:
         return False
     B, T, C = x.shape
-    if B * heads < _FUSED_ATTN_MIN_WGS:
+    if B * heads < _FUSED_ATTN_MIN_WGS or T < _FUSED_ATTN_MIN_T:
         return False
     return bool(lib.afldm_attn_block_fused_supported(T, C, C // heads, int(G)))
 

@@ -11,5 +11,6 @@ def run(env_extra, tag):
     d = json.loads(line[-1])
     print(tag, d["ms_per_step"], d["config"]["regions_ms_per_step"], flush=True)
 for rep in range(2):
-    run({"AFLDM_NO_FUSED_ATTN": "1"}, "three-launch")
-    run({}, "fused       ")
+    run({"AFLDM_NO_FUSED_ATTN": "1"}, "three-launch      ")
+    run({"AFLDM_FUSED_ATTN_MIN_T": "1024"}, "fused 32^2        ")
+    run({"AFLDM_FUSED_ATTN_MIN_T": "256"}, "fused 32^2 + 16^2 ")
