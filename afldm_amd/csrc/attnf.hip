@@ -63,12 +63,10 @@ struct AttnFCfg {
   static constexpr int W_BYTES = 3 * D * RW;
   static constexpr int AS_BYTES = C * 12;               // a[C], mu[C], beta[C] fp32 (GroupNorm folded into the weights)
   static constexpr int BIAS_BYTES = 3 * 32 * 4;         // folded q | k | v biases of this head, padded to 32, fp32
-  static constexpr int KN_BYTES = 64 + 96 * 4;          // per-wave max |k|^2 (fp32) [16 floats] + the layer's own biases [96]
+  static constexpr int KN_BYTES = 64;                   // per-wave max |k|^2 (fp32)
   static constexpr int OFF_K = 0, OFF_V = OFF_K + K_BYTES, OFF_CST = OFF_V + V_BYTES, OFF_W = OFF_CST + CST_BYTES,
                        OFF_AS = OFF_W + W_BYTES, OFF_BIAS = OFF_AS + AS_BYTES, OFF_KN = OFF_BIAS + BIAS_BYTES,
                        LDS_BYTES = OFF_KN + KN_BYTES;
-  static constexpr int PART_BYTES = 3 * D * (C / 8) * 4;   // per-(row, 16-byte piece) bias partials: aliases the K / V^T region
-  static_assert(PART_BYTES <= K_BYTES + V_BYTES, "bias partials must fit the (not yet written) K / V^T region");
   static constexpr int NU = TPW >= 2 ? 2 : 1;           // query tiles per attention pass
   static constexpr int PADC = D / 16, PADHI = (D % 16) / 8;   // where slot D sits: chunk, lane half (element 0)
 };
@@ -95,7 +93,7 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
   const int wi = xcd_remap(blockIdx.x, gridDim.x);
   const int b = wi / p.heads, h = wi - b * p.heads;
   auto stamp = [&](int i) {
-    if (p.trace && lane == 0) p.trace[((size_t)blockIdx.x * NW + wave) * 8 + i] = __builtin_amdgcn_s_memtime();
+    if (p.trace && lane == 0) p.trace[((size_t)blockIdx.x * NW + wave) * 12 + i] = __builtin_amdgcn_s_memtime();
   };
   stamp(0);
 
@@ -136,23 +134,22 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
     }
     stats_issue(g, ql);
   }
-  // (b) the head's 3 D weight rows
+  // (b) the head's 3 D weight rows: LPR lanes per row, each PPT 16-byte pieces (interleaved) - the folded bias of a row is
+  //     then a register sum + LPR-lane shuffle (no scratch, no extra barrier)
   constexpr int WPR = C / 8;                                   // 16-byte pieces per weight row
-  constexpr int WNP = (3 * D * WPR + NTHR - 1) / NTHR;         // pieces per thread
-  bf16x8 wr[WNP];
+  constexpr int LPR = NTHR >= 3 * D * 4 ? 4 : NTHR >= 3 * D * 2 ? 2 : 1;
+  constexpr int PPT = WPR / LPR;
+  static_assert(WPR % LPR == 0 && 3 * D * LPR <= NTHR, "weight rows must divide among the threads");
+  const int wrow = tid / LPR, wpart = tid % LPR;               // row 0 .. 3D-1 of (q | k | v), lane inside the row
+  const bool wlive = wrow < 3 * D;
+  const int wm = wlive ? wrow / D : 0, wrr = wlive ? wrow - wm * D : 0;
+  bf16x8 wr[PPT];
+  float bias_r = 0.f;
+  if (wlive) {
+    const bf16* wsrc = p.w + ((size_t)wm * C + h * D + wrr) * C;
 #pragma unroll
-  for (int i = 0; i < WNP; ++i) {
-    const int id = tid + i * NTHR;
-    const int row = id / WPR, pc = id - row * WPR;
-    const int m = row / D, r = row - m * D;
-    if (id < 3 * D * WPR) wr[i] = ld16<bf16x8>(p.w + ((size_t)m * C + h * D + r) * C + pc * 8);
-  }
-  constexpr int BRN = (96 + NTHR - 1) / NTHR;
-  float bias_r[BRN];
-#pragma unroll
-  for (int i = 0; i < BRN; ++i) {
-    const int o = tid + i * NTHR;
-    bias_r[i] = (o < 96 && (o & 31) < D) ? p.bias[(o >> 5) * C + h * D + (o & 31)] : 0.f;
+    for (int i = 0; i < PPT; ++i) wr[i] = ld16<bf16x8>(wsrc + (wpart + LPR * i) * 8);
+    bias_r = p.bias[wm * C + h * D + wrr];
   }
   // (c) this wave's first token tile, as MFMA fragments: lane (token, half) reads the 16 bytes of K step kk at
   //     channel 16 kk + 8 half (the two halves of a token are adjacent: 32-byte runs, 4 K steps per 128-byte line;
@@ -206,26 +203,21 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
     for (int e = 0; e < 8; ++e) v[e] = (bf16)((tid == 1 || (tid == 0 && e == 0)) ? 1.0f : 0.0f);
     st16<bf16x8>(sC + tid * 16, v);
   }
-  float* sB0 = sKN + 16;                                     // the layer's own q | k | v biases of this head (see KN_BYTES)
-#pragma unroll
-  for (int i = 0; i < BRN; ++i)
-    if (tid + i * NTHR < 96) sB0[tid + i * NTHR] = bias_r[i];
   stamp(1);
   __syncthreads();
+  stamp(8);
 #pragma unroll
   for (int kk = 0; kk < XPF; ++kk) xr[kk] = ld16<bf16x8>(xrow0 + kk * 16);
-  // ---- W' = bf16(W a) -> LDS (padded rows); per (row, piece) partial of the folded bias -> scratch (aliases K)
-  float* sPart = reinterpret_cast<float*>(smem + CF::OFF_K);
+  // ---- W' = bf16(W a) -> LDS (padded rows); folded bias of the row
+  if (wlive) {
+    float part = 0.f;
 #pragma unroll
-  for (int i = 0; i < WNP; ++i) {
-    const int id = tid + i * NTHR;
-    const int row = id / WPR, pc = id - row * WPR;
-    if (id < 3 * D * WPR) {
+    for (int i = 0; i < PPT; ++i) {
+      const int pc = wpart + LPR * i;
       const f32x4 a0 = ld16<f32x4>(sA + pc * 8), a1 = ld16<f32x4>(sA + pc * 8 + 4);
       const f32x4 m0 = ld16<f32x4>(sMu + pc * 8), m1 = ld16<f32x4>(sMu + pc * 8 + 4);
       const f32x4 b0 = ld16<f32x4>(sBt + pc * 8), b1 = ld16<f32x4>(sBt + pc * 8 + 4);
       bf16x8 wf;
-      float part = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float w = (float)wr[i][e];
@@ -233,24 +225,14 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
         wf[e] = (bf16)(w * av);
         part += w * bv - (float)wf[e] * mv;
       }
-      st16<bf16x8>(sW + row * RW + pc * 16, wf);
-      sPart[id] = part;
+      st16<bf16x8>(sW + wrow * RW + pc * 16, wf);
     }
-  }
-  __syncthreads();
-  for (int t4 = tid; t4 < 96 * 4; t4 += NTHR) {              // folded biases: 4 lanes per row, fixed order of additions
-    const int o = t4 >> 2, part = t4 & 3, m = o >> 5, r = o & 31;
-    constexpr int PPL = WPR / 4;
-    float v[PPL];
 #pragma unroll
-    for (int i = 0; i < PPL; ++i) v[i] = r < D ? sPart[(m * D + r) * WPR + part * PPL + i] : 0.f;
-    float acc = 0.f;
-#pragma unroll
-    for (int i = 0; i < PPL; ++i) acc += v[i];
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    if (part == 0) sB[o] = acc + sB0[o];                       // + the layer's own bias (staged before the first barrier)
+    for (int o = 1; o < LPR; o <<= 1) part += __shfl_xor(part, o, 64);       // (a row's LPR lanes are adjacent lanes of one wave)
+    if (wpart == 0) sB[wm * 32 + wrr] = part + bias_r;
+    if (wpart == LPR - 1 && wrr < 32 - D) sB[wm * 32 + D + wrr] = 0.f;        // the padding entries of the 32-wide bias rows
   }
+  stamp(9);
   __syncthreads();
   stamp(2);
 
@@ -598,7 +580,7 @@ static int attnf_launch_dbg(const AttnFP& p, hipStream_t st) {
 
 using namespace afldm;
 
-// diagnostic: device buffer of [workgroups][waves][8] uint64 that the next launches fill with s_memtime stamps
+// diagnostic: device buffer of [workgroups][waves][12] uint64 that the next launches fill with s_memtime stamps
 // (0 start, 1 / 2 before / after the prologue barrier, 3 / 4 before / after the barrier that ends the projection,
 //  5 / 6 end of the first / second attention pass); NULL switches it off
 extern "C" int afldm_attn_block_fused_trace(void* buf) {

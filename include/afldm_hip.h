@@ -304,7 +304,7 @@ int afldm_attention(const void* q, int ldq, const void* k, int ldk, const void* 
  * G groups).  Same rounding points as afldm_gn_apply + afldm_conv2d + afldm_attention (normalised tokens, q, k, v and the
  * softmax weights in bf16) except that the softmax scale is applied to q before its rounding. */
 int afldm_attn_block_fused_supported(int T, int C, int head_dim, int G);
-/* diagnostic: device buffer [workgroups][waves][8] of 64-bit shader-clock stamps that later afldm_attn_block_fused
+/* diagnostic: device buffer [workgroups][waves][12] of 64-bit shader-clock stamps that later afldm_attn_block_fused
  * launches fill (phase boundaries per wave; csrc/attnf.hip), NULL = off (the default). */
 int afldm_attn_block_fused_trace(void* buf);
 int afldm_attn_block_fused(const void* x, const float* stats, int S, const float* gamma, const float* beta, int G,

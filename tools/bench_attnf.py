@@ -28,12 +28,12 @@ def main():
         if os.environ.get("TRACE"):
             from afldm_amd import _lib
             nwg, nw = B * heads, 8
-            tr = torch.zeros(nwg * nw * 8, dtype=torch.int64, device="cuda")
+            tr = torch.zeros(nwg * nw * 12, dtype=torch.int64, device="cuda")
             _lib.lib.afldm_attn_block_fused_trace(tr.data_ptr())
             ops.attn_block_fused(x, st, gamma, beta, 32, 1e-5, w, b, heads, scale, out=out)
             torch.cuda.synchronize()
             _lib.lib.afldm_attn_block_fused_trace(None)
-            tr = tr.view(nwg, nw, 8).cpu().double()
+            tr = tr.view(nwg, nw, 12).cpu().double()
             # (the stamp counters of the 8 XCDs are not aligned: only differences inside a workgroup mean anything; the tick
             #  is calibrated on launch time / rounds of workgroups, one workgroup per CU)
             names = ["start", "prologue", "barrier", "projection", "barrier", "pass 1", "pass 2", "epilogue"]
@@ -49,6 +49,12 @@ def main():
                 seg.append(f"{names[i]} {d * tick_us:.1f} us ({100 * d / total:.0f} %)")
                 prev = i
             print(f"   per workgroup ({rounds} rounds, {total:.0f} ticks = {total * tick_us:.1f} us): " + " | ".join(seg), flush=True)
+            if float(tr[:, :, 8].max()) > 0:
+                w1 = float((rel[:, :, 8] - rel[:, :, 1]).mean()) * tick_us
+                fo = float((rel[:, :, 9] - rel[:, :, 8]).mean()) * tick_us
+                w2 = float((rel[:, :, 2] - rel[:, :, 9]).mean()) * tick_us
+                spread = float((rel[:, :, 1].max(1).values - rel[:, :, 1].min(1).values).mean()) * tick_us
+                print(f"   fold phase: wait at barrier 1 {w1:.2f} us (arrival spread of a workgroup's waves {spread:.2f}) | x issue + fold {fo:.2f} | barrier 2 {w2:.2f}")
         if os.environ.get("AFLDM_ATTNF_DBG") or os.environ.get("QUICK"):
             print(f"  dbg={os.environ.get('AFLDM_ATTNF_DBG')} stagger={os.environ.get('AFLDM_ATTNF_STAGGER')} T={T} C={C}: fused {t_f:7.1f} us", flush=True)
             continue

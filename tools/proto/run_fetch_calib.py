@@ -6,15 +6,16 @@ import ctypes, csv, glob, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 P, ROW = 1 << 20, 384            # 1 Mi pixels x 192 bf16 channels = 384 MiB (> the 256 MiB Infinity Cache)
 if len(sys.argv) > 1 and sys.argv[1] == "report":
-    f = glob.glob(sys.argv[2] + "/**/*counter_collection.csv", recursive=True)[0]
-    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == "FETCH_SIZE"]
     true = P * ROW
     lines = []
-    for r in rows:
-        n = r["Kernel_Name"]
-        if "k_pieces" in n or "k_stream" in n:
-            kb = float(r["Counter_Value"])
-            lines.append(f"{n[:40]:40s} FETCH_SIZE*1024 / true bytes = {kb * 1024 / true:.3f}")
+    unit = {"FETCH_SIZE": 1024.0, "TCC_MISS_sum": 128.0, "TCC_EA0_RDREQ_sum": 64.0, "TCC_EA0_RDREQ_32B_sum": 32.0, "TCC_BUBBLE_sum": 128.0,
+            "TCC_REQ_sum": 128.0, "TCC_HIT_sum": 128.0}
+    for f in glob.glob(sys.argv[2] + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            n = r["Kernel_Name"]
+            if ("k_pieces" in n or "k_stream" in n) and r["Counter_Name"] in unit:
+                v = float(r["Counter_Value"])
+                lines.append(f"{n[:32]:32s} {r['Counter_Name']:22s} x {unit[r['Counter_Name']]:6.0f} B / true bytes = {v * unit[r['Counter_Name']] / true:.3f}")
     print("\n".join(lines))
     open("gpurun_out/fetch_calib.txt", "w").write("\n".join(lines) + "\n")
     sys.exit(0)
