@@ -1605,6 +1605,8 @@ static const Variant kVariants[] = {
     {256, 128, 6, 3},  // 60  = 58 on 32x32x16 MFMAs
     {128, 96, 6, 2},   // 61  halo-patch, 32x32 planes, 128 x 96 tiles sized for TWO workgroups per CU (4 + 2 waves, 2-deep ring)
     {128, 96, 6, 2},   // 62  the same for 16x16 planes
+    {256, 128, 6, 3},  // 63  = 58 with persistent workgroups (k_conv3h_pers: one workgroup per CU walks its tiles)
+    {128, 192, 6, 3},  // 64  32x32 planes, 4 rows x 192 couts per tile, persistent workgroups (two tiles per CU at batch 64)
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -1716,8 +1718,9 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
     static const bool off = getenv("AFLDM_NO_CONV3H_SUB") != nullptr;
     if (!off && a->KS == 3 && a->C2 == 0 && a->W >= 64 && a->W % 32 == 0 && a->H % 8 == 0 && a->Cout % 128 == 0 &&
         Ct % (2 * elems_per_row) == 0 && M >= 256 * 192) {
-      static const int s_subv = getenv("AFLDM_CONV3H_SUBV") ? atoi(getenv("AFLDM_CONV3H_SUBV")) : 58;     // 58 / 59 / 60 (A/B)
-      vid = s_subv >= 58 && s_subv <= 60 ? s_subv : 58;
+      static const int s_subv = getenv("AFLDM_CONV3H_SUBV") ? atoi(getenv("AFLDM_CONV3H_SUBV")) : 63;     // 58 / 59 / 60 / 63 (A/B)
+      vid = (s_subv >= 58 && s_subv <= 60) || s_subv == 63 ? s_subv : 58;
+      if (vid == 63 && !(elems_per_row == 32 && M / 256 * (a->Cout / 128) >= 512)) vid = 58;      // bf16; persistent tiles pay from two tiles per CU
     }
   }
   {

@@ -335,3 +335,54 @@ def test_unet_forward_through_fused_attention_blocks(golden, cfg_name, monkeypat
     print(f"[UNet through fused attention] {cfg_name}: {len(calls)} fused blocks; vs oracle {r_f:.3e} (three-launch {r_o:.3e}); "
           f"fused vs three-launch {rel_rms(y_f.float(), y_o.float().cpu()):.3e}")
     assert r_f <= 2e-2 and r_f <= 2.0 * r_o + 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ persistent halo-patch tiles
+@pytest.mark.parametrize("case", [
+    # variant, reference variant, B, H, W, Cin, Cout, temb, residual
+    (63, 58, 5, 64, 64, 128, 128, False, True),      # 80 tiles of 8 x 32: every workgroup gets exactly one ... at 256 CUs; B below gives several
+    (63, 58, 40, 64, 64, 128, 128, True, True),      # 640 tiles: 2-3 per workgroup, producers run across tile boundaries
+    (63, 58, 9, 128, 128, 128, 256, False, False),   # two n tiles, 1152 tiles: 4-5 per workgroup
+    (63, 58, 3, 72, 96, 128, 256, False, True),      # non-square plane (9 x 3 blocks of 8 x 32 pixels)
+    (64, 46, 24, 32, 32, 192, 192, True, True),      # UNet 32^2 level: 4 rows per tile, 192 tiles
+    (64, 46, 66, 32, 32, 384, 192, False, True),     # 528 tiles: 2-3 per workgroup, ragged
+])
+def test_conv3x3_halo_patch_persistent_tiles_bit_identical(case):
+    """conv3h.hip k_conv3h_pers (round 4): persistent workgroups whose LDS-DMA producers run on across tile boundaries
+    (next tile's first patch / weights land while the epilogue of the current tile is staged through the other patch
+    buffer) must be BIT-IDENTICAL - output and GroupNorm partial sums - to the one-tile-per-workgroup kernel of the same
+    tile shape, and match F.conv2d."""
+    import ctypes
+    import torch.nn.functional as F
+    from afldm_amd import _lib, ops
+    vid, ref_vid, B, H, W, Cin, Cout, use_temb, use_res = case
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(vid + B + H)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dt).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(dt)
+    b = torch.randn(Cout, generator=g).cuda()
+    temb = torch.randn(B, Cout, generator=g).to(dt).cuda() if use_temb else None
+    res = torch.randn(B, H, W, Cout, generator=g).to(dt).cuda() if use_res else None
+    wp = ops.pack_weight(w.float().cuda(), dt)
+    outs = {}
+    for v in (vid, ref_vid):
+        try:
+            _lib.check(_lib.lib.afldm_conv2d_tune(v, -1), "tune")
+            ys = [ops.conv2d(x, wp, b, temb=temb, temb_stride=Cout if use_temb else 0, residual=res, want_stats=True) for _ in range(2)]
+            probe = ops.conv_args(x, wp, b, temb=temb, temb_stride=Cout if use_temb else 0, residual=res, out=ys[0])
+            assert _lib.lib.afldm_conv2d_variant(ctypes.byref(probe)) & 255 == v, f"variant {v} did not take this shape"
+        finally:
+            _lib.lib.afldm_conv2d_tune(-1, -1)
+        torch.cuda.synchronize()
+        assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0].gn_partial, ys[1].gn_partial)
+        outs[v] = ys[0]
+    assert torch.equal(outs[vid], outs[ref_vid]), float((outs[vid].float() - outs[ref_vid].float()).abs().max())
+    assert torch.equal(outs[vid].gn_partial, outs[ref_vid].gn_partial)
+    # and against F.conv2d on a few samples
+    for i in (0, B - 1):
+        ref = F.conv2d(x[i:i + 1].float().permute(0, 3, 1, 2).cpu(), w.float(), b.cpu(), padding=1)
+        if use_temb:
+            ref = ref + temb[i].float().cpu()[None, :, None, None]
+        if use_res:
+            ref = ref + res[i:i + 1].float().permute(0, 3, 1, 2).cpu()
+        assert rel_rms(outs[vid][i:i + 1].float().permute(0, 3, 1, 2), ref) <= 6e-3
