@@ -93,6 +93,8 @@ def _load():
         "afldm_select_step_row": ([vp, vp, vp, ip, vp, vp, c_size_t, vp], c_int),
         "afldm_probe_mfma": ([vp, ip, ip, vp], c_int),
         "afldm_probe_copy": ([vp, vp, c_size_t, vp], c_int),
+        "afldm_probe_chase": ([vp, vp, ip, vp], c_int),
+        "afldm_probe_empty": ([ip, vp], c_int),
     }
     for name, (argtypes, restype) in sigs.items():
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch

@@ -361,6 +361,34 @@ extern "C" int afldm_probe_mfma(float* out, int workgroups, int iters, afldm_str
   return check_launch("afldm_probe_mfma");
 }
 
+// dependent-load chain (one lane): next = buf[next]; `buf` holds ONE cycle over its n entries (host-built), the stride
+// between consecutive elements of the cycle is what the host chose (>= a cache line: every step misses).  out[0] = the
+// final index (keeps the chain alive), out[1] = elapsed shader-clock ticks (s_memtime).
+__global__ void k_probe_chase(const unsigned* __restrict__ buf, unsigned* __restrict__ out, int steps) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  unsigned i = 0;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int s = 0; s < steps; ++s) i = __builtin_nontemporal_load(buf + i);
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  out[0] = i;
+  out[1] = (unsigned)(t1 - t0);
+}
+__global__ void k_probe_empty(unsigned* out) {
+  if (out == nullptr) return;
+}
+
+extern "C" int afldm_probe_chase(const void* buf, void* out, int steps, afldm_stream_t stream) {
+  AFLDM_REQUIRE(buf && out && steps > 0, AFLDM_ENULL, "afldm_probe_chase: NULL pointer / no steps");
+  k_probe_chase<<<1, 64, 0, (hipStream_t)stream>>>((const unsigned*)buf, (unsigned*)out, steps);
+  return check_launch("afldm_probe_chase");
+}
+
+extern "C" int afldm_probe_empty(int workgroups, afldm_stream_t stream) {
+  AFLDM_REQUIRE(workgroups > 0, AFLDM_ESHAPE, "afldm_probe_empty: no workgroups");
+  k_probe_empty<<<workgroups, 64, 0, (hipStream_t)stream>>>(nullptr);
+  return check_launch("afldm_probe_empty");
+}
+
 extern "C" int afldm_probe_copy(const void* src, void* dst, size_t bytes, afldm_stream_t stream) {
   AFLDM_REQUIRE(src && dst, AFLDM_ENULL, "afldm_probe_copy: NULL pointer");
   AFLDM_REQUIRE(bytes % 16 == 0 && aligned16(src) && aligned16(dst), AFLDM_EALIGN, "afldm_probe_copy: whole 16-byte chunks");

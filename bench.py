@@ -113,7 +113,7 @@ def roofline_pass(unet, batch, dtype):
                             f"algorithmic bytes per launch there: {round(tj['algorithmic_bytes_per_launch'])}")
     except (OSError, ValueError, KeyError) as e:
         traffic_note = f"no usable PMC record ({type(e).__name__})"
-    mfma_bound = name.startswith("conv") or name == "linear" or name == "attention" or name.startswith("af_act_N3") \
+    mfma_bound = name.startswith("conv") or name in ("linear", "attention", "attn_fused") or name.startswith("af_act_N3") \
         or name.startswith("af_act_N16")
     if mfma_bound:
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
@@ -136,7 +136,7 @@ def roofline_pass(unet, batch, dtype):
                     bytes_per_launch=d["bytes"] / d["launches"])
     # whole-step dense rate: the algorithmic MFMA-shaped work of one step (3x3 / 1x1 convolutions, linear layers, attention; the
     # alias-free filters' dense separable form is kept apart) over the TIMED step - filled in by main()
-    dense = sum(agg[k]["flops"] for k in agg if k.startswith("conv") or k in ("linear", "attention")) / 3
+    dense = sum(agg[k]["flops"] for k in agg if k.startswith("conv") or k in ("linear", "attention", "attn_fused")) / 3
     af = sum(agg[k]["flops"] for k in agg if k.startswith("af_")) / 3
     roof["step_dense_tflop"] = round(dense / 1e12, 4)
     roof["step_af_filter_tflop"] = round(af / 1e12, 4)
@@ -208,7 +208,40 @@ def box_record(dev):
     src = torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 255)
     dst = torch.empty_like(src)
     cms = timed(lambda: _lib.check(lib.afldm_probe_copy(src.data_ptr(), dst.data_ptr(), nbytes, st), "probe_copy"), 5)
+    # latency side (the throughput probes did not explain a 4 % spread between two boxes): (a) the boundary
+    # between two dependent EMPTY kernels inside a captured graph (200 launches of 256 workgroups, replayed), (b) the
+    # boundary between two real streaming kernels (the 64 MiB copy probe, captured 20 times), (c) a dependent-load chain
+    # through 256 MiB with a 4 KiB + 128 B stride (every step misses the caches): ns per load
+    def graph_time(fn, n, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(n):
+                fn()
+        t = timed(g.replay, reps)
+        del g
+        return t
+    st2 = lambda: torch.cuda.current_stream().cuda_stream
+    t_empty = graph_time(lambda: _lib.check(lib.afldm_probe_empty(cus, st2()), "probe_empty"), 200)
+    small = 64 << 20
+    t_copy1 = timed(lambda: _lib.check(lib.afldm_probe_copy(src.data_ptr(), dst.data_ptr(), small, st), "probe_copy"), 5)
+    t_copy20 = graph_time(lambda: _lib.check(lib.afldm_probe_copy(src.data_ptr(), dst.data_ptr(), small, st2()), "probe_copy"), 20)
+    nent = (256 << 20) // 4
+    stride = (4096 + 128) // 4
+    steps = 4096
+    idx = (torch.arange(steps + 1, dtype=torch.int64) * stride) % nent
+    chain = torch.zeros(nent, dtype=torch.int32)
+    chain[idx[:-1]] = idx[1:].to(torch.int32)
+    chain = chain.to(dev)
+    cout = torch.zeros(4, dtype=torch.int32, device=dev)
+    _lib.check(lib.afldm_probe_chase(chain.data_ptr(), cout.data_ptr(), steps, st), "probe_chase")
+    torch.cuda.synchronize()
+    t_chase = timed(lambda: _lib.check(lib.afldm_probe_chase(chain.data_ptr(), cout.data_ptr(), steps, st), "probe_chase"), 3)
     rec = dict(mfma_tflops=round(flops / ms / 1e9, 1), mfma_probe_ms=round(ms, 2),
+               graph_empty_kernel_us=round(1e3 * t_empty / 200, 3),
+               graph_copy_boundary_us=round(1e3 * (t_copy20 / 20 - t_copy1), 3),
+               dependent_load_ns=round(1e6 * t_chase / steps, 1),
                # one 32x32x16 bf16 MFMA (32768 flop) occupies its SIMD's matrix pipe for 32 cycles
                mfma_clock_ghz=round(flops / (ms * 1e-3) / 32768.0 / (cus * 4) * 32 / 1e9, 3),
                copy_gbs=round(2.0 * nbytes / cms / 1e6, 1), copy_probe_ms=round(cms, 3), cus=cus,
@@ -228,7 +261,7 @@ def box_record(dev):
     rec["power_cap_w"] = round(int(cap) / 1e6, 1) if cap and cap.isdigit() else None
     pw = _sysfs_first([base + "hwmon/hwmon*/power1_average", base + "hwmon/hwmon*/power1_input"])
     rec["power_now_w"] = round(int(pw) / 1e6, 1) if pw and pw.isdigit() else None
-    del src, dst, out
+    del src, dst, out, chain, cout
     torch.cuda.empty_cache()
     return rec
 

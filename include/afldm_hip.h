@@ -367,6 +367,12 @@ int afldm_upfirdn2d_out_size(int in, int up, int down, int pad0, int pad1, int f
  * so that cross-box numbers can be normalised. */
 int afldm_probe_mfma(float* out, int workgroups, int iters, afldm_stream_t stream);
 int afldm_probe_copy(const void* src, void* dst, size_t bytes, afldm_stream_t stream);
+/* latency side of the fingerprint (round 4): afldm_probe_chase walks `steps` dependent loads through `buf` (uint32 indices
+ * forming one cycle, built by the host with a stride beyond a cache line; nontemporal loads) on one lane and writes
+ * out[0] = last index, out[1] = elapsed shader-clock ticks; afldm_probe_empty launches `workgroups` x 64 threads that do
+ * nothing (captured N times into a graph: the kernel-to-kernel boundary of this box). */
+int afldm_probe_chase(const void* buf, void* out, int steps, afldm_stream_t stream);
+int afldm_probe_empty(int workgroups, afldm_stream_t stream);
 
 #ifdef __cplusplus
 }
