@@ -333,9 +333,6 @@ def side_config(batch, dtype, steps=20, regions=3):
         ts.append(time.perf_counter() - t0)
     dt = median(ts)
     finite = bool(torch.isfinite(eng.lat).all().item())
-    # the process group as it actually ran (every rank takes part): world size, backend, each rank's device, and the
-    # sampler's one collective timed on its own + verified block by block
-    rccl = parallel.rccl_record(dev, local, payload=eng.lat) if world > 1 else None
     del eng, unet
     torch.cuda.empty_cache()
     return dict(batch=batch, dtype="bf16" if dtype == torch.bfloat16 else "fp32", steps=steps, regions=regions,
