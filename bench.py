@@ -210,8 +210,8 @@ def box_record(dev):
     cms = timed(lambda: _lib.check(lib.afldm_probe_copy(src.data_ptr(), dst.data_ptr(), nbytes, st), "probe_copy"), 5)
     # latency side (the throughput probes did not explain a 4 % spread between two boxes): (a) the boundary
     # between two dependent EMPTY kernels inside a captured graph (200 launches of 256 workgroups, replayed), (b) the
-    # boundary between two real streaming kernels (the 64 MiB copy probe, captured 20 times), (c) a dependent-load chain
-    # through 256 MiB with a 4 KiB + 128 B stride (every step misses the caches): ns per load
+    # same for a real streaming kernel (the copy probe on 64 MiB, captured 20 times: kernel + boundary), (c) a dependent-load
+    # chain of 4096 steps spread over 1 GiB (256 KiB + 128 B apart: beyond the L2s and the 256 MiB Infinity Cache): ns per load
     def graph_time(fn, n, reps=5):
         fn()
         torch.cuda.synchronize()
@@ -225,10 +225,9 @@ def box_record(dev):
     st2 = lambda: torch.cuda.current_stream().cuda_stream
     t_empty = graph_time(lambda: _lib.check(lib.afldm_probe_empty(cus, st2()), "probe_empty"), 200)
     small = 64 << 20
-    t_copy1 = timed(lambda: _lib.check(lib.afldm_probe_copy(src.data_ptr(), dst.data_ptr(), small, st), "probe_copy"), 5)
     t_copy20 = graph_time(lambda: _lib.check(lib.afldm_probe_copy(src.data_ptr(), dst.data_ptr(), small, st2()), "probe_copy"), 20)
-    nent = (256 << 20) // 4
-    stride = (4096 + 128) // 4
+    nent = (1 << 30) // 4
+    stride = ((256 << 10) + 128) // 4
     steps = 4096
     idx = (torch.arange(steps + 1, dtype=torch.int64) * stride) % nent
     chain = torch.zeros(nent, dtype=torch.int32)
@@ -240,7 +239,7 @@ def box_record(dev):
     t_chase = timed(lambda: _lib.check(lib.afldm_probe_chase(chain.data_ptr(), cout.data_ptr(), steps, st), "probe_chase"), 3)
     rec = dict(mfma_tflops=round(flops / ms / 1e9, 1), mfma_probe_ms=round(ms, 2),
                graph_empty_kernel_us=round(1e3 * t_empty / 200, 3),
-               graph_copy_boundary_us=round(1e3 * (t_copy20 / 20 - t_copy1), 3),
+               graph_copy_64mib_us=round(1e3 * t_copy20 / 20, 3),
                dependent_load_ns=round(1e6 * t_chase / steps, 1),
                # one 32x32x16 bf16 MFMA (32768 flop) occupies its SIMD's matrix pipe for 32 cycles
                mfma_clock_ghz=round(flops / (ms * 1e-3) / 32768.0 / (cus * 4) * 32 / 1e9, 3),

@@ -14,7 +14,7 @@ out, tag = sys.argv[1], sys.argv[2]
 
 
 def fam(n):
-    for k in ("k_conv3h", "k_igemm3", "k_igemm2", "k_igemm", "k_lin_wreg", "k_attn", "k_af_act_plane", "k_af_act_kron", "k_af_act_small",
+    for k in ("k_conv3h", "k_igemm3", "k_igemm2", "k_igemm", "k_lin_wreg", "k_attn_fused", "k_attn", "k_af_act_plane", "k_af_act_kron", "k_af_act_small",
               "k_resample_plane", "k_axis_contract", "k_splitk", "k_gn_apply", "k_gn_partial", "k_conv_cin4", "k_conv_small"):
         if k in n:
             return k
@@ -37,12 +37,21 @@ for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
             d["n"] += 1
 STEPS = float(nsteps)
 res = {}
+# Round 4 calibration (profiles/r04/fetch_calib.txt): FETCH_SIZE tallies 64 bytes per fabric read request WHATEVER its size - it is
+# exact for requests of <= 64 bytes (kernels that read 16 / 32 / 64-byte runs per row) and HALF the truth for 128-byte requests
+# (wide coalesced rows, LDS-DMA of 128-byte rows).  read_MB_low = FETCH_SIZE * 1024 (all requests <= 64 B), read_MB_high = 2 x
+# that (all requests 128 B); `read_MB_per_step` takes the one that matches how the family reads its operands.
+NARROW = ("k_af_act_plane", "k_af_act_kron", "k_af_act_small", "k_axis_contract", "k_resample_plane")      # channel pieces of <= 64 bytes per pixel
 for k, d in sorted(tot.items(), key=lambda kv: -(2 * kv[1]["fetch"] + kv[1]["write"])):
-    res[k] = dict(launches_per_step=round(d["n"] / STEPS, 1), read_MB_per_step=round(2 * d["fetch"] * 1024 / STEPS / 1e6, 1),
+    lo = d["fetch"] * 1024 / STEPS / 1e6
+    res[k] = dict(launches_per_step=round(d["n"] / STEPS, 1), read_MB_low=round(lo, 1), read_MB_high=round(2 * lo, 1),
+                  read_MB_per_step=round(lo if k in NARROW else 2 * lo, 1), reads="<= 64-byte runs" if k in NARROW else "128-byte requests",
                   write_MB_per_step=round(d["write"] * 1024 / STEPS / 1e6, 1))
 total = dict(read_MB_per_step=round(sum(v["read_MB_per_step"] for v in res.values()), 1),
              write_MB_per_step=round(sum(v["write_MB_per_step"] for v in res.values()), 1))
-doc = dict(tag=tag, note="HBM bytes per denoise step by kernel family: (2*FETCH_SIZE, WRITE_SIZE)*1024, separate --pmc passes, eager step",
+doc = dict(tag=tag, note="HBM bytes per denoise step by kernel family from FETCH_SIZE / WRITE_SIZE (separate --pmc passes, eager step); "
+                         "FETCH_SIZE counts 64 B per request: x1 for families reading <= 64-byte runs, x2 for 128-byte requests "
+                         "(profiles/r04/fetch_calib.txt)",
            total=total, families=res)
 print(json.dumps(doc, indent=1))
 open("gpurun_out/step_traffic_%s.json" % tag, "w").write(json.dumps(doc, indent=1) + "\n")
