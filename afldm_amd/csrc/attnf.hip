@@ -52,30 +52,34 @@ __device__ __forceinline__ f32x16 mfma32(const bf16x8& a, const bf16x8& b, const
 constexpr float ATT_TAU = 10.0f;   // lazy rescale threshold (log2 units)
 
 // D = head_dim (16 / 24), NW = waves, TPW = 32-token tiles per wave (T = 32 NW TPW), CK = C / 16 (K steps).
-template <int D, int NW, int TPW, int CK>
+// LEAN: weight rows unpadded with an XOR swizzle of the 16-byte piece index (instead of 16 bytes of padding per row) and the
+// GroupNorm vectors aliased onto the (not yet written) K region: the 16x16 level then needs <= 80 KiB and TWO four-wave
+// workgroups share a CU - one's prologue / fold runs under the other's projection / attention.
+template <int D, int NW, int TPW, int CK, bool LEAN = false>
 struct AttnFCfg {
   static constexpr int T = NW * TPW * 32, NT = T / 32, C = CK * 16;
   static constexpr int RK = D * 2;                      // K row bytes (real channels only)
   static constexpr int K_BYTES = T * RK;
   static constexpr int V_BYTES = NT * 2 * 2 * D * 16;   // [tile][j][hi][d] x 16 B
   static constexpr int CST_BYTES = 64;                  // [0,16) K pad chunk {1,0,..}; [16,32) ones; [32,48) zeros
-  static constexpr int RW = C * 2 + 16;                 // weight row stride (bank-conflict-free ds_read_b128)
+  static constexpr int RW = LEAN ? C * 2 : C * 2 + 16;  // weight row stride (bank-conflict-free ds_read_b128: padding, or the swizzle)
   static constexpr int W_BYTES = 3 * D * RW;
   static constexpr int AS_BYTES = C * 12;               // a[C], mu[C], beta[C] fp32 (GroupNorm folded into the weights)
   static constexpr int BIAS_BYTES = 3 * 32 * 4;         // folded q | k | v biases of this head, padded to 32, fp32
   static constexpr int KN_BYTES = 64;                   // per-wave max |k|^2 (fp32)
   static constexpr int OFF_K = 0, OFF_V = OFF_K + K_BYTES, OFF_CST = OFF_V + V_BYTES, OFF_W = OFF_CST + CST_BYTES,
-                       OFF_AS = OFF_W + W_BYTES, OFF_BIAS = OFF_AS + AS_BYTES, OFF_KN = OFF_BIAS + BIAS_BYTES,
-                       LDS_BYTES = OFF_KN + KN_BYTES;
+                       OFF_AS = LEAN ? OFF_K : OFF_W + W_BYTES, OFF_BIAS = OFF_W + W_BYTES + (LEAN ? 0 : AS_BYTES),
+                       OFF_KN = OFF_BIAS + BIAS_BYTES, LDS_BYTES = OFF_KN + KN_BYTES;
+  static_assert(!LEAN || (AS_BYTES <= K_BYTES + V_BYTES && (C * 2) % 256 == 0), "aliased GroupNorm vectors / swizzled rows");
   static constexpr int NU = TPW >= 2 ? 2 : 1;           // query tiles per attention pass
   static constexpr int PADC = D / 16, PADHI = (D % 16) / 8;   // where slot D sits: chunk, lane half (element 0)
 };
 
 // DBG (AFLDM_ATTNF_DBG, timing decomposition, garbage results): 1 no attention phase, 2 no exponentials, 4 no projection MFMAs,
 // 8 no token-tile reloads in the projection, 16 no W' fragment reads in the projection
-template <int D, int NW, int TPW, int CK, int DBG = 0>
-__global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
-  typedef AttnFCfg<D, NW, TPW, CK> CF;
+template <int D, int NW, int TPW, int CK, int DBG = 0, bool LEAN = false>
+__global__ void __launch_bounds__(NW * 64, LEAN ? 2 : 1) k_attn_fused(AttnFP p) {
+  typedef AttnFCfg<D, NW, TPW, CK, LEAN> CF;
   constexpr int T = CF::T, NT = CF::NT, C = CF::C, RK = CF::RK, RW = CF::RW, NU = CF::NU, NTHR = NW * 64;
   static_assert(D == 16 || D == 24, "head_dim 16 / 24");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -110,7 +114,7 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
   // trip instead of four dependent ones.
   // (a) GroupNorm partial sums: quarter-waves take one group each (cpg <= 16); consecutive lanes read consecutive
   //     channels of one split (one run), up to SV partials per lane in flight
-  constexpr int SV = 16;
+  constexpr int SV = LEAN ? 8 : 16;
   const int cpg = C / p.G, S = p.gs.S1, q4 = lane >> 4, ql = lane & 15, nst = cpg * S;
   const float* stb = p.gs.st1 + (size_t)b * S * C * 2;
   float* sMu = sA + C;
@@ -225,7 +229,7 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
         wf[e] = (bf16)(w * av);
         part += w * bv - (float)wf[e] * mv;
       }
-      st16<bf16x8>(sW + wrow * RW + pc * 16, wf);
+      st16<bf16x8>(sW + wrow * RW + ((LEAN ? pc ^ (wrow & 15) : pc) << 4), wf);
     }
 #pragma unroll
     for (int o = 1; o < LPR; o <<= 1) part += __shfl_xor(part, o, 64);       // (a row's LPR lanes are adjacent lanes of one wave)
@@ -242,9 +246,12 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
   // 16-byte piece of K's row.  Rows >= D read another row (their results are never used).
   const int sig = (ln & 0x13) | ((ln & 4) << 1) | ((ln & 8) >> 1);
   // (padding lanes read row - 16: finite data, and a row no other lane of their ds_read_b128 group maps onto)
-  const char* wq_base = sW + (0 * D + (sig < D ? sig : sig - 16)) * RW + hi * 16;       // + kk * 32
-  const char* wk_base = sW + (1 * D + (sig < D ? sig : sig - 16)) * RW + hi * 16;
-  const char* wv_base = sW + (2 * D + (ln < D ? ln : ln - 16)) * RW + hi * 16;
+  const int wq_row = 0 * D + (sig < D ? sig : sig - 16), wk_row = 1 * D + (sig < D ? sig : sig - 16), wv_row = 2 * D + (ln < D ? ln : ln - 16);
+  // fragment of K step kk = 16-byte piece 2 kk + half of the row (LEAN: at position piece ^ (row & 15))
+  auto wfrag = [&](int row, int kk) {
+    const int pc = 2 * kk + hi;
+    return ld16<bf16x8>(sW + row * RW + ((LEAN ? pc ^ (row & 15) : pc) << 4));
+  };
 
   bf16x8 qf[TPW][2];     // Q as B fragments (scaled by scale * log2 e), chunk c = channels 16c + 8 half + e
   float qn2[TPW];        // |q|^2 of this lane's query (of the bf16 values that enter the MFMA), per tile
@@ -261,15 +268,15 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
       av[r] = bv;
     }
     // (W' fragments one K step ahead of their MFMAs: two waves per SIMD do not cover an LDS round trip per step)
-    bf16x8 wq = ld16<bf16x8>(wq_base), wk = ld16<bf16x8>(wk_base), wv = ld16<bf16x8>(wv_base);
+    bf16x8 wq = wfrag(wq_row, 0), wk = wfrag(wk_row, 0), wv = wfrag(wv_row, 0);
 #pragma unroll
     for (int kk = 0; kk < CK; ++kk) {
       const bf16x8 xb = xr[kk % XPF];
       const bf16x8 wq_c = wq, wk_c = wk, wv_c = wv;
       if (kk + 1 < CK && !(DBG & 16)) {
-        wq = ld16<bf16x8>(wq_base + (kk + 1) * 32);
-        wk = ld16<bf16x8>(wk_base + (kk + 1) * 32);
-        wv = ld16<bf16x8>(wv_base + (kk + 1) * 32);
+        wq = wfrag(wq_row, kk + 1);
+        wk = wfrag(wk_row, kk + 1);
+        wv = wfrag(wv_row, kk + 1);
       }
       // the freed register takes K step kk + XPF: of this tile, or of the next one
       if (!(DBG & 8)) {
@@ -549,30 +556,30 @@ __global__ void __launch_bounds__(NW * 64) k_attn_fused(AttnFP p) {
   stamp(7);
 }
 
-template <int D, int NW, int TPW, int CK, int DBG = 0>
+template <int D, int NW, int TPW, int CK, int DBG = 0, bool LEAN = false>
 static int attnf_launch(const AttnFP& p, hipStream_t st) {
-  typedef AttnFCfg<D, NW, TPW, CK> CF;
+  typedef AttnFCfg<D, NW, TPW, CK, LEAN> CF;
   static bool once = false;
   if (!once) {
-    (void)hipFuncSetAttribute((const void*)k_attn_fused<D, NW, TPW, CK, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)k_attn_fused<D, NW, TPW, CK, DBG, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               CF::LDS_BYTES);
     once = true;
   }
-  k_attn_fused<D, NW, TPW, CK, DBG><<<p.B * p.heads, NW * 64, CF::LDS_BYTES, st>>>(p);
+  k_attn_fused<D, NW, TPW, CK, DBG, LEAN><<<p.B * p.heads, NW * 64, CF::LDS_BYTES, st>>>(p);
   return check_launch("afldm_attn_block_fused");
 }
 
-template <int D, int NW, int TPW, int CK>
+template <int D, int NW, int TPW, int CK, bool LEAN = false>
 static int attnf_launch_dbg(const AttnFP& p, hipStream_t st) {
   static const int dbg = getenv("AFLDM_ATTNF_DBG") ? atoi(getenv("AFLDM_ATTNF_DBG")) : 0;
   switch (dbg) {
-    case 1: return attnf_launch<D, NW, TPW, CK, 1>(p, st);
-    case 2: return attnf_launch<D, NW, TPW, CK, 2>(p, st);
-    case 4: return attnf_launch<D, NW, TPW, CK, 4>(p, st);
-    case 8: return attnf_launch<D, NW, TPW, CK, 8>(p, st);
-    case 16: return attnf_launch<D, NW, TPW, CK, 16>(p, st);
-    case 24: return attnf_launch<D, NW, TPW, CK, 24>(p, st);
-    default: return attnf_launch<D, NW, TPW, CK, 0>(p, st);
+    case 1: return attnf_launch<D, NW, TPW, CK, 1, LEAN>(p, st);
+    case 2: return attnf_launch<D, NW, TPW, CK, 2, LEAN>(p, st);
+    case 4: return attnf_launch<D, NW, TPW, CK, 4, LEAN>(p, st);
+    case 8: return attnf_launch<D, NW, TPW, CK, 8, LEAN>(p, st);
+    case 16: return attnf_launch<D, NW, TPW, CK, 16, LEAN>(p, st);
+    case 24: return attnf_launch<D, NW, TPW, CK, 24, LEAN>(p, st);
+    default: return attnf_launch<D, NW, TPW, CK, 0, LEAN>(p, st);
   }
 }
 
@@ -622,7 +629,12 @@ extern "C" int afldm_attn_block_fused(const void* x, const float* stats, int S, 
   }
   hipStream_t st = (hipStream_t)stream;
   if (d == 24 && T == 1024) return attnf_launch_dbg<24, 8, 4, 12>(p, st);
-  if (d == 24 && T == 256) return attnf_launch_dbg<24, 8, 1, 24>(p, st);
+  if (d == 24 && T == 256) {
+    // 16x16 level: two four-wave workgroups per CU (80 KiB each) unless AFLDM_ATTNF_L16=8 asks for the eight-wave form
+    static const int l16 = getenv("AFLDM_ATTNF_L16") ? atoi(getenv("AFLDM_ATTNF_L16")) : 4;
+    if (l16 == 8) return attnf_launch_dbg<24, 8, 1, 24>(p, st);
+    return attnf_launch_dbg<24, 4, 2, 24, true>(p, st);
+  }
   if (d == 16 && T == 256) return attnf_launch<16, 8, 1, 4>(p, st);
   if (d == 16 && T == 64) return attnf_launch<16, 2, 1, 8>(p, st);
   set_error("afldm_attn_block_fused: unreachable shape");
