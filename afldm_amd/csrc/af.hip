@@ -663,6 +663,124 @@ __global__ void __launch_bounds__(256) k_af_act_kron(AfP<T> p) {
   }
 }
 
+// ----------------------------------------------------------------------------- 8 x 8 planes, separable (round 4)
+// k_af_act_p8 (bf16): the Kronecker kernel above stages a 64 KB constant image per workgroup for 8 KB of planes and spends
+// two thirds of its wave-cycles parked (profiles/r03/pmc_sq_r03j.txt); here the four separable passes of the plane kernel
+// run on 16 x 16 x 32 MFMAs with TWO 8 x 8 planes sharing every tile, the upsampled 16 x 16 planes never leave the
+// registers, and the constants are five fragments (20 VGPRs) built from U / D at kernel start - no constant image, no
+// workgroup barrier, 4 KB of LDS per wave (input transpose + output staging).
+//   pass 1  T1^T[(p,w)][h'] = sum_h X_p[h][w] U[h'][h]                         A = X^T rows (LDS), B = U^T        (K = 8)
+//   pass 2  Z_p^T[w'][h']   = sum_w U[w'][w] T1^T[(p,w)][h']                   A = U (plane-selecting), B = pass 1's accumulator
+//           SiLU on the accumulator
+//   pass 3  V[h'][(p,w)]    = sum_w' S_p^T[w'][h'] D[w][w']                    A = pass 2's accumulators of BOTH planes, B = D (block diagonal)
+//   pass 4  Y[h][(p,w)]     = sum_h' D[h][h'] V[h'][(p,w)]                     A = D (two channel pairs stacked), B = pass 3's accumulators of two pairs
+// (an accumulator tile D[i][j] - lane = column j, registers = rows 4g + r - is a legal B operand of the next MFMA, contracting
+//  its ROW index, and read as an A operand it is its own transpose, again contracting the row index: passes 2 - 4 alternate
+//  the two so that w, then w', then h' are each the row index when their turn comes - no transpose through LDS.)
+__global__ void __launch_bounds__(256) k_af_act_p8(AfP<bf16> p) {
+  typedef bf16 T;
+  typedef Mma<T> MM;
+  __shared__ __attribute__((aligned(16))) char smem[4 * 4096];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  char* XT = smem + wave * 4096;                 // [16 c][8 w][8 h] bf16: 16 bytes per (c, w)
+  T* Ys = reinterpret_cast<T*>(XT + 2048);       // [64 px][16 c]
+  const int Ct = p.C1 + p.C2, ctiles = Ct / 16, nitems = p.B * ctiles;
+  const int cpg = p.gs.st1 ? Ct / p.G : 1;
+  const int item = blockIdx.x * 4 + wave;
+  const bool live = item < nitems;
+  const int b = live ? item / ctiles : 0, c0 = live ? (item - b * ctiles) * 16 : 0;
+  const bool second = c0 >= p.C1;
+  const T* xsrc = second ? p.x2 : p.x1;
+  const int Cs = second ? p.C2 : p.C1, cs0 = second ? c0 - p.C1 : c0;
+
+  // ---- input: lane (w = l & 7, channel octet cq = (l >> 3) & 1, row pair hh = l >> 4) reads rows 2 hh, 2 hh + 1
+  const int xw = lane & 7, xcq = (lane >> 3) & 1, xhh = lane >> 4;
+  bf16x8 xin[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+    xin[e] = ld16<bf16x8>(xsrc + ((size_t)b * 64 + (2 * xhh + e) * 8 + xw) * Cs + cs0 + xcq * 8);
+
+  // ---- constants (fragments of U [16][8] and D [8][16]; log2 e / ln 2 folded in as in the other MFMA kernels)
+  const float* __restrict__ U = p.U;
+  const float* __restrict__ D = p.D;
+  bf16x8 cB1, cA2[2], cB3, cA4;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    cB1[e] = (bf16)(lg == 0 ? U[li * 8 + e] : 0.f);                                              // B[k = h = e][j = h' = li]
+    const int w2 = 4 * (lg & 1) + (e & 3);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      cA2[t][e] = (bf16)((e < 4 && (lg >> 1) == t) ? U[li * 8 + w2] * 1.4426950408889634f : 0.f);   // A[i = w' = li][k = (p = g >> 1, w)]
+    const int wp = 4 * lg + (e & 3);                                                               // w' (pass 3) / h' (pass 4) of element e
+    cB3[e] = (bf16)(((e >> 2) == (li >> 3)) ? D[(li & 7) * 16 + wp] * 0.6931471805599453f : 0.f);  // B[k = (plane e >> 2, w')][j = (p_o, w_o) = li]
+    cA4[e] = (bf16)(((e >> 2) == (li >> 3)) ? D[(li & 7) * 16 + wp] : 0.f);                       // A[i = (pair, h) = li][k = (pair e >> 2, h')]
+  }
+
+  // ---- GroupNorm scale / shift of channel c0 + li (all lanes take part), then of this lane's channel octet
+  float sc = 1.f, sh = 0.f;
+  if (p.gs.st1) {
+    float mean, rstd;
+    gn_wave_keys(p.gs, true, b, (c0 + li) / cpg, cpg, 64.0 * cpg, p.eps, lane, mean, rstd);
+    sc = rstd * p.gamma[c0 + li];
+    sh = p.beta[c0 + li] - mean * sc;
+  }
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc) {
+    const float k = __shfl(sc, xcq * 8 + cc, 64), s0 = __shfl(sh, xcq * 8 + cc, 64);
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 v;
+    v[0] = (bf16)((float)xin[0][cc] * k + s0);
+    v[1] = (bf16)((float)xin[1][cc] * k + s0);
+    *reinterpret_cast<bf16x2*>(XT + (((xcq * 8 + cc) * 8 + xw) << 4) + xhh * 4) = v;
+  }
+  // (XT / Ys are private to the wave; LDS operations of one wave execute in order)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) {               // two channel pairs per round (pass 4 stacks them)
+    f32x4 v3[2];
+#pragma unroll
+    for (int hp = 0; hp < 2; ++hp) {
+      const int q = 2 * qq + hp;                  // channel pair: planes c0 + 2q, c0 + 2q + 1
+      // pass 1: rows (p, w) = li, K = h (lane group 0 only)
+      bf16x8 xa = ld16<bf16x8>(XT + (((2 * q + (li >> 3)) * 8 + (li & 7)) << 4));
+      if (lg != 0) xa = MM::zero();
+      f32x4 t1 = zero4;
+      MM::mma(t1, xa, cB1);
+      // pass 2 + SiLU: one tile per plane
+      const bf16x8 b2 = pack_chain<T>(t1, zero4);
+      f32x4 z0 = zero4, z1 = zero4;
+      MM::mma(z0, cA2[0], b2);
+      MM::mma(z1, cA2[1], b2);
+      z0 = silu_log2_x4(z0);
+      z1 = silu_log2_x4(z1);
+      // pass 3: both planes in one product (the accumulators as A: rows h')
+      const bf16x8 a3 = pack_chain<T>(z0, z1);
+      v3[hp] = zero4;
+      MM::mma(v3[hp], a3, cB3);
+    }
+    // pass 4: rows (pair, h), columns (p, w)
+    const bf16x8 b4 = pack_chain<T>(v3[0], v3[1]);
+    f32x4 y = zero4;
+    MM::mma(y, cA4, b4);
+    const int q = 2 * qq + (lg >> 1), c = 2 * q + (li >> 3), w = li & 7;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ys[((4 * (lg & 1) + r) * 8 + w) * 16 + c] = (bf16)y[r];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (live) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      st16<bf16x8>(p.y + ((size_t)b * 64 + lane) * Ct + c0 + e * 8, ld16<bf16x8>(Ys + lane * 16 + e * 8));
+  }
+}
+
 // ----------------------------------------------------------------------------- small planes
 template <typename T, int N>
 __global__ void __launch_bounds__(256) k_af_act_small(AfP<T> p) {
@@ -1204,6 +1322,12 @@ static int launch_af_kron(const AfP<T>& p, hipStream_t st) {
   return check_launch("afldm_af_act(kron)");
 }
 
+static int launch_af_p8(const AfP<bf16>& p, hipStream_t st) {
+  const int nitems = p.B * ((p.C1 + p.C2) / 16);
+  k_af_act_p8<<<(nitems + 3) / 4, 256, 0, st>>>(p);
+  return check_launch("afldm_af_act(p8)");
+}
+
 template <typename T, int N>
 static int launch_af_small(const AfP<T>& p, hipStream_t st) {
   const int total = p.B * (p.C1 + p.C2);
@@ -1232,6 +1356,11 @@ static int af_act_dispatch(const void* x1, int C1, const void* x2, int C2, const
       if (packed && p.C1 % 16 == 0 && p.C2 % 16 == 0 && !(s_small & 4)) return launch_af_kron<T, 4>(p, st);
       return launch_af_small<T, 4>(p, st);
     case 8:
+      if constexpr (sizeof(T) == 2) {
+        // bf16: the separable two-planes-per-tile kernel (no constant image); AFLDM_AF_P8=0 -> the Kronecker kernel (A/B)
+        static const bool p8 = !(getenv("AFLDM_AF_P8") && atoi(getenv("AFLDM_AF_P8")) == 0);
+        if (p8 && p.U && p.D && p.C1 % 16 == 0 && p.C2 % 16 == 0 && !(s_small & 8)) return launch_af_p8(p, st);
+      }
       if (packed && p.C1 % 16 == 0 && p.C2 % 16 == 0 && !(s_small & 8)) return launch_af_kron<T, 8>(p, st);
       return launch_af_small<T, 8>(p, st);
     case 16: return launch_af_mfma<T, 16>(p, st);
