@@ -86,6 +86,7 @@ def _load():
         "afldm_attention": ([vp, ip, vp, ip, vp, vp, ip, ip, ip, ip, ip, ip, ip, fp, ip, vp], c_int),
         "afldm_attn_block_fused_supported": ([ip, ip, ip, ip], c_int),
         "afldm_attn_block_fused_trace": ([vp], c_int),
+        "afldm_af_act_trace": ([vp], c_int),
         "afldm_attn_block_fused": ([vp, vp, ip, vp, vp, ip, fp, vp, vp, vp, ip, ip, ip, ip, fp, ip, vp], c_int),
         "afldm_ddim_step": ([vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, vp], c_int),
         "afldm_ddim_step_flat": ([vp, vp, vp, fp, fp, fp, fp, c_size_t, vp], c_int),

@@ -32,7 +32,9 @@ struct AfP {
   T* y;
   int C1, C2, G, B;
   float eps;
+  unsigned long long* trace;   // diagnostic (k_af_act_plane): [workgroup][wave][item 0 / 1][10] s_memtime stamps, or NULL
 };
+static unsigned long long* g_af_trace = nullptr;
 
 template <typename T>
 __device__ __forceinline__ typename Mma<T>::Chunk pack_chain(const f32x4& lo, const f32x4& hi);
@@ -220,7 +222,12 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
   const int ipw = (nitems + (int)gridDim.x - 1) / (int)gridDim.x;
   const int item_end = (wl + 1) * ipw < nitems ? (wl + 1) * ipw : nitems;
   int item = wl * ipw;
-  if (item < item_end) fetch(item);
+  const int item_first = item;
+  auto stamp = [&](int i) {
+    if (p.trace && lane == 0 && item - item_first < 2)
+      p.trace[(((size_t)blockIdx.x * CF::NW + wave) * 2 + (item - item_first)) * 10 + i] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
 
   // ---- GroupNorm scale / shift of an item's CH channels, buffered for two items (gscb / gshb[buf]).
   // One wave per group touched by the item's channels (usually 2-4): the cpg x S per-channel partial sums strided over
@@ -327,6 +334,87 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
     }
   };
 
+  // ---- the workgroup's FIRST TWO items at once, in front of everything else: they are consecutive channel tiles of one
+  // sample (2 CH channels, <= NW groups), so one wave per group folds the partial sums while gamma / beta - requested
+  // BEFORE the partial sums - and the first tile (requested right behind them) are in flight: one load round trip and one
+  // barrier for both items.  Item by item the chain (partial sums -> barrier -> gamma / beta -> barrier, ~2.5 us with
+  // every wave of the CU idle: the co-resident workgroups run in step) opened each of them.  Same terms in the same order
+  // as gn_group_sums_wave: bit-identical statistics.
+  int pre_done = 0;
+  if (item < item_end) {
+    const int b = item / ctiles, c0 = (item - b * ctiles) * CH;
+    int nit = 1;
+    if (item + 1 < item_end && (item + 1) / ctiles == b) nit = 2;
+    const int nch = nit * CH;
+    const int g_first = c0 / cpg, g_last = (c0 + nch - 1) / cpg;
+    const bool fast = p.gs.st1 != nullptr && g_last - g_first + 1 <= CF::NW && cpg * smax <= 64 * SPL;    // (workgroup-uniform)
+    if (p.gs.st1 == nullptr || fast) {
+      float gm = 1.f, bt = 0.f;
+      f32x2 sv[SPL];
+      const int g = g_first + wave;
+      if (fast) {
+        if (tid < nch) {
+          gm = p.gamma[c0 + tid];
+          bt = p.beta[c0 + tid];
+        }
+#pragma unroll
+        for (int u = 0; u < SPL; ++u) {
+          const int j = lane + 64 * u;
+          sv[u] = f32x2{0.f, 0.f};
+          if (g <= g_last && j < cpg * smax) {
+            const int c = g * cpg + j / smax, sp = j - (j / smax) * smax;
+            const bool second = c >= p.gs.C1;
+            const int S = second ? p.gs.S2 : p.gs.S1;
+            if (sp < S) {
+              const float* st = second ? p.gs.st2 : p.gs.st1;
+              const int Cs_ = second ? p.gs.C2 : p.gs.C1, cc = second ? c - p.gs.C1 : c;
+              sv[u] = *reinterpret_cast<const f32x2*>(st + (((size_t)b * S + sp) * Cs_ + cc) * 2);
+            }
+          }
+        }
+      }
+      fetch(item);
+      if (fast) {
+        if (g <= g_last) {
+          double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+          for (int u = 0; u < SPL; ++u) {
+            if (lane + 64 * u < cpg * smax) {
+              s1 += (double)sv[u][0];
+              s2 += (double)sv[u][1];
+            }
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
+          }
+          if (lane == 0) {
+            float mean, rstd;
+            gn_mean_rstd(s1, s2, (double)N * N * cpg, p.eps, mean, rstd);
+            gmsn[2 * (g - g_first)] = mean;
+            gmsn[2 * (g - g_first) + 1] = rstd;
+          }
+        }
+        __syncthreads();
+      }
+      if (tid < nch) {
+        const int k = tid / CH, t = tid - k * CH;
+        float sc = 1.f, sh = 0.f;
+        if (fast) {
+          const int gl = (c0 + tid) / cpg - g_first;
+          sc = gmsn[2 * gl + 1] * gm;
+          sh = bt - gmsn[2 * gl] * sc;
+        }
+        gscb[k * 16 + t] = sc;
+        gshb[k * 16 + t] = sh;
+      }
+      pre_done = nit;
+    } else {
+      fetch(item);
+    }
+  }
+
   bool have_stats = false;                                 // the pipelined path already published this item's scale / shift
   int ibuf = 0;
   for (; item < item_end; ++item, ibuf ^= 1) {
@@ -334,8 +422,10 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
     const int c0 = (item - b * ctiles) * CH;
     const float* gsc = gscb + ibuf * 16;
     const float* gsh = gshb + ibuf * 16;
-    if (!have_stats) stats_inline(item, ibuf);
+    stamp(1);
+    if (!have_stats && item - item_first >= pre_done) stats_inline(item, ibuf);
     __syncthreads();  // gsc/gsh ready; also: the previous item's output copy out of the X region is done
+    stamp(2);
     if constexpr (KH > N) {  // the output staging of the previous item overwrote the X region: re-zero its K padding
       for (int i = tid; i < N * CH * (KH - N); i += NT) {
         const int row = i / (KH - N), k = N + (i - row * (KH - N));
@@ -358,12 +448,16 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
         }
       }
     }
+    stamp(3);
     __syncthreads();
+    stamp(4);
     have_stats = false;
     n_piped = n_mine = false;
     if (item + 1 < item_end) {                 // in flight during the MFMA passes
       fetch(item + 1);
-      if constexpr (PIPE) stats_request(item + 1);
+      if constexpr (PIPE) {
+        if (item + 1 - item_first >= pre_done) stats_request(item + 1);
+      }
     }
 
     // ---- this wave's CPW channel planes, each carried through P1..P4 without a workgroup barrier
@@ -438,8 +532,10 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
           for (int kf = 0; kf < NKF3; ++kf) MM::mma(yacc[pl][t4][tw], cfrag(CF::F_DA + t4 * NKF3 + kf), vb[tw][kf]);
         }
     }
+    stamp(5);
     if constexpr (PIPE) stats_fold();
     __syncthreads();  // every wave has finished reading the X planes: the region becomes the output tile
+    stamp(6);
     if constexpr (PIPE) {
       stats_publish(ibuf ^ 1);
       have_stats = n_piped;
@@ -456,7 +552,9 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             Ys[(16 * t4 + 4 * lg + r) * YRP + (16 * tw + li) * CH + wave * CPW + pl] = from_f32<T>(yacc[pl][t4][tw][r]);
+    stamp(7);
     __syncthreads();
+    stamp(8);
     {
       constexpr int CPP = CH / EPC;  // 16-byte chunks per pixel
       for (int i = tid; i < N * N * CPP; i += NT) {
@@ -465,6 +563,7 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
         st16_out<Chunk>(p.y + ((size_t)b * N * N + pix) * Ct + c0 + q * EPC, ld16<Chunk>(Ys + h * YRP + w * CH + q * EPC));
       }
     }
+    stamp(9);
   }  // persistent item loop
 }
 
@@ -1345,6 +1444,7 @@ static int af_act_dispatch(const void* x1, int C1, const void* x2, int C2, const
   p.eps = eps;
   p.x1 = (const T*)x1; p.x2 = (const T*)x2; p.gs = gs; p.gamma = gamma; p.beta = beta;
   p.U = U; p.D = D; p.y = (T*)y; p.C1 = C1; p.C2 = C2; p.G = G; p.B = B;
+  p.trace = g_af_trace;
   // bit mask 4 / 8: plane sizes run on the VALU kernel instead of the Kronecker MFMA kernel.  N = 4 (default): one thread
   // per plane with the loop over the upsampled rows fully unrolled (all 64 coefficients in SGPRs) beats the MFMA form,
   // whose workgroups each stage a 64 KB constant image: 5.251 -> 5.229 ms/step (same box).  N = 8 needs 256 coefficients
@@ -1440,6 +1540,11 @@ extern "C" int afldm_af_act_slabs(const float* slabs, int nslab, const float* bi
   if (dtype == AFLDM_BF16) return af_act_slabs_launch<bf16>(slabs, nslab, bias, temb, temb_stride, residual, y_raw, gamma, beta, G, eps, act, U, D, y, B, C, N, st);
   set_error("afldm_af_act_slabs: unknown dtype %d", dtype);
   return AFLDM_EDTYPE;
+}
+
+extern "C" int afldm_af_act_trace(void* buf) {
+  g_af_trace = (unsigned long long*)buf;
+  return AFLDM_OK;
 }
 
 extern "C" int afldm_af_act(const void* x1, int C1, const void* x2, int C2, const float* stats1, int S1,

@@ -109,6 +109,10 @@ int afldm_gn_apply(const void* x1, int C1, const void* x2, int C2, const float* 
 int afldm_gn_fold(const float* stats_in, int S_in, float* stats_out, int S_out, int B, int C,
                   afldm_stream_t stream);
 
+/* diagnostic: device buffer [workgroups][4 waves][2 items][10] of 64-bit shader-clock stamps that later afldm_af_act
+ * launches on the plane kernel (N = 16 / 32) fill (phase boundaries of a workgroup's first two items; csrc/af.hip),
+ * NULL = off (the default). */
+int afldm_af_act_trace(void* buf);
 /* ---- alias-free operators -----------------------------------------------------------------
  * afldm_af_act: [GroupNorm-apply ->] WarpedNonlinearity(SiLU) (af_blocks.py:19-28):
  *   y = D silu(U xn U^T) D^T per (b, c) plane,  xn = GN-applied x when stats1 != NULL
