@@ -35,6 +35,8 @@ CASES = (  # B, H, Cout, variant, input channel counts
     (64, 8, 384, 51, (128, 256, 384, 512, 768)),
     (64, 4, 768, 52, (256, 512, 768, 1024, 1536)),
 )
+if os.environ.get("ONLY"):                        # e.g. ONLY=32,16
+    CASES = tuple(c for c in CASES if str(c[1]) in os.environ["ONLY"].split(","))
 for (B, H, Cout, v, cins) in CASES:
     pts = []
     for Cin in cins:
