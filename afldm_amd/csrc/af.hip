@@ -194,11 +194,18 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
     else return ld16<Chunk>(Cs + (f * 64 + lane) * EPC);
   };
 
-  // X tile staging units: unit u = (cq, w, hq) reads EPC pixels (h = hq*EPC + e) x EPC channels and
+  // X tile staging units: unit u = (cq, w, hq) reads PX pixels (h = hq*PX + e) x EPC channels and
   // writes them transposed (h contiguous).  UPT units per thread live in registers so that the NEXT
-  // item's tile is fetched from HBM while the current one is being computed.
-  constexpr int CQ = CH / EPC, HQ = N / EPC, UNITS = N * CQ * HQ, UPT = (UNITS + NT - 1) / NT;
-  Chunk pre[UPT][EPC];
+  // item's tile is fetched from HBM while the current one is being computed.  On 16^2 planes PX is chosen so that EVERY
+  // thread holds a unit: with 8-pixel units a 16^2 x 8-channel tile was 32 units - half a wave normalised and transposed
+  // the whole tile (2.3-2.6 k clocks per item with the other 3.5 waves waiting at the barrier): 19.6 -> 18.6 us per launch.
+  // (32^2 x 8 channels = 128 eight-pixel units: 4-pixel units for all 256 threads shorten the phase in clocks but the
+  //  launch takes 34.7 us instead of 31.7, same box - kept at 8; profiles/r04/af_plane_trace.txt)
+  constexpr int CQ = CH / EPC;
+  constexpr int PXW = N * N * CQ / NT, PX = PXW >= 4 ? EPC : (PXW >= 1 ? PXW : 1);
+  constexpr int HQ = N / PX, UNITS = N * CQ * HQ, UPT = (UNITS + NT - 1) / NT;
+  static_assert(N % PX == 0 && (PX & (PX - 1)) == 0, "staging unit");
+  Chunk pre[UPT][PX];
   auto fetch = [&](int item) {
     const int b = item / ctiles, c0 = (item - b * ctiles) * CH;
     const bool second = c0 >= p.C1;
@@ -210,8 +217,8 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
       if (u < UNITS) {
         const int cq = u % CQ, w = (u / CQ) % N, hq = u / (CQ * N);
 #pragma unroll
-        for (int e = 0; e < EPC; ++e)
-          pre[k][e] = ld16<Chunk>(xsrc + ((size_t)(b * N + hq * EPC + e) * N + w) * Cs_ + cs0 + cq * EPC);
+        for (int e = 0; e < PX; ++e)
+          pre[k][e] = ld16<Chunk>(xsrc + ((size_t)(b * N + hq * PX + e) * N + w) * Cs_ + cs0 + cq * EPC);
       }
     }
   };
@@ -441,10 +448,16 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
 #pragma unroll
         for (int cc = 0; cc < EPC; ++cc) {
           const float sc = gsc[cq * EPC + cc], sh = gsh[cq * EPC + cc];
-          Chunk o;
+          T* dst = Xs + ((size_t)((cq * EPC + cc) * N + w)) * KHP + hq * PX;
+          if constexpr (PX == 1) {
+            *dst = from_f32<T>(to_f32(pre[k][0][cc]) * sc + sh);
+          } else {
+            typedef __attribute__((ext_vector_type(PX))) T Run;       // PX consecutive h of one (channel, w): 4 - 16 bytes
+            Run o;
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) o[e] = from_f32<T>(to_f32(pre[k][e][cc]) * sc + sh);
-          st16<Chunk>(Xs + ((size_t)((cq * EPC + cc) * N + w)) * KHP + hq * EPC, o);
+            for (int e = 0; e < PX; ++e) o[e] = from_f32<T>(to_f32(pre[k][e][cc]) * sc + sh);
+            *reinterpret_cast<Run*>(dst) = o;
+          }
         }
       }
     }
