@@ -12,9 +12,14 @@ sys.path.insert(0, ROOT)
 def main():
     import torch
     from afldm_amd import ops
-    from bench_kernels import timeit
+    from bench_kernels import timeit, timeit_graph
+    if os.environ.get("GRAPH"):            # launches captured into a HIP graph (needed below ~25 us per launch)
+        timeit = lambda fn, iters=50: timeit_graph(fn)
     B = int(os.environ.get("B", "64"))
-    for T, C, heads in ((1024, 192, 8), (256, 384, 16)):
+    shapes = ((1024, 192, 8), (256, 384, 16))
+    if os.environ.get("SHAPES"):           # e.g. SHAPES=64x384x16
+        shapes = tuple(tuple(int(v) for v in sh.split("x")) for sh in os.environ["SHAPES"].split(","))
+    for T, C, heads in shapes:
         g = torch.Generator().manual_seed(1)
         x = torch.randn(B, T, C, generator=g).to(torch.bfloat16).cuda()
         side = int(T ** 0.5)

@@ -8,26 +8,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 import torch
 from afldm_amd import _lib, ops
+from bench_kernels import timeit_graph
 
-
-def timeit_graph(fn, reps=20, iters=10):
-    """us per call with `reps` calls captured into one HIP graph (the Python call overhead would hide a 20 us kernel)."""
-    fn(); torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    s = torch.cuda.Stream()
-    with torch.cuda.stream(s):
-        fn()
-        with torch.cuda.graph(g, stream=s):
-            for _ in range(reps):
-                fn()
-    g.replay(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        g.replay()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / (iters * reps) * 1e3
 
 CASES = (  # B, H, Cout, variant, input channel counts
     (64, 32, 192, 41, (64, 128, 192, 256, 384, 576)),

@@ -29,6 +29,27 @@ def timeit(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters * 1e3   # us
 
 
+def timeit_graph(fn, reps=20, iters=10):
+    """us per call with `reps` calls captured into one HIP graph: the Python call overhead (~20 us) hides anything shorter
+    when the calls are issued eagerly."""
+    fn(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        fn()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(reps):
+                fn()
+    g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (iters * reps) * 1e3
+
+
 # (name, B, H, W, C1, C2, Cout, KS)  at batch 64
 CONV_SHAPES = [
     ("L32 192->192 3x3", 64, 32, 32, 192, 0, 192, 3),
