@@ -702,10 +702,11 @@ __global__ void __launch_bounds__(256) k_af_act_kron(AfP<T> p) {
     // ---- GroupNorm scale/shift of channel c0 + li: lane group lg adds every 4th channel of its group
     float sc = 1.f, sh = 0.f;
     if (p.gs.st1) {   // (wave-uniform branch; idle waves of the last group take part with their clamped item)
+      const float gm = p.gamma[c0 + li], bt = p.beta[c0 + li];    // requested in front of the partial sums: one round trip, not two
       float mean, rstd;
       gn_wave_keys(p.gs, true, b, (c0 + li) / cpg, cpg, (double)P * cpg, p.eps, lane, mean, rstd);
-      sc = rstd * p.gamma[c0 + li];
-      sh = p.beta[c0 + li] - mean * sc;
+      sc = rstd * gm;
+      sh = bt - mean * sc;
     }
 
     // ---- X tile (already in registers) -> Xk[c][px] (pixels K-contiguous), GroupNorm applied; the scale / shift of a
@@ -832,10 +833,11 @@ __global__ void __launch_bounds__(256) k_af_act_p8(AfP<bf16> p) {
   // ---- GroupNorm scale / shift of channel c0 + li (all lanes take part), then of this lane's channel octet
   float sc = 1.f, sh = 0.f;
   if (p.gs.st1) {
+    const float gm = p.gamma[c0 + li], bt = p.beta[c0 + li];      // requested in front of the partial sums
     float mean, rstd;
     gn_wave_keys(p.gs, true, b, (c0 + li) / cpg, cpg, 64.0 * cpg, p.eps, lane, mean, rstd);
-    sc = rstd * p.gamma[c0 + li];
-    sh = p.beta[c0 + li] - mean * sc;
+    sc = rstd * gm;
+    sh = bt - mean * sc;
   }
 #pragma unroll
   for (int cc = 0; cc < 8; ++cc) {
@@ -909,13 +911,20 @@ __global__ void __launch_bounds__(256) k_af_act_small(AfP<T> p) {
     const T* xs = second ? p.x2 : p.x1;
     const int Cs = second ? p.C2 : p.C1;
     const int cc = second ? c - p.C1 : c;
+    // the plane itself is requested first (dead lanes re-read plane (0, 0)): its latency runs under the statistics chain
+    T xr[N][N];
+#pragma unroll
+    for (int h = 0; h < N; ++h)
+#pragma unroll
+      for (int w = 0; w < N; ++w) xr[h][w] = xs[((size_t)(b * N + h) * N + w) * Cs + cc];
     float sc = 1.f, sh = 0.f;
     if (p.gs.st1) {
       const int cpg = Ct / p.G;
+      const float gm = p.gamma[c], bt = p.beta[c];                // requested in front of the partial sums
       float mean, rstd;
       gn_wave_keys(p.gs, live, b, c / cpg, cpg, (double)N * N * cpg, p.eps, threadIdx.x & 63, mean, rstd);
-      sc = rstd * p.gamma[c];
-      sh = p.beta[c] - mean * sc;
+      sc = rstd * gm;
+      sh = bt - mean * sc;
     }
     if (!live) return;
     float X[N][N], Y[N][N];
@@ -923,7 +932,7 @@ __global__ void __launch_bounds__(256) k_af_act_small(AfP<T> p) {
     for (int h = 0; h < N; ++h)
 #pragma unroll
       for (int w = 0; w < N; ++w) {
-        X[h][w] = to_f32(xs[((size_t)(b * N + h) * N + w) * Cs + cc]) * sc + sh;
+        X[h][w] = to_f32(xr[h][w]) * sc + sh;
         Y[h][w] = 0.f;
       }
     // hp stays a run-time loop: X/Y are indexed statically (registers), the matrix rows with a
@@ -1000,6 +1009,7 @@ __global__ void __launch_bounds__(256) k_af_act_slabs(AfSlabP<T> p) {
   float X[N][N], Y[N][N];
   float add = p.bias ? p.bias[c] : 0.f;
   const float tv = p.temb ? to_f32(p.temb[(size_t)b * p.temb_stride + c]) : 0.f;
+  const float gm = p.gamma[c], bt = p.beta[c];             // (with the first batch of loads, not behind the two barriers)
   float s1 = 0.f, s2 = 0.f;
   {
     // slab order z = 0, 1, ... per pixel (the reduction kernel's order); the first four slabs as fully unrolled
@@ -1055,7 +1065,7 @@ __global__ void __launch_bounds__(256) k_af_act_slabs(AfSlabP<T> p) {
   __syncthreads();
   {
     const float mean = sM[tid / cpg][0], rstd = sM[tid / cpg][1];
-    const float sc = rstd * p.gamma[c], sh = p.beta[c] - mean * sc;
+    const float sc = rstd * gm, sh = bt - mean * sc;
 #pragma unroll
     for (int h = 0; h < N; ++h)
 #pragma unroll

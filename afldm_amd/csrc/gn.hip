@@ -82,6 +82,40 @@ __global__ void __launch_bounds__(256) k_gn_apply(const T* __restrict__ x1, int 
   const int r0 = (blockIdx.x % blocks_per_sample) * rows_per_block;
   float* sc = lds;
   float* sh = lds + C;
+  typedef typename Mma<T>::Chunk Chunk;
+  constexpr int EPC = Mma<T>::EPC;
+  const int r1 = r0 + rows_per_block < HW ? r0 + rows_per_block : HW;
+  // Everything that does not depend on the statistics is REQUESTED first - gamma / beta of the channels this thread
+  // will tabulate and the first four rows of its channel column - so that the kernel is one load round trip deep
+  // instead of three (partial sums -> gamma / beta -> data: ~1.5 us each on the launch-bound small levels).
+  constexpr int GPT = 4;                                    // table entries per thread kept in registers (C <= 1024)
+  const bool table_regs = C <= GPT * (int)blockDim.x;
+  float gmr[GPT], btr[GPT];
+  if (table_regs) {
+#pragma unroll
+    for (int k = 0; k < GPT; ++k) {
+      const int c = (int)threadIdx.x + k * (int)blockDim.x;
+      gmr[k] = c < C ? gamma[c] : 0.f;
+      btr[k] = c < C ? beta[c] : 0.f;
+    }
+  }
+  // Streaming form: a thread keeps ONE 16-byte channel column (its scale / shift live in registers)
+  // and walks down the rows with four independent loads in flight - no index division, no LDS
+  // reads in the loop (8-byte accesses run at 0.54-0.70x the 16-byte rate, MI355X_MICROARCH.md).
+  const bool streaming = C1 % EPC == 0 && C2 % EPC == 0 && C / EPC <= (int)blockDim.x;
+  const int nc = streaming ? C / EPC : 1, rl = (int)blockDim.x / nc;
+  const bool mine = streaming && (int)threadIdx.x < rl * nc;
+  const int col = (int)threadIdx.x % nc, lane_r = (int)threadIdx.x / nc, cc0 = EPC * col;
+  const bool second0 = cc0 >= C1;
+  const T* src = (second0 ? x2 : x1) + (size_t)b * HW * (second0 ? C2 : C1) + (second0 ? cc0 - C1 : cc0);
+  const size_t Cs0 = second0 ? C2 : C1;
+  int row = r0 + lane_r;
+  Chunk v0[4];
+  const bool have0 = mine && row + 3 * rl < r1;
+  if (have0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v0[u] = ld16<Chunk>(src + (size_t)(row + u * rl) * Cs0);
+  }
   // group statistics: 8 lanes per group (each adds every 8th channel of the group), G <= 32 per round
   for (int g0 = 0; g0 < G; g0 += 32) {
     const int g = g0 + (threadIdx.x >> 3), part = threadIdx.x & 7;
@@ -101,26 +135,30 @@ __global__ void __launch_bounds__(256) k_gn_apply(const T* __restrict__ x1, int 
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const float mean = sc[C + C + 2 * (c / cpg)], rstd = sc[C + C + 2 * (c / cpg) + 1];
-    const float k = rstd * gamma[c];
-    sc[c] = k;
-    sh[c] = beta[c] - mean * k;
+  if (table_regs) {
+#pragma unroll
+    for (int k = 0; k < GPT; ++k) {
+      const int c = (int)threadIdx.x + k * (int)blockDim.x;
+      if (c < C) {
+        const float mean = sc[C + C + 2 * (c / cpg)], rstd = sc[C + C + 2 * (c / cpg) + 1];
+        const float kk = rstd * gmr[k];
+        sc[c] = kk;
+        sh[c] = btr[k] - mean * kk;
+      }
+    }
+  } else {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      const float mean = sc[C + C + 2 * (c / cpg)], rstd = sc[C + C + 2 * (c / cpg) + 1];
+      const float k = rstd * gamma[c];
+      sc[c] = k;
+      sh[c] = beta[c] - mean * k;
+    }
   }
   __syncthreads();
-  const int r1 = r0 + rows_per_block < HW ? r0 + rows_per_block : HW;
-  typedef typename Mma<T>::Chunk Chunk;
-  constexpr int EPC = Mma<T>::EPC;
-  if (C1 % EPC == 0 && C2 % EPC == 0 && C / EPC <= (int)blockDim.x) {
-    // Streaming form: a thread keeps ONE 16-byte channel column (its scale / shift live in registers)
-    // and walks down the rows with four independent loads in flight - no index division, no LDS
-    // reads in the loop (8-byte accesses run at 0.54-0.70x the 16-byte rate, MI355X_MICROARCH.md).
-    const int nc = C / EPC, rl = (int)blockDim.x / nc;
-    if ((int)threadIdx.x < rl * nc) {
-      const int col = (int)threadIdx.x % nc, lane_r = (int)threadIdx.x / nc, c = EPC * col;
-      const bool second = c >= C1;
-      const T* src = (second ? x2 : x1) + (size_t)b * HW * (second ? C2 : C1) + (second ? c - C1 : c);
-      const size_t Cs = second ? C2 : C1;
+  if (streaming) {
+    if (mine) {
+      const int c = cc0;
+      const size_t Cs = Cs0;
       T* dst = y + (size_t)b * HW * C + c;
       float ks[EPC], hs[EPC];
 #pragma unroll
@@ -128,11 +166,7 @@ __global__ void __launch_bounds__(256) k_gn_apply(const T* __restrict__ x1, int 
         ks[e] = sc[c + e];
         hs[e] = sh[c + e];
       }
-      int row = r0 + lane_r;
-      for (; row + 3 * rl < r1; row += 4 * rl) {
-        Chunk v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = ld16<Chunk>(src + (size_t)(row + u * rl) * Cs);
+      auto emit = [&](const Chunk (&v)[4]) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           Chunk o;
@@ -144,6 +178,16 @@ __global__ void __launch_bounds__(256) k_gn_apply(const T* __restrict__ x1, int 
           }
           st16_out<Chunk>(dst + (size_t)(row + u * rl) * C, o);
         }
+      };
+      if (have0) {                                          // the batch requested in front of the statistics
+        emit(v0);
+        row += 4 * rl;
+      }
+      for (; row + 3 * rl < r1; row += 4 * rl) {
+        Chunk v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ld16<Chunk>(src + (size_t)(row + u * rl) * Cs);
+        emit(v);
       }
       for (; row < r1; row += rl) {
         const Chunk v = ld16<Chunk>(src + (size_t)row * Cs);

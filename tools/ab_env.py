@@ -3,7 +3,8 @@ import os, sys, json, subprocess
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 def run(env_extra, tag):
     env = dict(os.environ, **env_extra)
-    r = subprocess.run([sys.executable, "bench.py", "--steps", "40", "--warmup", "10", "--no-cpu-baseline", "--no-roofline", "--no-extras"],
+    extra = os.environ.get("AB_ARGS", "").split()          # e.g. AB_ARGS="--batch 8"
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "40", "--warmup", "10", "--no-cpu-baseline", "--no-roofline", "--no-extras"] + extra,
                        capture_output=True, text=True, env=env, cwd=root)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if not line:
