@@ -211,7 +211,8 @@ def box_record(dev):
     # latency side (the throughput probes did not explain a 4 % spread between two boxes): (a) the boundary
     # between two dependent EMPTY kernels inside a captured graph (200 launches of 256 workgroups, replayed), (b) the
     # same for a real streaming kernel (the copy probe on 64 MiB, captured 20 times: kernel + boundary), (c) a dependent-load
-    # chain of 4096 steps spread over 1 GiB (256 KiB + 128 B apart: beyond the L2s and the 256 MiB Infinity Cache): ns per load
+    # chain of 4096 steps spread over 1 GiB (256 KiB + 128 B apart), cold (one pass right after a 1 GiB copy has swept the
+    # L2s and the 256 MiB Infinity Cache) and cache-resident (repeated passes: its 4096 lines are 512 KiB): ns per load
     def graph_time(fn, n, reps=5):
         fn()
         torch.cuda.synchronize()
@@ -234,13 +235,26 @@ def box_record(dev):
     chain[idx[:-1]] = idx[1:].to(torch.int32)
     chain = chain.to(dev)
     cout = torch.zeros(4, dtype=torch.int32, device=dev)
-    _lib.check(lib.afldm_probe_chase(chain.data_ptr(), cout.data_ptr(), steps, st), "probe_chase")
-    torch.cuda.synchronize()
-    t_chase = timed(lambda: _lib.check(lib.afldm_probe_chase(chain.data_ptr(), cout.data_ptr(), steps, st), "probe_chase"), 3)
+    chase = lambda: _lib.check(lib.afldm_probe_chase(chain.data_ptr(), cout.data_ptr(), steps, st), "probe_chase")
+    t_chase_hot = timed(chase, 3)                  # the chain's 4 096 lines (512 KiB) are cache-resident after the first pass
+    # cold: ONE launch right after a 1 GiB stream copy has swept the L2s and the 256 MiB Infinity Cache (no warm-up pass)
+    t_chase = 1e30
+    for _ in range(2):
+        _lib.check(lib.afldm_probe_copy(src.data_ptr(), dst.data_ptr(), nbytes, st), "probe_copy")
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        chase()
+        e1.record()
+        torch.cuda.synchronize()
+        t_chase = min(t_chase, e0.elapsed_time(e1))
+    ticks = int(cout.cpu()[1].item()) & 0xFFFFFFFF       # s_memtime ticks of the last (cold) chase loop
     rec = dict(mfma_tflops=round(flops / ms / 1e9, 1), mfma_probe_ms=round(ms, 2),
                graph_empty_kernel_us=round(1e3 * t_empty / 200, 3),
                graph_copy_64mib_us=round(1e3 * t_copy20 / 20, 3),
-               dependent_load_ns=round(1e6 * t_chase / steps, 1),
+               dependent_load_ns=round(1e6 * t_chase / steps, 1),                  # beyond every cache (HBM)
+               dependent_load_cached_ns=round(1e6 * t_chase_hot / steps, 1),       # the same chain, cache-resident
+               memtime_ticks_per_us=round(ticks / (1e3 * t_chase), 1),             # s_memtime rate while one wave chases
                # one 32x32x16 bf16 MFMA (32768 flop) occupies its SIMD's matrix pipe for 32 cycles
                mfma_clock_ghz=round(flops / (ms * 1e-3) / 32768.0 / (cus * 4) * 32 / 1e9, 3),
                copy_gbs=round(2.0 * nbytes / cms / 1e6, 1), copy_probe_ms=round(cms, 3), cus=cus,
