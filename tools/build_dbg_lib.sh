@@ -11,7 +11,7 @@ for m in "$@"; do
   wt=""; case $f in conv|conv3h) wt="-DAFLDM_WT=1";; esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $wt -D$m -c afldm_amd/csrc/$f.hip -o /tmp/dbg_${f}_$m.o
   objs=""
-  for o in api misc gn af sep conv conv3h attn fir lin skinny convout; do
+  for o in $(ls $L/*.o | xargs -n1 basename | sed 's/\.o$//'); do
     if [ $o = $f ]; then objs="$objs /tmp/dbg_${f}_$m.o"; else objs="$objs $L/$o.o"; fi
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $L/libafldm_${f}_$m.so $objs
