@@ -93,6 +93,7 @@ def _load():
         "afldm_select_timestep": ([vp, vp, vp, ip, vp], c_int),
         "afldm_select_step_row": ([vp, vp, vp, ip, vp, vp, c_size_t, vp], c_int),
         "afldm_probe_mfma": ([vp, ip, ip, vp], c_int),
+        "afldm_probe_mfma_random": ([vp, ip, ip, vp], c_int),
         "afldm_probe_copy": ([vp, vp, c_size_t, vp], c_int),
         "afldm_probe_chase": ([vp, vp, ip, vp], c_int),
         "afldm_probe_empty": ([ip, vp], c_int),

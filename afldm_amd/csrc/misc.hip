@@ -351,6 +351,46 @@ __global__ __launch_bounds__(256) void k_probe_mfma(float* out, int iters) {
   if (s == -1.2345f) out[blockIdx.x * 256 + threadIdx.x] = s;      // never true: keeps the loop alive
 }
 
+// The same loop with operands of RANDOM bf16 bit patterns (sign and mantissa random, 0.5 <= |x| < 2) rotating through four
+// register sets: the matrix pipe's sustained rate depends on the data it multiplies (the chip holds 2.36 GHz on the
+// near-constant operands above and ~1.55 GHz on these: 1.6 against 2.4 PFLOP/s, tools/proto/mfma_power.hip) - this figure,
+// not the datasheet peak, is what a convolution on real activations can reach.
+__device__ __forceinline__ unsigned probe_hash(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ probe_bf16x8 probe_rnd8(unsigned seed) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  u32x4 v;
+  for (int i = 0; i < 4; ++i) {
+    const unsigned h = probe_hash(seed * 4 + i);
+    const unsigned lo = ((h & 0x8000u) | (0x3f00u + (h & 0xffu))) & 0xffffu;
+    const unsigned hi = (((h >> 16) & 0x8000u) | (0x3f00u + ((h >> 16) & 0xffu))) & 0xffffu;
+    v[i] = lo | (hi << 16);
+  }
+  return __builtin_bit_cast(probe_bf16x8, v);
+}
+__global__ __launch_bounds__(256) void k_probe_mfma_random(float* out, int iters) {
+  probe_bf16x8 a[4], b[4];
+  for (int s = 0; s < 4; ++s) {
+    a[s] = probe_rnd8(threadIdx.x * 8 + s + blockIdx.x * 4096);
+    b[s] = probe_rnd8(threadIdx.x * 8 + s + 4 + blockIdx.x * 4096);
+  }
+  probe_f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  for (int it = 0; it < iters; it += 4) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[s], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(s + 1) & 3], b[s], c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(s + 2) & 3], b[(s + 1) & 3], c2, 0, 0, 0);
+      c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(s + 3) & 3], b[(s + 2) & 3], c3, 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
+  if (s == -1.2345f) out[blockIdx.x * 256 + threadIdx.x] = s;      // never true: keeps the loop alive
+}
+
 __global__ __launch_bounds__(256) void k_probe_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
@@ -359,6 +399,13 @@ extern "C" int afldm_probe_mfma(float* out, int workgroups, int iters, afldm_str
   AFLDM_REQUIRE(out && workgroups > 0 && iters > 0, AFLDM_ESHAPE, "afldm_probe_mfma: out[workgroups * 256], workgroups, iters > 0");
   k_probe_mfma<<<workgroups, 256, 0, (hipStream_t)stream>>>(out, iters);
   return check_launch("afldm_probe_mfma");
+}
+
+extern "C" int afldm_probe_mfma_random(float* out, int workgroups, int iters, afldm_stream_t stream) {
+  AFLDM_REQUIRE(out && workgroups > 0 && iters > 0 && iters % 4 == 0, AFLDM_ESHAPE,
+                "afldm_probe_mfma_random: out[workgroups * 256], workgroups > 0, iters > 0 and a multiple of 4");
+  k_probe_mfma_random<<<workgroups, 256, 0, (hipStream_t)stream>>>(out, iters);
+  return check_launch("afldm_probe_mfma_random");
 }
 
 // dependent-load chain (one lane): next = buf[next]; `buf` holds ONE cycle over its n entries (host-built), the stride

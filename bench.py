@@ -204,6 +204,9 @@ def box_record(dev):
     iters = 240000
     ms = timed(lambda: _lib.check(lib.afldm_probe_mfma(out.data_ptr(), wgs, iters, st), "probe_mfma"), 3)
     flops = wgs * 4.0 * iters * 4 * 32 * 32 * 16 * 2
+    # the same loop on random bf16 operands: the chip's sustained MFMA rate depends on the data (power), this is the
+    # ceiling a convolution on real activations sees
+    ms_rnd = timed(lambda: _lib.check(lib.afldm_probe_mfma_random(out.data_ptr(), wgs, iters, st), "probe_mfma_random"), 3)
     nbytes = 1 << 30
     src = torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 255)
     dst = torch.empty_like(src)
@@ -250,6 +253,7 @@ def box_record(dev):
         t_chase = min(t_chase, e0.elapsed_time(e1))
     ticks = int(cout.cpu()[1].item()) & 0xFFFFFFFF       # s_memtime ticks of the last (cold) chase loop
     rec = dict(mfma_tflops=round(flops / ms / 1e9, 1), mfma_probe_ms=round(ms, 2),
+               mfma_tflops_random_operands=round(flops / ms_rnd / 1e9, 1),
                graph_empty_kernel_us=round(1e3 * t_empty / 200, 3),
                graph_copy_64mib_us=round(1e3 * t_copy20 / 20, 3),
                dependent_load_ns=round(1e6 * t_chase / steps, 1),                  # beyond every cache (HBM)
@@ -519,6 +523,12 @@ def main():
             out["step_dense"] = {"tflop_per_step": round(rate * dt / args.steps, 4), "tflops": round(rate, 1), "peak": peak,
                                  "frac": round(rate / peak, 4), "af_filter_tflop_per_step": roof.pop("step_af_filter_tflop"),
                                  "note": "algorithmic flops of the step's convolutions + linear layers + attention over the timed step"}
+            if roof.get("bound") == "mfma" and dtype == torch.bfloat16 and out["box"].get("mfma_tflops_random_operands"):
+                # next to the datasheet peak: the MFMA rate THIS box sustains on random bf16 operands (the chip clocks down
+                # under data that toggles the multipliers; box.mfma_tflops is the same loop on near-constant operands)
+                rp = out["box"]["mfma_tflops_random_operands"]
+                roof["peak_random_operands"] = rp
+                roof["frac_of_random_operand_peak"] = round(roof["achieved"] / rp, 4)
             out["roofline"] = roof
             out["kernel_families"] = fam
         del eng

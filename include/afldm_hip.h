@@ -370,6 +370,10 @@ int afldm_upfirdn2d_out_size(int in, int up, int down, int pad0, int pad1, int f
  * Neither replaces a reference computation: they fingerprint the box (MFMA clock under load, HBM copy rate)
  * so that cross-box numbers can be normalised. */
 int afldm_probe_mfma(float* out, int workgroups, int iters, afldm_stream_t stream);
+/* the same loop on operands of random bf16 bit patterns rotating through four register sets (iters % 4 == 0): the
+ * sustained MFMA rate of the chip is data-dependent (power): ~1.6 PFLOP/s here against ~2.4 on the near-constant
+ * operands of afldm_probe_mfma. */
+int afldm_probe_mfma_random(float* out, int workgroups, int iters, afldm_stream_t stream);
 int afldm_probe_copy(const void* src, void* dst, size_t bytes, afldm_stream_t stream);
 /* latency side of the fingerprint (round 4): afldm_probe_chase walks `steps` dependent loads through `buf` (uint32 indices
  * forming one cycle, built by the host with a stride beyond a cache line; nontemporal loads) on one lane and writes
