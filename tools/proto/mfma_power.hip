@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_mfma(float* out, unsigned long long* ti
       b[s] = rnd8(threadIdx.x * 8 + s + 4 + blockIdx.x * 4096);
     }
   }
-  if (MODE == 2) {
+  if (MODE >= 2) {
     for (int i = threadIdx.x; i < 1024; i += 256) reinterpret_cast<u32x4*>(lds)[i] = __builtin_bit_cast(u32x4, rnd8(i + 77));
     __syncthreads();
   }
@@ -47,6 +47,15 @@ __global__ __launch_bounds__(256) void k_mfma(float* out, unsigned long long* ti
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
+      if (MODE >= 3) {
+        // MODE - 2 fragment reads per 4 MFMAs, data discarded (operands stay the random register sets): the halo kernel
+        // reads 20 fragments per 48 16x16x32 MFMAs = 3.3 per four 32x32x16 MFMAs' worth of flops
+#pragma unroll
+        for (int r = 0; r < MODE - 2; ++r) {
+          const bf16x8 v = *reinterpret_cast<const bf16x8*>(lds + ((threadIdx.x * 16 + ((it * 4 + s) * 4 + r) * 1024) & 16383));
+          asm volatile("" ::"v"(v));
+        }
+      }
       if (MODE == 2) {
         // one fragment read per MFMA (conflict-free: lane * 16 bytes), folded into the operands so that it stays live
         const bf16x8 r = *reinterpret_cast<const bf16x8*>(lds + ((threadIdx.x * 16 + (it * 4 + s) * 1024) & 16383));
@@ -68,6 +77,10 @@ __global__ __launch_bounds__(256) void k_mfma(float* out, unsigned long long* ti
 extern "C" int mp_run(float* out, unsigned long long* ticks, int mode, int wgs, int iters, hipStream_t st) {
   if (mode == 0) k_mfma<0><<<wgs, 256, 0, st>>>(out, ticks, iters);
   else if (mode == 1) k_mfma<1><<<wgs, 256, 0, st>>>(out, ticks, iters);
-  else k_mfma<2><<<wgs, 256, 0, st>>>(out, ticks, iters);
+  else if (mode == 2) k_mfma<2><<<wgs, 256, 0, st>>>(out, ticks, iters);
+  else if (mode == 3) k_mfma<3><<<wgs, 256, 0, st>>>(out, ticks, iters);
+  else if (mode == 4) k_mfma<4><<<wgs, 256, 0, st>>>(out, ticks, iters);
+  else if (mode == 6) k_mfma<6><<<wgs, 256, 0, st>>>(out, ticks, iters);
+  else k_mfma<5><<<wgs, 256, 0, st>>>(out, ticks, iters);
   return (int)hipGetLastError();
 }

@@ -12,9 +12,11 @@ wgs, iters = cus * 4, 30000
 out = torch.zeros(wgs * 256, dtype=torch.float32, device="cuda")
 ticks = torch.zeros(2, dtype=torch.int64, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
-names = {0: "constant low-entropy operands", 1: "random bf16 operands, 4 rotating sets", 2: "random operands + one ds_read_b128 per 4 MFMAs"}
+names = {0: "constant low-entropy operands", 1: "random bf16 operands, 4 rotating sets", 2: "operands replaced by one ds_read_b128 per 4 MFMAs",
+         3: "random operands + 1 discarded ds_read_b128 per 4 MFMAs", 4: "random operands + 2 reads per 4 MFMAs",
+         5: "random operands + 3 reads per 4 MFMAs", 6: "random operands + 4 reads per 4 MFMAs"}
 for rep in range(2):
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 3, 4, 5, 6):
         for _ in range(2):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
