@@ -299,6 +299,47 @@ def test_attn_block_fused_vs_three_launch_path_and_reference(T, C, heads, B, hot
         assert torch.equal(slow, got)
 
 
+@pytest.mark.parametrize("T,C,heads", [(1024, 192, 8), (256, 384, 16)])
+def test_attn_block_fused_full_size_properties(T, C, heads):
+    """BASELINE configs[1] size (batch 64, the FFHQ UNet's 32^2 / 16^2 attention levels), where the fp32 restatement takes
+    too long: size-independent properties of GroupNorm -> q | k | v -> softmax attention.  (a) batch invariance: a sample
+    computed inside the batch of 64 is bit-identical to the same sample launched on its own (a workgroup is one (sample,
+    head) and nothing else enters it); (b) token-permutation equivariance: GroupNorm statistics, projections and the
+    softmax sums are invariant under a permutation P of the tokens, so out(P x) = P out(x) up to the order of the fp32
+    accumulation over keys and the bf16 rounding of the softmax weights; (c) the output rows are convex combinations of the
+    value rows: every output channel lies inside the [min, max] of that channel of v over the sample (v from the
+    three-launch path's projection); (d) finite everywhere."""
+    from afldm_amd import ops
+    B, G, eps = 64, 32, 1e-5
+    gen = torch.Generator().manual_seed(C + 7)
+    x = (torch.randn(B, T, C, generator=gen) * (0.7 + torch.rand(1, 1, C, generator=gen)) + 0.3 * torch.randn(1, 1, C, generator=gen))
+    xg = x.to(torch.bfloat16).cuda()
+    gamma, beta = (0.5 + torch.rand(C, generator=gen)).cuda(), (0.3 * torch.randn(C, generator=gen)).cuda()
+    w = torch.randn(3 * C, C, generator=gen) / C ** 0.5
+    wpack = ops.pack_weight(w.cuda(), torch.bfloat16)
+    bpack = (0.2 * torch.randn(3 * C, generator=gen)).cuda()
+    side = int(T ** 0.5)
+    scale = (C // heads) ** -0.5
+    run = lambda xx: ops.attn_block_fused(xx, ops.gn_stats(xx.view(xx.shape[0], side, side, C), G), gamma, beta, G, eps, wpack, bpack,
+                                          heads, scale)
+    out = run(xg)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out.float()).all())
+    for b in (0, 17, 63):                                                            # (a)
+        assert torch.equal(run(xg[b:b + 1].contiguous())[0], out[b])
+    perm = torch.randperm(T, generator=gen).cuda()                                   # (b)
+    outp = run(xg[:, perm].contiguous())
+    r = rel_rms(outp.float(), out[:, perm].float().cpu())
+    print(f"[attn fused full size] T={T} C={C}: token permutation rel-RMS {r:.3e}")
+    assert r <= 4e-3
+    hn = ops.gn_apply(xg.view(B, side, side, C), ops.gn_stats(xg.view(B, side, side, C), G), gamma, beta, G, eps, act=0).view(B, T, C)
+    _, vt = ops.linear_split(hn, wpack, bpack, 2 * C)                                # (c) v^T [B, C, T]
+    vmin, vmax = vt.float().amin(2), vt.float().amax(2)                              # [B, C]
+    o = out.float()
+    slack = 2e-2 * (vmax - vmin).unsqueeze(1) + 1e-3                                 # bf16 rounding of the weights and of v itself
+    assert bool((o <= vmax.unsqueeze(1) + slack).all()) and bool((o >= vmin.unsqueeze(1) - slack).all())
+
+
 def test_attn_block_fused_rejects_what_it_has_no_kernel_for():
     from afldm_amd import _lib, ops
     x = torch.zeros(2, 64, 384, dtype=torch.bfloat16, device="cuda")
