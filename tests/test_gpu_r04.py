@@ -427,3 +427,48 @@ def test_conv3x3_halo_patch_persistent_tiles_bit_identical(case):
         if use_res:
             ref = ref + res[i:i + 1].float().permute(0, 3, 1, 2).cpu()
         assert rel_rms(outs[vid][i:i + 1].float().permute(0, 3, 1, 2), ref) <= 6e-3
+
+
+def test_af_act_trace_fills_stamps_and_leaves_the_result_alone():
+    """afldm_af_act_trace: a diagnostic - with a stamp buffer armed the plane kernel writes monotonically increasing
+    shader-clock stamps for each workgroup's first items and produces the very same output."""
+    from afldm_amd import _lib, ops
+    B, N, C, G = 8, 16, 64, 32
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.randn(B, N, N, C, generator=gen) * 1.3 + 0.2).to(torch.bfloat16).cuda()
+    st = ops.gn_stats(x, G)
+    gamma, beta = (0.5 + torch.rand(C, generator=gen)).cuda(), torch.randn(C, generator=gen).cuda()
+    ref = ops.af_act(x, None, st, gamma, beta, G, 1e-5)
+    tr = torch.zeros(1024 * 4 * 2 * 10, dtype=torch.int64, device="cuda")
+    _lib.check(_lib.lib.afldm_af_act_trace(tr.data_ptr()), "af_act_trace")
+    try:
+        got = ops.af_act(x, None, st, gamma, beta, G, 1e-5)
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(_lib.lib.afldm_af_act_trace(None), "af_act_trace")
+    assert torch.equal(got, ref)
+    a = tr.cpu().view(1024, 4, 2, 10)
+    used = a[:, 0, 0, 0] != 0
+    assert int(used.sum()) >= 1
+    first = a[used][:, :, 0, :]                                   # [workgroup, wave, stamp] of the first item
+    assert bool((first[:, :, 1:] >= first[:, :, :-1]).all()) and bool((first[:, :, 9] > first[:, :, 0]).all())
+    # switched off again: the buffer stays untouched
+    tr.zero_()
+    ops.af_act(x, None, st, gamma, beta, G, 1e-5)
+    torch.cuda.synchronize()
+    assert int(tr.abs().sum()) == 0
+
+
+def test_box_probes_run_and_check_their_arguments():
+    """The measurement-only entry points bench.py's `box` record uses: both MFMA probes run; the random-operand probe
+    refuses an iteration count that is not a multiple of its four rotating operand sets."""
+    from afldm_amd import _lib
+    lib = _lib.lib
+    st = torch.cuda.current_stream().cuda_stream
+    out = torch.zeros(64 * 256, dtype=torch.float32, device="cuda")
+    assert lib.afldm_probe_mfma(out.data_ptr(), 64, 400, st) == 0
+    assert lib.afldm_probe_mfma_random(out.data_ptr(), 64, 400, st) == 0
+    torch.cuda.synchronize()
+    assert lib.afldm_probe_mfma_random(out.data_ptr(), 64, 401, st) != 0
+    assert b"multiple of 4" in lib.afldm_last_error()
+    assert lib.afldm_probe_mfma_random(None, 64, 400, st) != 0
