@@ -16,9 +16,13 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("AFLDM_SAME_GPU") == "1":
+        # test rig only: every rank of a single-GPU box drives device 0 (exercises the N > 1 code path - per-rank capture,
+        # barriers, the gather - where only one GPU exists; RCCL refuses two ranks on one device, so the backend is gloo)
+        local = 0
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"     # "nccl" is RCCL on ROCm
+            backend = os.environ.get("AFLDM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")     # "nccl" is RCCL on ROCm
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
@@ -41,6 +45,17 @@ def global_noise(total, shape, seed):
     return torch.randn((total,) + tuple(shape), generator=g)
 
 
+def all_gather_into(out, local):
+    """dist.all_gather_into_tensor(out, local); under the gloo backend (test rigs: CPU ranks, or several ranks on one GPU)
+    device tensors are staged through host memory, which gloo's all-gather needs."""
+    if dist.get_backend() == "gloo" and local.is_cuda:
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, local.cpu().contiguous())
+        out.copy_(host)
+        return
+    dist.all_gather_into_tensor(out, local)
+
+
 def gather_rows(local, total, rank, world):
     """All-gather variable-size row shards back into the global [total, ...] tensor on every rank."""
     if world == 1:
@@ -48,13 +63,13 @@ def gather_rows(local, total, rank, world):
     sizes = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
     if len(set(sizes)) == 1:
         out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous())
+        all_gather_into(out, local.contiguous())
         return out
     pad = max(sizes)
     buf = torch.zeros((pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     buf[: local.shape[0]] = local
     out = torch.empty((world * pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, buf)
+    all_gather_into(out, buf)
     return torch.cat([out[r * pad: r * pad + sizes[r]] for r in range(world)], 0)
 
 
@@ -103,20 +118,23 @@ def rccl_record(device, local_rank, payload=None):
            "distinct_devices": len({(r["local_rank"], r["uuid"]) for r in ranks})}
     if payload is not None:
         out = torch.empty((world * payload.shape[0],) + tuple(payload.shape[1:]), dtype=payload.dtype, device=payload.device)
-        dist.all_gather_into_tensor(out, payload)
+        all_gather_into(out, payload)
         sync = torch.cuda.synchronize if on_gpu else (lambda: None)
         sync()
         dist.barrier()
         reps = 20
         t0 = time.perf_counter()
         for _ in range(reps):
-            dist.all_gather_into_tensor(out, payload)
+            all_gather_into(out, payload)
         sync()
         dt = (time.perf_counter() - t0) / reps
         # every rank's block must be that rank's payload: compare block checksums with the owners' own
         mine = payload.double().sum().reshape(1)
-        sums = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(sums, mine)
+        gl = dist.get_backend() == "gloo" and mine.is_cuda
+        mine_x = mine.cpu() if gl else mine
+        sums = [torch.empty_like(mine_x) for _ in range(world)]
+        dist.all_gather(sums, mine_x)
+        sums = [t.to(mine.device) for t in sums]
         n = payload.shape[0]
         ok = all(bool(torch.equal(out[r * n:(r + 1) * n].double().sum().reshape(1), sums[r])) for r in range(world))
         rec.update(all_gather_us=round(1e6 * dt, 1), all_gather_bytes=out.numel() * out.element_size(),

@@ -357,6 +357,49 @@ def side_config(batch, dtype, steps=20, regions=3):
                 latents_finite=finite)
 
 
+def concurrent_engines(n=2, batch=64, dtype=torch.bfloat16, steps=20, regions=3):
+    """NOT the bench configuration (one batch of 64 per GPU) - a throughput-serving data point: `n` independent batch-64
+    jobs in flight on one GPU, each a DenoiseEngine replaying its own captured graph on its own stream.  The kernels of
+    one job run under the launch ramps / write tails / cold first tiles of the other's (profiles/r04/two_streams_ab.txt)."""
+    from afldm_amd.engine import DenoiseEngine
+    from afldm_amd.schedulers.ddim import ffhq_ddim_scheduler
+    unet = build_unet(dtype, torch.device("cuda", torch.cuda.current_device()))
+    gen = torch.Generator().manual_seed(1234)
+    noise = [torch.randn(batch, 4, 32, 32, generator=gen) for _ in range(n)]
+    streams = [torch.cuda.Stream() for _ in range(n)]
+    engs = []
+    for i, s in enumerate(streams):
+        with torch.cuda.stream(s):
+            e = DenoiseEngine(unet, ffhq_ddim_scheduler(), batch, 50, use_graph=True)
+            e.reset(noise[i])
+            e.step(6)
+            engs.append(e)
+    torch.cuda.synchronize()
+    spg = engs[0].steps_per_graph
+    steps -= steps % spg
+    ts = []
+    for _ in range(regions):
+        for i, s in enumerate(streams):
+            with torch.cuda.stream(s):
+                engs[i].reset(noise[i])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps // spg):                       # the host alternates between the jobs' queues
+            for i, s in enumerate(streams):
+                with torch.cuda.stream(s):
+                    engs[i].step(spg)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    dt = median(ts)
+    finite = all(bool(torch.isfinite(e.lat).all().item()) for e in engs)
+    del engs, unet
+    torch.cuda.empty_cache()
+    return dict(config=f"{n} independent batch-{batch} jobs in flight on one GPU ({n} streams) - not the bench configuration",
+                jobs=n, batch_per_job=batch, dtype="bf16" if dtype == torch.bfloat16 else "fp32", steps=steps, regions=regions,
+                ms_per_step_all_jobs=round(1e3 * dt / steps, 4), ms_per_64_samples=round(1e3 * dt / steps * 64 / (n * batch), 4),
+                value=round(n * batch * steps / dt, 2), unit="denoise-steps/s", latents_finite=finite)
+
+
 def build_vae(dtype, device):
     """The reference's AF-VAE (configs/vae/model_afvae.json: [128, 256, 512, 512], 2 layers per block, 83.65 M
     parameters) with seeded PyTorch default-init weights."""
@@ -473,13 +516,13 @@ def main():
             done += n
             pos[0] = (pos[0] + n) % 50
         if world > 1 and gather:
-            torch.distributed.all_gather_into_tensor(final, eng.lat)        # the ONE collective of the sampler
+            parallel.all_gather_into(final, eng.lat)        # the ONE collective of the sampler (RCCL all_gather_into_tensor)
 
     run_steps(args.warmup if args.warmup > 0 else 1, gather=False)       # includes graph capture
     if world > 1:
         # RCCL builds its communicator rings / channels lazily on the first collective of a kind:
         # that one-off set-up belongs to the warm-up, not to the timed steps
-        torch.distributed.all_gather_into_tensor(final, eng.lat)
+        parallel.all_gather_into(final, eng.lat)
     pos[0] = 0
     regions = timed_regions(run_steps, args.steps, max(1, args.regions), world, dev)
     dt = median(regions)
@@ -538,6 +581,7 @@ def main():
             torch.cuda.empty_cache()
             out["other_configs"] = [side_config(1, torch.bfloat16), side_config(8, torch.bfloat16),
                                     side_config(64, torch.float32, steps=10), side_config(1, torch.float32)]
+            out["concurrent_jobs"] = [concurrent_engines(2), concurrent_engines(3)]
             out["vae_c4"] = vae_workload()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

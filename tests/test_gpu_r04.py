@@ -472,3 +472,29 @@ def test_box_probes_run_and_check_their_arguments():
     assert lib.afldm_probe_mfma_random(out.data_ptr(), 64, 401, st) != 0
     assert b"multiple of 4" in lib.afldm_last_error()
     assert lib.afldm_probe_mfma_random(None, 64, 400, st) != 0
+
+
+def test_bench_two_ranks_on_one_gpu_runs_the_multi_rank_path():
+    """bench.py --gpus 2 launched the way the driver launches it (torch.distributed.run, one process per rank), on the ONE
+    GPU of the test box: AFLDM_SAME_GPU=1 puts both ranks on device 0 and the backend is gloo (RCCL refuses two ranks on
+    one device).  Not a scaling point - it executes everything the N > 1 line needs besides RCCL itself: per-rank noise
+    shards and graph capture, barrier + MAX-over-ranks timing, the all-gather of the final latents inside the timed
+    region, the process-group record; and it checks the record's honesty (2 ranks, ONE distinct device)."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, AFLDM_SAME_GPU="1", AFLDM_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--regions", "1",
+           "--no-cpu-baseline", "--no-extras", "--no-roofline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["config"]["latents_finite"]
+    assert d["config"]["global_batch"] == 128 and d["value"] > 0
+    rc = d["rccl"]
+    assert rc["world_size"] == 2 and rc["backend"] == "gloo" and len(rc["ranks"]) == 2 and rc["distinct_devices"] == 1
+    assert rc["all_gather_verified"] is True and rc["all_gather_bytes"] == 128 * 4 * 32 * 32 * 4

@@ -38,7 +38,8 @@ def run_one():
 m, ts = timed(run_one)
 print(f"one engine, batch 64:            {m:.4f} ms/step  {['%.4f' % t for t in ts]}", flush=True)
 
-per = 64 // NS
+per = int(os.environ.get("PER", str(64 // NS)))          # PER=64 NSTREAMS=2: two batch-64 engines (128 samples per "step")
+noise = parallel.global_noise(per * NS, (4, 32, 32), 1234).to(dev) if per * NS != 64 else noise
 streams = [torch.cuda.Stream() for _ in range(NS)]
 engs = []
 for i, s in enumerate(streams):
@@ -63,7 +64,9 @@ def run_two():
     for s in streams:
         main.wait_stream(s)
 m2, ts2 = timed(run_two)
-print(f"{NS} engines, batch {per} each, {NS} streams: {m2:.4f} ms per 64-sample step  {['%.4f' % t for t in ts2]}", flush=True)
+print(f"{NS} engines, batch {per} each, {NS} streams: {m2:.4f} ms per {per * NS}-sample step = {m2 * 64 / (per * NS):.4f} per 64 samples  {['%.4f' % t for t in ts2]}", flush=True)
+if per * NS != 64:
+    sys.exit(0)
 # same result?
 one.reset(noise); one.step(10); torch.cuda.synchronize()
 ref = one.lat.clone()
