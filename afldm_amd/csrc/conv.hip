@@ -1607,6 +1607,8 @@ static const Variant kVariants[] = {
     {128, 96, 6, 2},   // 62  the same for 16x16 planes
     {256, 128, 6, 3},  // 63  = 58 with persistent workgroups (k_conv3h_pers: one workgroup per CU walks its tiles)
     {128, 192, 6, 3},  // 64  32x32 planes, 4 rows x 192 couts per tile, persistent workgroups (two tiles per CU at batch 64)
+    {64, 96, 6, 3},    // 65  32x32 planes, 2 rows x 96 couts per tile (small batches)
+    {64, 96, 6, 3},    // 66  16x16 planes, 4 rows x 96 couts per tile (small batches)
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -1656,7 +1658,7 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
     if (kVariants[v].ver == 6) {
       // halo-patch kernel: the small-tile variants (51+) may split the CHANNEL BLOCKS over up to 4 slices when the
       // tiles alone leave most CUs idle; the slice count must divide the number of 128-byte channel blocks
-      if (v < 51 || v >= 57) return 1;
+      if (v < 51 || (v >= 57 && v != 65 && v != 66)) return 1;
       const int ncb = Ct / (2 * elems_per_row);
       int z = 1;
       for (int c = 2; c <= 4; ++c)
@@ -1706,8 +1708,14 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
       else if (s_h3 >= 3 && a->W == 8 && M >= 2048 && a->Cout % 96 == 0) vid = 51;
       else if (s_h3 >= 3 && a->W == 4 && M >= 1024 && a->Cout % 96 == 0) vid = 52;
       else if (s_h3 >= 4 && bf && a->Cout % 96 == 0) {      // small batches (bf16; fp32 measured slower: 4.99 vs 4.38 ms/step at batch 1): the 96-cout tiles with split channel blocks
-        if (a->W == 32 && M >= 1024) vid = 55;
-        else if (a->W == 16 && M >= 256) vid = 54;
+        // 64-pixel tiles (65 / 66) while the 128-pixel ones leave CUs without a workgroup: per launch 13.2 -> 10.2 us
+        // (batch 8, 32^2), 18.2 -> 14.9 (batch 8, 16^2 incl. the reduction), 11.5 -> 9.7 (batch 1); in the step 2.463 -> 2.410
+        // (batch 8), 2.198 -> 2.153 (batch 1), 2.80 -> 2.75 ms (batch 16), same box (profiles/r04/small_batch_tiles_ab.txt).
+        // AFLDM_CONV3H_SB: bit 0: 32x32 planes, bit 1: 16x16 planes (0 = the 128-pixel tiles, for A/B)
+        static const int s_sb = getenv("AFLDM_CONV3H_SB") ? atoi(getenv("AFLDM_CONV3H_SB")) : 3;
+        const long long t128s = (M / 128) * (a->Cout / 96);
+        if (a->W == 32 && M >= 1024) vid = ((s_sb & 1) && t128s < 256) ? 65 : 55;
+        else if (a->W == 16 && M >= 256) vid = ((s_sb & 2) && t128s < 256) ? 66 : 54;
         else if (a->W == 8 && M >= 64) vid = 51;
         else if (a->W == 4 && M >= 64) vid = 52;
       }

@@ -1149,6 +1149,9 @@ static const H3Variant kH3[] = {
     // across tile boundaries (bf16, whole K per workgroup)
     {256, 32, 128, 4, 2, 16, 1, 1},   // 63: as 58 (AF-VAE planes of 64^2 and up)
     {128, 32, 192, 2, 2, 16, 1},      // 64: 32x32 planes, 4 rows per tile: two tiles per CU at batch 64
+    // Small batches (round 4): 64-pixel tiles, so that batch 8 still gives every CU a workgroup at the 32^2 / 16^2 levels
+    {64, 32, 96, 2, 2, 16, 3},        // 65: 32x32 planes, 2 rows x 96 couts, 3 taps per step
+    {64, 16, 96, 2, 2, 16, 3},        // 66: 16x16 planes, 4 rows x 96 couts
 };
 constexpr int kNumH3 = (int)(sizeof(kH3) / sizeof(kH3[0]));
 
@@ -1171,7 +1174,8 @@ bool conv3h_supported(int variant, int dtype_size, const ConvP& p) {
   const int z = p.splitk > 0 ? p.splitk : 1;
   const bool tile_ok = HW % v.bm == 0 || (v.bm % HW == 0 && (z > 1 || dtype_size == 2));    // several samples per tile: as split-K slabs, or (bf16) through the per-sample epilogue
   const bool plane_ok = v.sub ? (p.W > v.w && p.W % v.w == 0 && p.H % (v.bm / v.w) == 0 && z == 1) : (p.W == v.w && p.H == p.W && tile_ok);
-  if (k >= 22 && !(dtype_size == 2 && z == 1 && HW % v.bm == 0 && p.C1 / kstep >= 2 && (!p.temb || p.temb_mod > 0))) return false;   // persistent variants
+  if ((k == 22 || k == 23) && !(dtype_size == 2 && z == 1 && HW % v.bm == 0 && p.C1 / kstep >= 2 && (!p.temb || p.temb_mod > 0))) return false;   // persistent variants
+  if (k >= 24 && dtype_size != 2) return false;                                      // 65 / 66: bf16 instantiations only
   return p.KS == 3 && p.C2 == 0 && plane_ok && p.M % v.bm == 0 && p.Cout % v.bn == 0 &&
          p.C1 % kstep == 0 && (p.C1 / kstep) % z == 0 && p.out_mode == 0 && !p.y2 && p.y_ld % eo == 0 &&
          (!p.residual || p.res_ld % eo == 0) && (!p.temb || (p.temb_stride % eo == 0 && p.temb_mod % eo == 0)) &&
@@ -1274,6 +1278,8 @@ void conv3h_launch(int variant, int dtype_size, const ConvP& p, hipStream_t st) 
   const int k = variant - kConv3hFirst;
   if (k == 22) { launch_h3_pers<256, 32, 128, 4, 2, true>(p, st); return; }
   if (k == 23) { launch_h3_pers<128, 32, 192, 2, 2, false>(p, st); return; }
+  if (k == 24) { launch_h3<bf16, 64, 32, 96, 2, 2, 16, 3>(p, st); return; }
+  if (k == 25) { launch_h3<bf16, 64, 16, 96, 2, 2, 16, 3>(p, st); return; }
   if (dtype_size == 2) launch_h3_variant<bf16>(k, p, st);
   else launch_h3_variant<float>(k, p, st);
 }

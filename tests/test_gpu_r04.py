@@ -498,3 +498,42 @@ def test_bench_two_ranks_on_one_gpu_runs_the_multi_rank_path():
     rc = d["rccl"]
     assert rc["world_size"] == 2 and rc["backend"] == "gloo" and len(rc["ranks"]) == 2 and rc["distinct_devices"] == 1
     assert rc["all_gather_verified"] is True and rc["all_gather_bytes"] == 128 * 4 * 32 * 32 * 4
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,va,vb", [(8, 32, 192, 192, 55, 65), (1, 32, 192, 192, 55, 65), (1, 16, 384, 384, 54, 66),
+                                                (4, 16, 768, 384, 54, 66), (8, 16, 384, 384, 54, 66)])
+def test_conv3x3_small_batch_64_pixel_tiles_vs_128_pixel_tiles(B, H, Cin, Cout, va, vb):
+    """Variants 65 / 66 of the halo-patch kernel (64-pixel tiles: the small-batch default of round 4) against the 128-pixel
+    tiles they replace, on the same inputs with bias, residual and GroupNorm statistics: the K order is the same, so the
+    outputs are bit-identical whenever both plans use the same number of channel-block slices (otherwise they differ by
+    the order of the slab sums: one bf16 ulp); the per-channel statistics agree to fp32 summation order."""
+    import ctypes
+    from afldm_amd import _lib, ops
+    g = torch.Generator().manual_seed(B + H + Cin)
+    x = torch.randn(B, H, H, Cin, generator=g).to(torch.bfloat16).cuda()
+    w = ops.pack_weight((torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).cuda(), torch.bfloat16)
+    b = torch.randn(Cout, generator=g).cuda()
+    res = torch.randn(B, H, H, Cout, generator=g).to(torch.bfloat16).cuda()
+    outs = {}
+    for v in (va, vb):
+        _lib.check(_lib.lib.afldm_conv2d_tune(v, -1), "tune")
+        try:
+            y = ops.conv2d(x, w, b, residual=res, want_stats=True)
+            a = ops.conv_args(x, w, b, residual=res, out=torch.empty_like(y))
+            need = _lib.lib.afldm_conv2d_workspace(ctypes.byref(a))
+            ws = torch.empty(max(need, 4) // 4, dtype=torch.float32, device="cuda")
+            a.workspace, a.workspace_bytes = ops.ptr(ws), need
+            code = _lib.lib.afldm_conv2d_variant(ctypes.byref(a))
+        finally:
+            _lib.lib.afldm_conv2d_tune(-1, -1)
+        assert (code & 255) == v, f"variant {v} was not taken (plan says {code & 255})"
+        outs[v] = (y, y.gn_partial.sum(1), (code >> 8) & 255)
+    (ya, sa, za), (yb, sb, zb) = outs[va], outs[vb]
+    if za == zb:
+        assert torch.equal(ya, yb)
+    else:
+        assert float((ya.float() - yb.float()).abs().max()) <= 2.0 ** -6 * float(ya.float().abs().max())
+    assert float((sa - sb).abs().max()) <= 1e-4 * float(sa.abs().max())
+    ref = torch.nn.functional.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float().cpu().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2),
+                                     b.cpu(), padding=1).permute(0, 2, 3, 1) + res.float().cpu()
+    assert rel_rms(yb.float(), ref) <= 6e-3
