@@ -1661,7 +1661,8 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
       if (v < 51 || (v >= 57 && v != 65 && v != 66)) return 1;
       const int ncb = Ct / (2 * elems_per_row);
       int z = 1;
-      for (int c = 2; c <= 4; ++c)
+      static const int s_zmax = getenv("AFLDM_CONV3H_ZMAX") ? atoi(getenv("AFLDM_CONV3H_ZMAX")) : 8;      // (4 -> 8: batch 8 2.410 -> 2.378, batch 1 2.158 -> 2.134 ms/step, same box)
+      for (int c = 2; c <= s_zmax; ++c)
         if (ncb % c == 0 && tiles * c <= 320) z = c;
       // AFLDM_CONV3H_Z1=1: no slices from 128 tiles on (the 4x4 level at batch 64 through the per-sample epilogue of the
       // multi-sample tiles: 12.6 MB less slab traffic and one launch less per layer, conv3x3 family 1.52x -> 1.43x of
