@@ -840,8 +840,10 @@ def attention(q, k, vt, heads, scale=None, out=None):
 
 
 _FUSED_ATTN = os.environ.get("AFLDM_NO_FUSED_ATTN", "0") != "1"
-# below this many (sample, head) workgroups the chip is not filled by one workgroup per pair: the three-launch path wins
-_FUSED_ATTN_MIN_WGS = int(os.environ.get("AFLDM_FUSED_ATTN_MIN_WGS", "256"))
+# below this many (sample, head) workgroups the chip is too empty with one workgroup per pair: the three-launch path wins.
+# In-step A/B (profiles/r04/small_batch_tiles_ab.txt): 128 against 256: batch 8 2.385 -> 2.362 (the 16^2 level fuses), batch 12
+# 2.741 -> 2.710, batch 16 2.741 -> 2.717, batch 24 3.485 -> 3.373 ms/step; 64: batch 8 2.394 (the 32^2 level loses)
+_FUSED_ATTN_MIN_WGS = int(os.environ.get("AFLDM_FUSED_ATTN_MIN_WGS", "128"))
 # fewest tokens per sample the fused launch is used for (in-step A/B decides between the 32^2 level only and 32^2 + 16^2)
 _FUSED_ATTN_MIN_T = int(os.environ.get("AFLDM_FUSED_ATTN_MIN_T", "256"))
 
