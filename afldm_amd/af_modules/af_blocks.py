@@ -36,7 +36,12 @@ class WarpedNonlinearity(nn.Module):
             return ops.silu(x) if x.ndim < 4 else ops.af_act(x)
         if x.ndim < 4:
             return self.nonlinearity(x)
-        return ops.af_lpf_down2(self.nonlinearity(ops.af_up2(x)).contiguous())
+        # The wrapped module is the caller's code and expects the reference's NCHW tensor (af_blocks.py:24-27): modules with
+        # channel semantics - PReLU(num_parameters=C), Softmax / GLU over dim 1, channel-wise norms - would silently
+        # compute something else on the internal NHWC layout.  A permuted VIEW carries the NCHW shape and
+        # strides over the NHWC memory; the result is brought back to contiguous NHWC for the HIP low-pass.
+        up = ops.af_up2(x).permute(0, 3, 1, 2)
+        return ops.af_lpf_down2(self.nonlinearity(up).permute(0, 2, 3, 1).contiguous())
 
 
 class AliasFreeUpsample2D(Upsample2D):

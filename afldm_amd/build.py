@@ -54,7 +54,8 @@ def _fingerprint(cmd, deps):
 def build(force=False, verbose=True):
     os.makedirs(OUT_DIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "conv_common.hpp"), os.path.join(HERE, "..", "include", "afldm_hip.h")]
+    headers = [os.path.join(CSRC, h) for h in ("common.hpp", "conv_common.hpp", "conv3h_tile.hpp", "conv3h_body.inc", "af_plane.hpp",
+                                               "af_plane_passes.inc")] + [os.path.join(HERE, "..", "include", "afldm_hip.h")]
     def command(src, obj):
         mode = os.environ.get("AFLDM_VGPR_FORM", "")
         vg = mode == "all" or (mode != "none" and os.path.basename(src) in VGPR_FORM)

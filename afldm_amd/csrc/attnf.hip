@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(NW * 64, LEAN ? 2 : 1) k_attn_fused(AttnFP p) 
           s2 += (double)sv[u][1];
         }
       }
-      if (j0 + 16 * SV >= nst) break;                       // (wave-uniform)
+      if (j0 + 16 * SV >= nst) break;                       // (per lane: j0 depends on the lane; the shuffles below come after the loop)
       stats_issue(g, j0 + 16 * SV);
     }
 #pragma unroll
@@ -559,11 +559,10 @@ __global__ void __launch_bounds__(NW * 64, LEAN ? 2 : 1) k_attn_fused(AttnFP p) 
 template <int D, int NW, int TPW, int CK, int DBG = 0, bool LEAN = false>
 static int attnf_launch(const AttnFP& p, hipStream_t st) {
   typedef AttnFCfg<D, NW, TPW, CK, LEAN> CF;
-  static bool once = false;
-  if (!once) {
+  static unsigned long long once = 0;
+  if (first_on_device(once)) {
     (void)hipFuncSetAttribute((const void*)k_attn_fused<D, NW, TPW, CK, DBG, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               CF::LDS_BYTES);
-    once = true;
   }
   k_attn_fused<D, NW, TPW, CK, DBG, LEAN><<<p.B * p.heads, NW * 64, CF::LDS_BYTES, st>>>(p);
   return check_launch("afldm_attn_block_fused");

@@ -331,6 +331,18 @@ __device__ __forceinline__ void gn_finalize(const GnStats& s, int b, int g, int 
   gn_mean_rstd(s1, s2, n, eps, mean, rstd);
 }
 
+// "Once per DEVICE" guard for hipFuncSetAttribute(MaxDynamicSharedMemorySize, ...): the attribute belongs to the
+// (function, device) pair, so a process that drives a second GPU has to set it there too.  `done` is a
+// bit mask over device ordinals; the caller keeps it in a function-local static.
+static inline bool first_on_device(unsigned long long& done) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done & bit) return false;
+  done |= bit;
+  return true;
+}
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace afldm

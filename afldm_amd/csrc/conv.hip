@@ -1772,11 +1772,10 @@ static void launch_igemm(const ConvP& p0, hipStream_t st) {
   const int tiles_m = (p.M + BM - 1) / BM;
   dim3 grid(tiles_m * p.tiles_n, 1, p.splitk);
   constexpr int lds = 2 * KCH * (BM + BN) * 64;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;
+  if (first_on_device(attr_set)) {
     (void)hipFuncSetAttribute((const void*)k_igemm<T, BM, BN, WGM, WGN, KCH>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
   }
   k_igemm<T, BM, BN, WGM, WGN, KCH><<<grid, WGM * WGN * 64, lds, st>>>(p);
 }
@@ -1789,11 +1788,10 @@ static void launch_igemm2(const ConvP& p0, hipStream_t st) {
   const int tiles_m = (p.M + BM - 1) / BM;
   dim3 grid(tiles_m * p.tiles_n, 1, p.splitk);
   constexpr int lds = STAGES * KCH * (BM + BN) * 64;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;
+  if (first_on_device(attr_set)) {
     (void)hipFuncSetAttribute((const void*)k_igemm2<T, BM, BN, WGM, WGN, KCH, STAGES, NPROD, R128, MINW>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
   }
   k_igemm2<T, BM, BN, WGM, WGN, KCH, STAGES, NPROD, R128, MINW><<<grid, (WGM * WGN + NPROD) * 64, lds, st>>>(p);
 }
@@ -1807,10 +1805,9 @@ static void launch_igemm3(const ConvP& p0, hipStream_t st) {
     p.tiles_n = p.Cout / 192;
     const int tiles = (p.M / 128) * p.tiles_n;
     constexpr int lds = STAGES * (128 + 192) * 128 + 4 * 32 * (96 + 8) * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (first_on_device(attr_set)) {
       (void)hipFuncSetAttribute((const void*)k_igemm3<T, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      attr_set = true;
     }
     k_igemm3<T, STAGES><<<tiles < 256 ? tiles : 256, 512, lds, st>>>(p);
   }
@@ -2088,10 +2085,9 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
   if (pl.kind == 1 && cin4_mfma_ok<T>(a)) {
     if (smode == ST_EPILOGUE) p.stats_out = a->stats_out;
     const int lds = CIN4_BM * (a->Cout + 8) * 2 + 4 * a->Cout * 2 * (int)sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (first_on_device(attr_set)) {
       (void)hipFuncSetAttribute((const void*)k_conv_cin4_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
     }
     k_conv_cin4_mfma<<<(p.M + CIN4_BM - 1) / CIN4_BM, 256, lds, st>>>(p);
     rc = check_launch("afldm_conv2d(cin4_mfma)");

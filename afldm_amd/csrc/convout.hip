@@ -184,10 +184,9 @@ extern "C" int afldm_conv_out_fused(const void* x, const float* stats, int S, co
   auto lds_of = [](int c) { return (c / 64) * 340 * 128 + 4 * 9 * c * 2 + 16 + (2 * c + 2 * 64) * 4; };
 #define AFLDM_CO(C_)                                                                                                   \
   if (C == C_) {                                                                                                       \
-    static bool attr_set = false;                                                                                      \
-    if (!attr_set) {                                                                                                   \
+    static unsigned long long attr_set = 0;                                                                            \
+    if (first_on_device(attr_set)) {                                                                                   \
       (void)hipFuncSetAttribute((const void*)k_conv_out_fused<C_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_of(C_)); \
-      attr_set = true;                                                                                                 \
     }                                                                                                                  \
     k_conv_out_fused<C_><<<grid, 512, lds_of(C_), st>>>(p);                                                            \
   }

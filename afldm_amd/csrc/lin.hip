@@ -197,10 +197,9 @@ __global__ void __launch_bounds__((NWC + NPROD) * 64, MINW) k_lin_wreg(LinP p) {
 template <int K, int NPW, int BM, int NST, int NWC, int NPROD, int MINW>
 static int launch_lin(LinP p, hipStream_t st) {
   typedef LinCfg<K, NPW, BM, NST, NWC> CF;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;
+  if (first_on_device(attr_set)) {
     (void)hipFuncSetAttribute((const void*)k_lin_wreg<K, NPW, BM, NST, NWC, NPROD, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS);
-    attr_set = true;
   }
   p.ntiles = p.M / BM;
   p.nchunks = p.N / CF::BN;

@@ -387,10 +387,9 @@ template <typename T, int K, int R, int R2, int NWV, bool UID = false, int CT = 
 static int launch_sep_w(const SepP& p, int per_cu, hipStream_t st) {
   typedef SepCfg<T, K, R, R2, NWV, UID, CT> CF;
   static_assert(CF::LDS_BYTES <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;
+  if (first_on_device(attr_set)) {
     (void)hipFuncSetAttribute((const void*)k_sep<T, K, R, R2, NWV, UID, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
-    attr_set = true;
   }
   const long long ngroups = p.outer_count * (p.inner_count / CF::LPW);
   long long grid = 256 * per_cu;

@@ -68,6 +68,9 @@ class DenoiseEngine:
         nb = int(os.environ.get("AFLDM_BRANCHES", branches))
         self.branches = nb if nb > 1 and batch_size % nb == 0 else 1
         self._side = [torch.cuda.Stream() for _ in range(self.branches - 1)]
+        # counters of in-kernel reductions / cluster hand-overs: private to this engine (one per branch), so that its
+        # captured graphs can replay next to another engine's on a different stream
+        self._sync = [ops.new_sync_buffer(dev) for _ in range(self.branches)]
 
     # one denoise step, entirely stream-ordered
     def _step(self):
@@ -86,15 +89,16 @@ class DenoiseEngine:
         for i, s in enumerate(self._side):
             s.wait_stream(main)
             with torch.cuda.stream(s):
-                self._substep(self.lat[(i + 1) * per:(i + 2) * per], self.x_nhwc[(i + 1) * per:(i + 2) * per])
+                self._substep(self.lat[(i + 1) * per:(i + 2) * per], self.x_nhwc[(i + 1) * per:(i + 2) * per], branch=i + 1)
         self._substep(self.lat[:per], self.x_nhwc[:per])
         for s in self._side:
             main.wait_stream(s)
 
-    def _substep(self, lat, x_nhwc):
-        ops.to_nhwc(lat, self.unet.dtype, out=x_nhwc)
-        eps = self.unet.forward_nhwc(x_nhwc, self.t_cur, temb_slices=self.temb_slices)
-        ops.ddim_step(lat, eps, self.coef, self.step_idx, advance=False, out=lat)
+    def _substep(self, lat, x_nhwc, branch=0):
+        with ops.sync_scope(self._sync[branch]):
+            ops.to_nhwc(lat, self.unet.dtype, out=x_nhwc)
+            eps = self.unet.forward_nhwc(x_nhwc, self.t_cur, temb_slices=self.temb_slices)
+            ops.ddim_step(lat, eps, self.coef, self.step_idx, advance=False, out=lat)
 
     def _capture(self):
         keep = self.lat.clone()

@@ -607,10 +607,42 @@ _SYNC = {}
 _SYNC_SPARE = {}
 
 
+SYNC_WORDS = 32768        # int32 words of a sync buffer: [0, 8192) split-K tile counters, [8192] error word,
+                          # [16384, 32768) cluster hand-over counters of the merged launches (one 128-byte line per sample)
+_SYNC_OVERRIDE = None
+
+
+def new_sync_buffer(device):
+    """A private, zeroed sync buffer (see _sync_words) for ONE stream of launches - a DenoiseEngine (each of its
+    branches) owns one, so that graphs captured on torch's shared capture stream and later replayed CONCURRENTLY on
+    different streams never share counters."""
+    return torch.zeros(SYNC_WORDS, dtype=torch.int32, device=device)
+
+
+class sync_scope:
+    """with sync_scope(buf): every launch issued inside takes `buf` as its sync words instead of the per-stream one."""
+
+    def __init__(self, buf):
+        self.buf = buf
+
+    def __enter__(self):
+        global _SYNC_OVERRIDE
+        self.prev, _SYNC_OVERRIDE = _SYNC_OVERRIDE, self.buf
+        return self.buf
+
+    def __exit__(self, *a):
+        global _SYNC_OVERRIDE
+        _SYNC_OVERRIDE = self.prev
+
+
 def _sync_words(device):
-    """Zero-initialised counter words for the in-kernel split-K reduction (afldm_conv_args.sync): one buffer per
-    (device, stream) - launches of ONE stream share it in stream order and each leaves it zero; concurrent streams
-    (DenoiseEngine branches) must not share tile counters."""
+    """Zero-initialised counter words for the in-kernel split-K reduction (afldm_conv_args.sync) and the cluster
+    hand-overs of the merged launches: one buffer per (device, stream) - launches of ONE stream share it in stream order
+    and each leaves it zero; concurrent streams (DenoiseEngine branches) must not share counters.  An
+    engine scopes its own buffer over its launches (sync_scope): captured graphs all run on torch's one capture stream
+    at capture time but may replay concurrently later."""
+    if _SYNC_OVERRIDE is not None:
+        return _SYNC_OVERRIDE
     key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     if key not in _SYNC:
         # never allocate under graph capture (the buffer would live in that graph's private pool while this dict hands
@@ -623,9 +655,9 @@ def _sync_words(device):
                                    "capture; run one eager step (warm-up) before capturing")
             _SYNC[key] = spares.pop()
         else:
-            _SYNC[key] = torch.zeros(16384, dtype=torch.int32, device=device)
+            _SYNC[key] = new_sync_buffer(device)
             while len(spares) < 8:
-                spares.append(torch.zeros(16384, dtype=torch.int32, device=device))
+                spares.append(new_sync_buffer(device))
     return _SYNC[key]
 
 

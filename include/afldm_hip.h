@@ -305,8 +305,12 @@ int afldm_attention(const void* q, int ldq, const void* k, int ldk, const void* 
  * projects its head's q / k / v with w_qkv [3C,C] (to_q | to_k | to_v rows) + bias_qkv [3C] and runs the attention
  * against K / V^T resident in LDS; o [B,T,C] = the input of to_out.  q | k | v never exist in memory.
  * bf16 only; shapes: see afldm_attn_block_fused_supported (1 = there is a kernel for T tokens, C channels, head_dim,
- * G groups).  Same rounding points as afldm_gn_apply + afldm_conv2d + afldm_attention (normalised tokens, q, k, v and the
- * softmax weights in bf16) except that the softmax scale is applied to q before its rounding. */
+ * G groups).  Rounding points: q, k, v and the softmax weights are rounded to bf16 as in afldm_conv2d + afldm_attention,
+ * but the NORMALISED TOKENS ARE NEVER MATERIALISED: GroupNorm is folded into the head's weight rows, W' = bf16(W * rstd *
+ * gamma) with the shift in the (fp32) bias, so bf16 rounds W' where the three-launch path rounds the normalised tokens, and
+ * the softmax scale is applied to q before its one rounding.  Same error class (2.1e-3 against 1.9e-3 vs the fp32 form on
+ * random data), different bits: a sample's bf16 result depends on which path its batch selected (policy: ops.py
+ * _FUSED_ATTN_MIN_WGS; tests pin the path). */
 int afldm_attn_block_fused_supported(int T, int C, int head_dim, int G);
 /* diagnostic: device buffer [workgroups][waves][12] of 64-bit shader-clock stamps that later afldm_attn_block_fused
  * launches fill (phase boundaries per wave; csrc/attnf.hip), NULL = off (the default). */

@@ -1,0 +1,110 @@
+"""Round-5 parity cases on MI355X.
+
+VERDICT r04 item 2: the BENCH path - batch 64, bf16, the fused attention front end on by policy, the step replayed as
+a HIP graph - tied to the oracle over a trajectory, not only over single forwards:
+  * the 50-step C1 run, the 99-evaluation I2SB bridge and `ddim_inversion` a second time with every eligible attention
+    block forced onto the fused launch (`_FUSED_ATTN_MIN_WGS = 0`: a batch of 1 takes it), against the same oracle
+    fixtures the three-launch path is held to;
+  * a batch-64 forward and a batch-64 50-step graph-replayed run whose sample 0 is the oracle fixture's input, asserted
+    against the fixture (reference loop: ldm_pipeline.py:103-109).
+Tolerances as in test_gpu_r02.py: bf16 forward <= 2e-2, multi-step <= 5e-2 rel-RMS."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_r02 import build_unet, rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+def _force_fused(monkeypatch):
+    """Every eligible attention block on afldm_attn_block_fused, whatever the batch; returns the call log."""
+    from afldm_amd import ops
+    monkeypatch.setattr(ops, "_FUSED_ATTN_MIN_WGS", 0)
+    calls = []
+    real = ops.attn_block_fused
+    monkeypatch.setattr(ops, "attn_block_fused", lambda *a, **k: (calls.append(tuple(a[0].shape)), real(*a, **k))[1])
+    return calls
+
+
+def test_ffhq_full_50_step_ddim_fused_attention_vs_oracle(golden, monkeypatch):
+    """C1 at full length (50 DDIM steps, FFHQ size, batch 1, graph replay) with the attention blocks of the 32^2 / 16^2
+    levels on the fused front end - the kernel bench.py times - against the fp32 oracle (tests/golden/g13_r03.npz)."""
+    from afldm_amd.engine import DenoiseEngine
+    from afldm_amd.schedulers.ddim import ffhq_ddim_scheduler
+    calls = _force_fused(monkeypatch)
+    g = golden("g13_r03.npz")
+    unet, _, _ = build_unet("ffhq", torch.bfloat16)
+    eng = DenoiseEngine(unet, ffhq_ddim_scheduler(), 1, 50, use_graph=True)
+    eng.reset(torch.from_numpy(g["ffhq_x"]))
+    eng.step(25)
+    mid = rel_rms(eng.lat, g["ffhq_ddim_step25"])
+    eng.step(25)
+    fin = rel_rms(eng.lat, g["ffhq_ddim_final"])
+    print(f"[C1 50 steps, fused attention] bf16: rel-RMS vs oracle after 25 steps {mid:.3e}, after 50 steps {fin:.3e}; "
+          f"{len(calls)} fused launches captured")
+    assert len(calls) >= 10, calls                        # 10 eligible blocks per forward (warm-up + capture)
+    assert mid <= 5e-2 and fin <= 5e-2, (mid, fin)
+
+
+def test_ffhq_99_evaluation_bridge_and_inversion_fused_attention_vs_oracle(golden, monkeypatch):
+    """C5's sampler at full length (99 UNet evaluations) and `ddim_inversion` with the fused attention front end forced
+    (same fixtures and bounds as test_gpu_r02.py holds the three-launch path to)."""
+    from afldm_amd.configs import FFHQ_DDIM_CONFIG
+    from afldm_amd.pipelines.i2sb_pipeline import I2SBLDMPipeline
+    from afldm_amd.pipelines.ldm_pipeline import MyLDMPipeline
+    from afldm_amd.schedulers.ddim import ffhq_ddim_scheduler
+    from afldm_amd.schedulers.i2sb import I2SBScheduler
+    calls = _force_fused(monkeypatch)
+    g = golden("g14_r03.npz")
+    cfg = {k: v for k, v in FFHQ_DDIM_CONFIG.items() if k != "set_alpha_to_one"}
+    unet, _, _ = build_unet("ffhq", torch.bfloat16)
+    pipe = I2SBLDMPipeline(None, unet, I2SBScheduler.from_config(cfg))
+    pipe.set_progress_bar_config(disable=True)
+    out = pipe._bridge(torch.from_numpy(g["i2sb_start"]).cuda().to(torch.bfloat16), 100, True, None)
+    r = rel_rms(out.float(), g["i2sb_final99"])
+    n_bridge = len(calls)
+    lp = MyLDMPipeline(None, unet, ffhq_ddim_scheduler())
+    lp.scheduler.set_timesteps(6, device="cuda")
+    inv = lp.ddim_inversion(torch.from_numpy(g["inv_in"]).cuda().to(torch.bfloat16), bar=False)
+    ri = rel_rms(inv.float(), g["inv_out_6"])
+    print(f"[C5 99 evaluations / inversion, fused attention] bf16: bridge {r:.3e} ({n_bridge} fused launches), inversion {ri:.3e}")
+    assert n_bridge >= 10 and len(calls) > n_bridge
+    assert r <= 6e-3 and ri <= 5e-2, (r, ri)
+
+
+def test_bench_path_batch64_forward_sample0_vs_oracle_fixture(golden):
+    """Exactly what bench.py times (batch 64, bf16, policy defaults: the fused attention front end is ON at this batch):
+    sample 0 of the batch is the oracle fixture's input (g6_ffhq_unet.npz), its output must meet the fixture at the
+    bf16 forward tolerance; the other 63 samples are noise."""
+    from afldm_amd import ops
+    g = golden("g6_ffhq_unet.npz")
+    unet, _, _ = build_unet("ffhq", torch.bfloat16)
+    x = torch.randn(64, 4, 32, 32, generator=torch.Generator().manual_seed(11))
+    x[0] = torch.from_numpy(g["x"])[0]
+    assert ops.attn_block_fused_ok(torch.empty(64, 1024, 192, dtype=torch.bfloat16, device="cuda"), 8, 32)
+    y = unet(x.cuda(), 981).sample
+    r = rel_rms(y[:1].float(), g["y_t981"])
+    print(f"[bench path, batch 64 forward] sample 0 vs oracle fixture: rel-RMS {r:.3e}")
+    assert r <= 2e-2, r
+
+
+def test_bench_path_batch64_50_steps_sample0_vs_oracle(golden):
+    """The bench configuration over the reference's whole loop: a batch-64 bf16 DenoiseEngine (HIP-graph replay of the
+    step, fused attention on by policy) runs all 50 DDIM steps; sample 0 started from the oracle fixture's noise and
+    must meet the oracle's step-25 and final latents (tests/golden/g13_r03.npz) at the multi-step tolerance."""
+    from afldm_amd.engine import DenoiseEngine
+    from afldm_amd.schedulers.ddim import ffhq_ddim_scheduler
+    g = golden("g13_r03.npz")
+    unet, _, _ = build_unet("ffhq", torch.bfloat16)
+    x = torch.randn(64, 4, 32, 32, generator=torch.Generator().manual_seed(12))
+    x[0] = torch.from_numpy(g["ffhq_x"])[0]
+    eng = DenoiseEngine(unet, ffhq_ddim_scheduler(), 64, 50, use_graph=True)
+    eng.reset(x)
+    eng.step(25)
+    mid = rel_rms(eng.lat[:1], g["ffhq_ddim_step25"])
+    eng.step(25)
+    fin = rel_rms(eng.lat[:1], g["ffhq_ddim_final"])
+    assert torch.isfinite(eng.lat).all()
+    print(f"[bench path, batch 64, 50 steps] sample 0 vs oracle: after 25 steps {mid:.3e}, after 50 steps {fin:.3e}")
+    assert mid <= 5e-2 and fin <= 5e-2, (mid, fin)

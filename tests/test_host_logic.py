@@ -215,6 +215,44 @@ def test_two_process_gloo_sharded_sampling(tmp_path, total):
     assert r.stdout.count("OK") == 2
 
 
+_WORKER8 = r"""
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from afldm_amd import parallel
+rank, world, local = parallel.init_distributed("gloo")
+assert world == 8
+total = int(sys.argv[2])
+s, e = parallel.shard_range(total, rank, world)
+sizes = [parallel.shard_range(total, r, world)[1] - parallel.shard_range(total, r, world)[0] for r in range(world)]
+assert sum(sizes) == total and max(sizes) - min(sizes) <= 1 and e - s == sizes[rank]
+fn = lambda z: z * 2.0 + z.flatten(1).sum(1).view(-1, 1, 1, 1)      # per-sample, like the sampler
+out = parallel.sample_sharded(fn, total, (4, 8, 8), 4321, rank, world, "cpu")
+ref = fn(parallel.global_noise(total, (4, 8, 8), 4321))
+assert out.shape == ref.shape and torch.equal(out, ref), (rank, out.shape)
+rec = parallel.rccl_record("cpu", local, payload=torch.full((e - s if total % world == 0 else 5, 4), float(rank)))
+assert rec["world_size"] == 8 and rec["backend"] == "gloo" and rec["all_gather_verified"] and len(rec["ranks"]) == 8
+assert sorted(r["rank"] for r in rec["ranks"]) == list(range(8)) and rec["distinct_devices"] == 8, rec
+parallel.barrier()
+print("OK", rank)
+"""
+
+
+@pytest.mark.parametrize("total", [512, 500])
+def test_eight_process_gloo_sharded_sampling_and_record(tmp_path, total):
+    """World size 8 - the shape of BASELINE configs[2] (batch 512 over 8 GPUs) - on CPU/gloo: even (512 = 8 x 64) and
+    uneven (500: four ranks of 63, four of 62) shards through `sample_sharded`'s ONE all-gather equal the single-process
+    result bit for bit, and the bench line's process-group record counts 8 ranks / 8 distinct local ranks
+    (the world = 8 bookkeeping exercised before the first real SCALE record)."""
+    script = tmp_path / "worker8.py"
+    script.write_text(_WORKER8)
+    port = 29300 + (os.getpid() % 200) + (total % 7)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(script), ROOT, str(total)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("OK") == 8
+
+
 def test_afldm_alias_and_diffusers_shim():
     """`afldm.X` is the same module object as `afldm_amd.X`; the diffusers shim exposes the names
     the reference's hot-path files import (af_blocks.py:6-7, cross_frame_attn.py:3, ldm_pipeline.py:1-4)."""
