@@ -28,6 +28,15 @@ class ConvArgs(Structure):
     ]
 
 
+class AfActArgs(Structure):
+    """afldm_af_act_args (include/afldm_hip.h): the activation half of afldm_af_act_conv2d."""
+    _fields_ = [
+        ("x1", c_void_p), ("x2", c_void_p), ("C1", c_int), ("C2", c_int), ("stats1", c_void_p), ("S1", c_int),
+        ("stats2", c_void_p), ("S2", c_int), ("gamma", c_void_p), ("beta", c_void_p), ("G", c_int), ("eps", c_float),
+        ("U", c_void_p), ("D", c_void_p), ("packed", c_void_p),
+    ]
+
+
 class SepArgs(Structure):
     _fields_ = [
         ("x", c_void_p), ("y", c_void_p), ("M", c_void_p), ("M2", c_void_p), ("gn_table", c_void_p),
@@ -83,6 +92,12 @@ def _load():
         "afldm_conv2d_tune": ([ip, ip], c_int),
         "afldm_conv2d_fused_splitk": ([ip], c_int),
         "afldm_conv2d_variant": ([POINTER(ConvArgs)], c_int),
+        "afldm_af_act_conv2d_merged": ([POINTER(AfActArgs), POINTER(ConvArgs)], c_int),
+        "afldm_af_act_conv2d": ([POINTER(AfActArgs), POINTER(ConvArgs), vp], c_int),
+        "afldm_af_act_conv2d_trace": ([vp], c_int),
+        "afldm_act_conv_act_merged": ([POINTER(AfActArgs), POINTER(ConvArgs), POINTER(AfActArgs)], c_int),
+        "afldm_act_conv_act": ([POINTER(AfActArgs), POINTER(ConvArgs), POINTER(AfActArgs), vp, vp], c_int),
+        "afldm_af_act_conv2d_mode": ([ip], c_int),
         "afldm_attention": ([vp, ip, vp, ip, vp, vp, ip, ip, ip, ip, ip, ip, ip, fp, ip, vp], c_int),
         "afldm_attn_block_fused_supported": ([ip, ip, ip, ip], c_int),
         "afldm_attn_block_fused_trace": ([vp], c_int),

@@ -2037,9 +2037,9 @@ static int stats_mode(const afldm_conv_args* a, const Exec& e, int* S) {
 
 extern "C" int afldm_gn_stats(const void* x, int C, float* stats, int B, int HW, int dtype, afldm_stream_t stream);
 
+// the argument block of every GEMM-path kernel, from the caller's arguments (plan-independent part)
 template <typename T>
-static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
-  ConvP p;
+static void fill_convp(const afldm_conv_args* a, ConvP& p) {
   p.x1 = a->x1; p.x2 = a->x2; p.w = a->w; p.bias = a->bias; p.temb = a->temb; p.residual = a->residual;
   p.y = a->y; p.ws = (float*)a->workspace;
   p.y2 = a->y2; p.split_n = a->split_n;
@@ -2071,6 +2071,13 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
     static const int s_mfast = getenv("AFLDM_CONV_MFAST") ? atoi(getenv("AFLDM_CONV_MFAST")) : -1;
     p.m_fast = s_mfast >= 0 ? s_mfast : ((long long)a->Cout * a->KS * a->KS > (long long)p.M ? 1 : 0);
   }
+  p.xcd_gn = 0;
+}
+
+template <typename T>
+static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
+  ConvP p;
+  fill_convp<T>(a, p);
   const Exec ex = resolve_exec<T>(a);
   const Plan& pl = ex.pl;
   int smode = 0;
@@ -2220,6 +2227,39 @@ static afldm_conv_args conv_chunk_args(const afldm_conv_args* a, int c) {
   q.B = c;
   return q;
 }
+
+// conv3h_plan (conv_common.hpp): true when afldm_conv2d would run this problem as ONE halo-patch launch (k_conv3h, whole
+// K per workgroup, statistics - if asked for - from its epilogue); then *p is exactly the argument block that launch
+// takes and *variant its id.  The merged launches of actconv.hip run that tile as their last phase.
+template <typename T>
+static bool plan_h3(const afldm_conv_args* a, ConvP& p, int& vid) {
+  if (conv_batch_chunk(a) != a->B || a->w_batch_stride || a->defer_reduce || a->KS != 3) return false;
+  if (lin_wreg_bm(a) || skinny_stats_splits(a)) return false;
+  fill_convp<T>(a, p);
+  const Exec ex = resolve_exec<T>(a);
+  if (ex.pl.kind != 0 || kVariants[ex.vid].ver != 6 || ex.splitk != 1 || ex.fused) return false;
+  p.stats_out = nullptr;
+  p.stats_S = 1;
+  p.stats_multi = 0;
+  if (a->stats_out) {
+    if (stats_mode<T>(a, ex, &p.stats_S) != ST_EPILOGUE) return false;
+    p.stats_out = a->stats_out;
+    p.stats_multi = (a->H * a->W) == 1 ? 2 : (a->H * a->W) < kVariants[ex.vid].bm ? 1 : 0;
+  }
+  p.ksteps = 9 * ((a->C1 + a->C2) / (KCH_DEFAULT * epr<T>()));
+  p.splitk = 1;
+  p.sync = nullptr;
+  vid = ex.vid;
+  return true;
+}
+namespace afldm {
+bool conv3h_plan(const afldm_conv_args* a, ConvP* p, int* variant) {
+  if (!a || conv_validate(a)) return false;
+  if (a->dtype == AFLDM_BF16) return plan_h3<bf16>(a, *p, *variant);
+  if (a->dtype == AFLDM_F32) return plan_h3<float>(a, *p, *variant);
+  return false;
+}
+}  // namespace afldm
 
 extern "C" int afldm_conv2d_variant(const afldm_conv_args* a0) {
   if (!a0 || (a0->dtype != AFLDM_F32 && a0->dtype != AFLDM_BF16)) return -1;

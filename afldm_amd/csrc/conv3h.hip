@@ -43,10 +43,14 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_conv3h(ConvP
 #define H3_BX blockIdx.x
 #define H3_NBX gridDim.x
 #define H3_BZ blockIdx.z
+#define H3_PATCH_AUX 0
+#define H3_PRODUCER_EXIT return;
 #include "conv3h_body.inc"
+#undef H3_PRODUCER_EXIT
 #undef H3_BX
 #undef H3_NBX
 #undef H3_BZ
+#undef H3_PATCH_AUX
 }
 
 // ----------------------------------------------------------------------------------------------- persistent tiles

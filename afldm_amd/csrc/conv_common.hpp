@@ -48,5 +48,8 @@ constexpr int kConv3hFirst = 41;
 bool conv3h_supported(int variant, int dtype_size, const ConvP& p);      // p.splitk = the planned K slices
 int conv3h_tile(int variant, int* bm, int* bn);
 void conv3h_launch(int variant, int dtype_size, const ConvP& p, hipStream_t st);
+// conv.hip: true when afldm_conv2d(a) is ONE k_conv3h launch (whole K per workgroup, statistics from its epilogue); fills the
+// argument block of that launch and its variant id (the merged launches of actconv.hip run the tile as their last phase)
+bool conv3h_plan(const afldm_conv_args* a, ConvP* p, int* variant);
 
 }  // namespace afldm

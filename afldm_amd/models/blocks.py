@@ -286,6 +286,21 @@ class ResnetBlock2D(nn.Module):
             return self.nonlinearity(ops.gn_apply(x1, stats, gamma, beta, norm.num_groups, norm.eps, act=0, x2=x2))
         return ops.gn_apply(x1, stats, gamma, beta, norm.num_groups, norm.eps, act=1, x2=x2)
 
+    def _norm_act_conv(self, norm, x, conv, **kw):
+        """conv(nonlinearity(norm(x))): ONE merged launch at the 32^2 / 16^2 levels of the alias-free bf16 model
+        (ops.af_act_conv2d, csrc/actconv.hip), else the activation kernel followed by the convolution."""
+        from ..af_modules.af_blocks import WarpedNonlinearity
+        x1, x2 = _pair(x)
+        if (isinstance(self.nonlinearity, WarpedNonlinearity) and self.nonlinearity.fused_silu and x1.ndim == 4
+                and x1.dtype == torch.bfloat16 and x1.shape[1] in ops._ACTCONV_N and tuple(conv.kernel_size) == (3, 3)):
+            gamma, beta = packed_norm(norm)
+            stats = ops.gn_stats(x1, norm.num_groups, x2=x2)
+            w, b = packed_conv(conv, x1.dtype)
+            out = ops.af_act_conv2d(x1, x2, stats, gamma, beta, norm.num_groups, norm.eps, w, b, **kw)
+            if out is not None:
+                return out
+        return conv_forward(conv, self._norm_act(norm, x), **kw)
+
     def _conv1_norm2_act_fused(self, h, temb_proj, temb_stride):
         """conv1 -> norm2 -> WarpedNonlinearity on the 2x2 / 4x4 planes when conv1 splits K: the activation kernel takes
         the convolution's fp32 slabs and finishes them itself (afldm_af_act_slabs) - no reduction launch, no stored
@@ -352,6 +367,12 @@ class ResnetBlock2D(nn.Module):
         """next_gn: the GroupNorm module of an attention block that consumes this block's output next (the block loops
         pass it): lets conv2 hand its result over already normalised where that saves launches."""
         x1, x2 = _pair(input_tensor)
+        if x1.ndim == 4 and x1.shape[1] in (16, 32):
+            # 32^2 / 16^2 levels: norm -> activation -> conv pairs as merged launches where there is a kernel for them
+            h = self._norm_act_conv(self.norm1, input_tensor, self.conv1, temb=temb_proj, temb_stride=temb_stride, want_stats=True)
+            res = conv_forward(self.conv_shortcut, input_tensor) if self.conv_shortcut is not None else x1
+            assert self.conv_shortcut is not None or x2 is None
+            return self._norm_act_conv(self.norm2, h, self.conv2, residual=res, want_stats=True)
         h = self._norm_act(self.norm1, input_tensor)
         fused = self._conv1_norm2_act_fused(h, temb_proj, temb_stride)
         if fused is not None:

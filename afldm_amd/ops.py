@@ -8,7 +8,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ConvArgs, DTYPE_CODE, SepArgs, check, stream_ptr
+from ._lib import AfActArgs, ConvArgs, DTYPE_CODE, SepArgs, check, stream_ptr
 
 _FILTER_CACHE = {}
 _PROFILE = None
@@ -610,13 +610,18 @@ _SYNC_SPARE = {}
 SYNC_WORDS = 32768        # int32 words of a sync buffer: [0, 8192) split-K tile counters, [8192] error word,
                           # [16384, 32768) cluster hand-over counters of the merged launches (one 128-byte line per sample)
 _SYNC_OVERRIDE = None
+_SCOPED_SYNC = []
 
 
 def new_sync_buffer(device):
     """A private, zeroed sync buffer (see _sync_words) for ONE stream of launches - a DenoiseEngine (each of its
     branches) owns one, so that graphs captured on torch's shared capture stream and later replayed CONCURRENTLY on
     different streams never share counters."""
-    return torch.zeros(SYNC_WORDS, dtype=torch.int32, device=device)
+    buf = torch.zeros(SYNC_WORDS, dtype=torch.int32, device=device)
+    import weakref
+    _SCOPED_SYNC[:] = [r for r in _SCOPED_SYNC if r() is not None]
+    _SCOPED_SYNC.append(weakref.ref(buf))
+    return buf
 
 
 class sync_scope:
@@ -751,6 +756,118 @@ def conv2d(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, o
              (M * Ct + a.Cout * a.KS * a.KS * Ct + M * a.Cout * (2 if residual is not None else 1)) * es,
              replay=lambda keep=keep: conv2d_launch(keep[0]))
     return out
+
+
+_ACTCONV = os.environ.get("AFLDM_NO_ACTCONV", "0") != "1"
+# plane sizes whose norm -> activation -> conv pairs ResnetBlock2D issues as merged launches.  EMPTY by default: built, bit-identical,
+# and measured SLOWER in the step (profiles/r05/actconv_ab.txt: 4.99 -> 5.01 ms with the 16^2 pairs, 5.09 with 32^2 too);
+# AFLDM_ACTCONV_N=16,32 turns them on (tests call the op directly)
+_ACTCONV_N = tuple(int(v) for v in os.environ.get("AFLDM_ACTCONV_N", "").split(",") if v)
+
+
+def act_conv_act(x1, x2, pre, w, bias=None, temb=None, temb_stride=0, residual=None, want_stats=False, post=None):
+    """[pre: GroupNorm-apply -> WarpedNonlinearity(SiLU) ->] 3x3 conv [-> post: GroupNorm-apply -> WarpedNonlinearity] as
+    ONE launch (afldm_act_conv_act, csrc/actconv.hip).
+      pre  = None (x1 IS the convolution's input) or (stats, gamma, beta, G, eps) applied to the virtual concat x1 | x2
+             (stats None: activation without normalisation);
+      post = None or (gamma, beta, G, eps): the activation of the convolution's own output with the statistics its
+             epilogue writes (gamma None: no normalisation).
+    Returns (conv_out, post_out) - conv_out carries `.gn_partial` when want_stats or post needs them and `.act_input`
+    (the activated input) when pre is given - or None when there is no merged kernel for the chain (the caller runs the
+    separate ops).  Bit-identical to them."""
+    if (not _ACTCONV or x1.ndim != 4 or x1.dtype != torch.bfloat16 or x1.shape[1] != x1.shape[2] or x1.shape[1] not in (16, 32)
+            or (pre is None and post is None)):
+        return None
+    C1, x2, C2 = _cat_args(x1, x2)
+    B, N = x1.shape[0], x1.shape[1]
+    Cout = w.shape[0]
+    if w.shape[1] != 3 or w.shape[3] != C1 + C2 or (pre is None and x2 is not None):
+        return None
+    act_out = torch.empty((B, N, N, C1 + C2), dtype=x1.dtype, device=x1.device) if pre is not None else x1
+    out = torch.empty((B, N, N, Cout), dtype=x1.dtype, device=x1.device)
+    a = conv_args(act_out, w, bias, None, temb, temb_stride, residual, out)
+    if a.sync_bytes < (16384 + 64 * B) * 4:
+        return None
+    need = lib.afldm_conv2d_workspace(ctypes.byref(a))
+    workspace = None
+    if need:                                   # (the plan would split K given the room: no merged kernel then, as conv2d decides)
+        workspace = torch.empty(need // 4, dtype=torch.float32, device=x1.device)
+        a.workspace, a.workspace_bytes = ptr(workspace), need
+    st = None
+    post_norm = post is not None and post[0] is not None
+    if (want_stats or post_norm) and Cout % 4 == 0:
+        S = lib.afldm_conv2d_stats_splits(ctypes.byref(a))
+        st = torch.empty((B, S, Cout, 2), dtype=torch.float32, device=x1.device)
+        a.stats_out = ptr(st)
+    U, D = filter_matrices(N, x1.device)
+    packed = packed_filters(N, x1.dtype, x1.device)
+    aa = pp = None
+    keep = [a, x1, x2, U, D, packed, act_out, out, st, workspace]
+    if pre is not None:
+        stats, gamma, beta, G, eps = pre
+        aa = AfActArgs()
+        aa.x1, aa.x2, aa.C1, aa.C2 = ptr(x1), ptr(x2), C1, C2
+        p1, S1, p2, S2 = _stats_ptrs(stats)
+        aa.stats1, aa.S1, aa.stats2, aa.S2 = p1, S1, p2, S2
+        aa.gamma, aa.beta, aa.G, aa.eps = ptr(gamma), ptr(beta), int(G), float(eps)
+        aa.U, aa.D, aa.packed = ptr(U), ptr(D), ptr(packed)
+        keep += [aa, stats, gamma, beta]
+    post_out = None
+    if post is not None:
+        gamma2, beta2, G2, eps2 = post
+        if post_norm and st is None:
+            return None
+        pp = AfActArgs()
+        pp.x1, pp.x2, pp.C1, pp.C2 = ptr(out), None, Cout, 0
+        pp.stats1, pp.S1, pp.stats2, pp.S2 = (ptr(st), st.shape[1], None, 0) if post_norm else (None, 0, None, 0)
+        pp.gamma, pp.beta, pp.G, pp.eps = ptr(gamma2), ptr(beta2), int(G2), float(eps2)
+        pp.U, pp.D, pp.packed = ptr(U), ptr(D), ptr(packed)
+        post_out = torch.empty((B, N, N, Cout), dtype=x1.dtype, device=x1.device)
+        keep += [pp, gamma2, beta2, post_out]
+    ra = ctypes.byref(aa) if aa is not None else None
+    rp = ctypes.byref(pp) if pp is not None else None
+    if not lib.afldm_act_conv_act_merged(ra, ctypes.byref(a), rp):
+        return None
+    keep = tuple(keep)
+    tok = _begin()
+    check(lib.afldm_act_conv_act(ra, ctypes.byref(a), rp, ptr(post_out), stream_ptr()), "act_conv_act")
+    if st is not None:
+        out.gn_partial = st
+    if tok is not None:
+        M, Ct, es = B * N * N, C1 + C2, x1.element_size()
+        # algorithmic work of the chain: the activations' dense separable form + the convolution; bytes: every tensor the
+        # separate launches would read / write once (raw in, activated in, weights, output (+ residual), activated out)
+        fl = 2.0 * M * Cout * 9 * Ct + (24.0 * N ** 3 * B * Ct if pre is not None else 0.0) + (24.0 * N ** 3 * B * Cout if post is not None else 0.0)
+        by = (M * Ct * (2 if pre is not None else 1) + Cout * 9 * Ct + M * Cout * ((2 if residual is not None else 1) + (1 if post is not None else 0))) * es
+        name = ("af_act_" if pre is not None else "") + "conv3x3" + ("_af_act" if post is not None else "") + f"_N{N}"
+
+        def replay(ra=ra, rp=rp, a=a, post_out=post_out, keep=keep):
+            check(lib.afldm_act_conv_act(ra, ctypes.byref(a), rp, ptr(post_out), stream_ptr()), "act_conv_act")
+        _end(tok, name, fl, by, replay=replay)
+    if pre is not None:
+        out.act_input = act_out          # the activated tensor (kept alive with the output; tests read it)
+    return out, post_out
+
+
+def af_act_conv2d(x1, x2, stats, gamma, beta, G, eps, w, bias=None, temb=None, temb_stride=0, residual=None,
+                  want_stats=False):
+    """[GroupNorm-apply ->] WarpedNonlinearity(SiLU) -> 3x3 conv as ONE launch: act_conv_act without the trailing
+    activation.  Returns the convolution's output or None (no merged kernel: the caller runs af_act + conv2d)."""
+    got = act_conv_act(x1, x2, (stats, gamma, beta, G, eps), w, bias, temb, temb_stride, residual, want_stats)
+    return None if got is None else got[0]
+
+
+def actconv_error(device=None):
+    """Error word of the merged launches' cluster hand-over (0 = fine; 1 = a workgroup gave up waiting for its cluster,
+    2 = a workgroup did not run on the XCD its id implies) over every sync buffer seen so far; synchronises, clears."""
+    worst = 0
+    bufs = [b for (dev, _), b in _SYNC.items() if device is None or dev == str(device)] + [r() for r in _SCOPED_SYNC if r() is not None]
+    for buf in bufs:
+        v = int(buf[8193].item())
+        if v:
+            worst = max(worst, v)
+            buf[8193] = 0
+    return worst
 
 
 def conv2d_slabs(x1, w, x2=None):

@@ -286,6 +286,56 @@ size_t afldm_conv2d_workspace(const afldm_conv_args* args);
 /* split count S of the statistics afldm_conv2d writes to stats_out for this problem (> 0). */
 int afldm_conv2d_stats_splits(const afldm_conv_args* args);
 
+/* ---- merged launch: [GroupNorm ->] WarpedNonlinearity -> 3x3 convolution ---------------------
+ * `hidden_states = self.nonlinearity(self.norm1(x)); hidden_states = self.conv1(hidden_states)` of diffusers
+ * ResnetBlock2D.forward with the reference's WarpedNonlinearity in place of SiLU (af_blocks.py:19-28), and the
+ * norm2 -> nonlinearity -> conv2 pair after it, as ONE launch at the 32^2 / 16^2 levels (bf16; csrc/actconv.hip): the
+ * workgroups that convolve a sample's tiles first run that sample's activation items and hand the activated tensor over
+ * inside the launch (per-sample counter in `conv->sync`).  `act` = the arguments of afldm_af_act without its output;
+ * `conv` = the arguments of afldm_conv2d whose x1 is BOTH the activation's output buffer ([B,N,N,C1+C2], written) and the
+ * convolution's input (x2 = NULL, C1 = act->C1 + act->C2).  conv->sync needs >= (16384 + 64 * B) * 4 bytes (zero between
+ * launches; words [16384, ...) hold one 128-byte counter line per sample, word 8193 an error flag: 1 = a workgroup gave up
+ * waiting for its cluster, 2 = a workgroup did not run on the XCD its id implies).
+ * Results are bit-identical to afldm_af_act(..., y = conv->x1) followed by afldm_conv2d(conv); shapes without a merged
+ * kernel (afldm_af_act_conv2d_merged(...) == 0: other plane sizes, fp32, split-K plans, no sync words, AFLDM_NO_ACTCONV=1)
+ * run as exactly those two launches. */
+typedef struct {
+  const void* x1;
+  const void* x2;       /* second tensor of a virtual concat, or NULL */
+  int C1, C2;
+  const float* stats1;  /* per-channel GroupNorm partial sums of x1 [B][S1][C1][2], NULL = no normalisation */
+  int S1;
+  const float* stats2;
+  int S2;
+  const float* gamma;
+  const float* beta;
+  int G;
+  float eps;
+  const float* U;       /* as afldm_af_act */
+  const float* D;
+  const void* packed;
+} afldm_af_act_args;
+int afldm_af_act_conv2d_merged(const afldm_af_act_args* act, const afldm_conv_args* conv);
+/* diagnostic: device buffer [workgroups][16] of 64-bit s_memtime stamps that later merged launches fill (0 start; 1 / 2 first
+ * activation's prologue / items done; 3 / 4 / 5 first hand-over: stores acknowledged, cluster complete, left; 6 tile done;
+ * 7 / 8 / 9 second hand-over; 10 / 11 second activation), NULL = off (the default). */
+int afldm_af_act_conv2d_trace(void* buf);
+/* 1: every merged launch uses the general (placement-independent) hand-over - write-through stores, agent-scope atomics,
+ * acquire fence - instead of the XCD-local one it picks when every cluster sits inside one XCD; 0 (default): automatic.
+ * Same results either way (tests; A/B of the two forms). */
+int afldm_af_act_conv2d_mode(int general);
+int afldm_af_act_conv2d(const afldm_af_act_args* act, const afldm_conv_args* conv, afldm_stream_t stream);
+/* The general chain: [pre: norm1 -> nonlinearity ->] conv [-> post: norm2 -> nonlinearity] of ResnetBlock2D.forward as ONE
+ * launch (pre or post may be NULL, not both).  `post` normalises the convolution's OWN output with the partial sums its
+ * epilogue writes: post->x1 = conv->y, post->C1 = conv->Cout, post->C2 = 0, post->stats1 = conv->stats_out (or NULL: no
+ * normalisation), post->S1 = afldm_conv2d_stats_splits(conv); the activated result goes to post_y [B,N,N,Cout].  The tile's
+ * workgroups hand conv->y over per sample inside the launch and run that sample's activation items out of the XCD's L2;
+ * conv->y itself is still written.  conv->sync needs >= (16384 + 64 * B) * 4 bytes.  Bit-identical to the two / three
+ * launches, which is also how shapes without a merged kernel run (afldm_act_conv_act_merged == 0). */
+int afldm_act_conv_act_merged(const afldm_af_act_args* pre, const afldm_conv_args* conv, const afldm_af_act_args* post);
+int afldm_act_conv_act(const afldm_af_act_args* pre, const afldm_conv_args* conv, const afldm_af_act_args* post, void* post_y,
+                       afldm_stream_t stream);
+
 /* ---- attention ---------------------------------------------------------------------------
  * F.scaled_dot_product_attention as called by AttnProcessor2_0 / CrossFrameAttnProcessor
  * (cross_frame_attn.py:125,128): o = softmax(q k^T * scale) v per (batch, head).

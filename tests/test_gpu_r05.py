@@ -108,3 +108,69 @@ def test_bench_path_batch64_50_steps_sample0_vs_oracle(golden):
     assert torch.isfinite(eng.lat).all()
     print(f"[bench path, batch 64, 50 steps] sample 0 vs oracle: after 25 steps {mid:.3e}, after 50 steps {fin:.3e}")
     assert mid <= 5e-2 and fin <= 5e-2, (mid, fin)
+
+
+# ------------------------------------------------------------------------------------------------ merged launches
+@pytest.mark.parametrize("case", [
+    # B, N, C1, C2, Cout, temb, residual
+    (64, 32, 192, 0, 192, True, False),       # conv1 of a 32^2 resnet block: XCD-local hand-over, 4 workgroups per sample
+    (64, 32, 192, 0, 192, False, True),       # conv2 (+ residual)
+    (64, 32, 384, 192, 192, True, False),     # up block: virtual concat, groups straddle the two tensors
+    (64, 16, 384, 0, 384, False, True),       # 16^2: 2 x 2 tiles per sample, 8-wave workgroups
+    (64, 16, 768, 384, 384, True, False),
+    (64, 16, 192, 0, 384, True, False),
+    (40, 32, 192, 0, 192, True, True),        # 160 tiles: clusters straddle XCDs -> the general (agent-scope) hand-over
+    (36, 16, 384, 384, 384, True, False),
+    (3, 32, 192, 0, 192, True, True),         # small batches take other convolution tiles: the two launches (None)
+    (16, 32, 192, 192, 192, False, False),    # two clusters per XCD
+])
+def test_af_act_conv2d_merged_launch_bit_identical_to_two_launches(case):
+    """afldm_af_act_conv2d (csrc/actconv.hip): norm -> WarpedNonlinearity -> 3x3 conv of a ResnetBlock2D as ONE launch with
+    a per-sample hand-over inside it, against afldm_af_act followed by afldm_conv2d on the same inputs: output,
+    activated tensor and GroupNorm partial sums bit-identical, re-runs bit-identical, no hand-over error flag."""
+    from afldm_amd import ops
+    B, N, C1, C2, Cout, use_temb, use_res = case
+    g = torch.Generator().manual_seed(B * 1000 + N + C1)
+    Ct = C1 + C2
+    x1 = (torch.randn(B, N, N, C1, generator=g) * 1.5 + 0.3).cuda().to(torch.bfloat16)
+    x2 = torch.randn(B, N, N, C2, generator=g).cuda().to(torch.bfloat16) if C2 else None
+    w = ops.pack_weight((torch.randn(Cout, Ct, 3, 3, generator=g) * (9 * Ct) ** -0.5).cuda(), torch.bfloat16)
+    bias = torch.randn(Cout, generator=g).cuda()
+    gamma, beta = (1 + 0.2 * torch.randn(Ct, generator=g)).cuda(), (0.2 * torch.randn(Ct, generator=g)).cuda()
+    temb = torch.randn(B, Cout, generator=g).cuda().to(torch.bfloat16) if use_temb else None
+    res = torch.randn(B, N, N, Cout, generator=g).cuda().to(torch.bfloat16) if use_res else None
+    stats = ops.gn_stats(x1, 32, x2=x2)
+    a_ref = ops.af_act(x1, x2, stats, gamma, beta, 32, 1e-6)
+    y_ref = ops.conv2d(a_ref, w, bias, temb=temb, temb_stride=Cout if use_temb else 0, residual=res, want_stats=True)
+    outs = [ops.af_act_conv2d(x1, x2, stats, gamma, beta, 32, 1e-6, w, bias, temb=temb, temb_stride=Cout if use_temb else 0,
+                              residual=res, want_stats=True) for _ in range(3)]
+    if B != 64 and outs[0] is None:
+        # batches whose convolution plan is not the one-tile-per-CU halo variant (64-pixel tiles of small batches, ...) have no
+        # merged kernel by design: the caller runs the two launches
+        assert all(o is None for o in outs)
+        return
+    assert all(o is not None for o in outs), "no merged kernel for a shape the UNet's 32^2 / 16^2 levels use"
+    # the chains conv -> act and act -> conv -> act (the activation BEHIND the convolution takes the statistics its epilogue writes)
+    g2, b2 = (1 + 0.2 * torch.randn(Cout, generator=g)).cuda(), (0.2 * torch.randn(Cout, generator=g)).cuda()
+    a2_ref = ops.af_act(y_ref, None, ops.gn_stats(y_ref, 32), g2, b2, 32, 1e-6)
+    kw = dict(temb=temb, temb_stride=Cout if use_temb else 0, residual=res, want_stats=True, post=(g2, b2, 32, 1e-6))
+    for got in (ops.act_conv_act(a_ref, None, None, w, bias, **kw), ops.act_conv_act(x1, x2, (stats, gamma, beta, 32, 1e-6), w, bias, **kw)):
+        assert got is not None
+        assert torch.equal(got[0], y_ref) and torch.equal(got[1], a2_ref) and torch.equal(got[0].gn_partial, y_ref.gn_partial)
+    # the general (placement-independent) hand-over on the same problem
+    from afldm_amd import _lib
+    _lib.lib.afldm_af_act_conv2d_mode(1)
+    try:
+        outs.append(ops.af_act_conv2d(x1, x2, stats, gamma, beta, 32, 1e-6, w, bias, temb=temb, temb_stride=Cout if use_temb else 0,
+                                      residual=res, want_stats=True))
+    finally:
+        _lib.lib.afldm_af_act_conv2d_mode(0)
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o.act_input, a_ref) and torch.equal(o, y_ref) and torch.equal(o.gn_partial, y_ref.gn_partial)
+    assert ops.actconv_error() == 0
+    # the no-normalisation form (stats = None) is the activation alone in front of the convolution
+    a0 = ops.af_act(x1, x2)
+    y0 = ops.conv2d(a0, w, bias)
+    o0 = ops.af_act_conv2d(x1, x2, None, None, None, 0, 0.0, w, bias)
+    assert o0 is not None and torch.equal(o0, y0) and torch.equal(o0.act_input, a0)
