@@ -95,6 +95,9 @@ def _load():
         "afldm_af_act_conv2d_merged": ([POINTER(AfActArgs), POINTER(ConvArgs)], c_int),
         "afldm_af_act_conv2d": ([POINTER(AfActArgs), POINTER(ConvArgs), vp], c_int),
         "afldm_af_act_conv2d_trace": ([vp], c_int),
+        "afldm_trunk_phase_bytes": ([], c_int),
+        "afldm_trunk_trace": ([vp], c_int),
+        "afldm_trunk_run": ([vp, ip, vp, vp, vp, ip, vp, vp, vp, c_size_t, vp], c_int),
         "afldm_act_conv_act_merged": ([POINTER(AfActArgs), POINTER(ConvArgs), POINTER(AfActArgs)], c_int),
         "afldm_act_conv_act": ([POINTER(AfActArgs), POINTER(ConvArgs), POINTER(AfActArgs), vp, vp], c_int),
         "afldm_af_act_conv2d_mode": ([ip], c_int),

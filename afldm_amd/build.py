@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(OUT_DIR, "libafldm_hip.so")
-SOURCES = ["api.hip", "misc.hip", "gn.hip", "af.hip", "sep.hip", "conv.hip", "conv3h.hip", "actconv.hip", "attn.hip", "attnf.hip", "fir.hip", "lin.hip", "skinny.hip", "convout.hip"]
+SOURCES = ["api.hip", "misc.hip", "gn.hip", "af.hip", "sep.hip", "conv.hip", "conv3h.hip", "actconv.hip", "trunk.hip", "attn.hip", "attnf.hip", "fir.hip", "lin.hip", "skinny.hip", "convout.hip"]
 ARCH = "gfx950"
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # Kernels whose MFMA accumulators are post-processed by VALU code (softmax, SiLU, GroupNorm affine):

@@ -12,7 +12,7 @@ from dataclasses import dataclass
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, trunk
 from ..configs import FrozenConfig
 from . import blocks as B
 
@@ -202,11 +202,25 @@ class UNet2DModel(nn.Module):
 
         h = B.conv_forward(self.conv_in, x, want_stats=True)
         skips = (h,)
-        for blk in self.down_blocks:
+        up_blocks = list(self.up_blocks)
+        for bi, blk in enumerate(self.down_blocks):
+            if bi == len(self.down_blocks) - 1 and trunk.eligible(self, h):
+                # the 2x2 level (this block, the mid block, the resnets of up_blocks[0]) as ONE cooperative launch
+                first, ups = self.down_blocks[-1], up_blocks[0]
+                n_lvl = len(first.resnets) + len(self.mid_block.resnets) + len(ups.resnets)
+                sl = take(n_lvl)
+                tr = trunk.get(self, h, self._temb_weights(self.dtype)[2])
+                skips = skips[:-1]                                # the level's input is the skip its last resnet consumes
+                h = tr.run(h, sl[0][0].data_ptr(), sl[0][1])
+                for u in (ups.upsamplers or ()):
+                    h = u(h)
+                up_blocks = up_blocks[1:]
+                break
             h, outs = blk(h, take(len(blk.resnets)))
             skips += outs
-        h = self.mid_block(h, take(len(self.mid_block.resnets)))
-        for blk in self.up_blocks:
+        else:
+            h = self.mid_block(h, take(len(self.mid_block.resnets)))
+        for blk in up_blocks:
             n = len(blk.resnets)
             res, skips = skips[-n:], skips[:-n]
             h = blk(h, res, take(n))

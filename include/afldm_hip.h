@@ -336,6 +336,21 @@ int afldm_act_conv_act_merged(const afldm_af_act_args* pre, const afldm_conv_arg
 int afldm_act_conv_act(const afldm_af_act_args* pre, const afldm_conv_args* conv, const afldm_af_act_args* post, void* post_y,
                        afldm_stream_t stream);
 
+/* ---- the 2x2 level of the UNet as ONE cooperative launch ------------------------------------------
+ * diffusers UNet2DModel.forward over down_blocks[-1] -> mid_block -> the resnets of up_blocks[0] (reference
+ * configs/ldm/model_unet.json after the surgery of af_api.py:70-83): 7 ResnetBlock2D + the mid block's self-attention on
+ * 2 x 2 planes, bf16 (csrc/trunk.hip).  One persistent workgroup per CU walks `phases` - an array of `nphases` records of
+ * afldm_trunk_phase_bytes() bytes each, written by the host mirror (afldm_amd/trunk.py: GEMM partial products on 192 x 192
+ * weight blocks / slab reduction + bias + time embedding + residual + GroupNorm + WarpedNonlinearity / 4-token attention) -
+ * with a grid barrier between phases.  x_in / y_out [B,2,2,C] are the level's input and output, temb the step's
+ * time-embedding row(s) at the level's first resnet (temb_stride elements between samples, 0 = shared); U [4x2], D [2x4] the
+ * N = 2 filter matrices.  sync: >= 32832 bytes, zero between launches (words 8200 / 8201; word 8193 = 3 when a barrier
+ * timed out).  Every workgroup must be resident at once: the launch needs the GPU to itself (one such launch at a time). */
+int afldm_trunk_phase_bytes(void);
+int afldm_trunk_trace(void* buf);      /* diagnostic: [nphases][2] 64-bit s_memtime stamps of workgroup 0 (phase start, barrier passed) */
+int afldm_trunk_run(const void* phases, int nphases, const void* x_in, void* y_out, const void* temb, int temb_stride,
+                    const float* U, const float* D, unsigned int* sync, size_t sync_bytes, afldm_stream_t stream);
+
 /* ---- attention ---------------------------------------------------------------------------
  * F.scaled_dot_product_attention as called by AttnProcessor2_0 / CrossFrameAttnProcessor
  * (cross_frame_attn.py:125,128): o = softmax(q k^T * scale) v per (batch, head).

@@ -174,3 +174,29 @@ def test_af_act_conv2d_merged_launch_bit_identical_to_two_launches(case):
     y0 = ops.conv2d(a0, w, bias)
     o0 = ops.af_act_conv2d(x1, x2, None, None, None, 0, 0.0, w, bias)
     assert o0 is not None and torch.equal(o0, y0) and torch.equal(o0.act_input, a0)
+
+
+# ------------------------------------------------------------------------------------------------ cooperative 2x2 level
+@pytest.mark.parametrize("B", [1, 8, 64])
+def test_cooperative_2x2_level_vs_separate_launches_and_oracle(golden, B, monkeypatch):
+    """afldm_trunk_run (csrc/trunk.hip + afldm_amd/trunk.py): down_blocks[-1] -> mid_block -> up_blocks[0].resnets of the FFHQ AF-UNet
+    as ONE cooperative launch (opt-in: it measured slower, profiles/r05/trunk_coop.txt) against the 51 separate launches of the
+    same level and against the oracle fixture: finite, bit-identical reruns, no barrier time-out, bf16 forward tolerance."""
+    from afldm_amd import ops, trunk
+    g = golden("g6_ffhq_unet.npz")
+    unet, _, _ = build_unet("ffhq", torch.bfloat16)
+    x = torch.randn(B, 4, 32, 32, generator=torch.Generator().manual_seed(40 + B))
+    x[0] = torch.from_numpy(g["x"])[0]
+    x = x.cuda()
+    monkeypatch.setattr(trunk, "_ENABLED", False)
+    y_sep = unet(x, 981).sample
+    monkeypatch.setattr(trunk, "_ENABLED", True)
+    assert trunk.eligible(unet, torch.empty(B, 2, 2, 768, dtype=torch.bfloat16, device="cuda"))
+    y1 = unet(x, 981).sample
+    y2 = unet(x, 981).sample
+    torch.cuda.synchronize()
+    assert torch.isfinite(y1).all() and torch.equal(y1, y2) and ops.actconv_error() == 0
+    r_sep, r_orc = rel_rms(y1.float(), y_sep.float().cpu()), rel_rms(y1[:1].float(), g["y_t981"])
+    print(f"[cooperative 2x2 level] B={B}: vs separate launches {r_sep:.3e}, sample 0 vs oracle fixture {r_orc:.3e} "
+          f"(separate launches: {rel_rms(y_sep[:1].float(), g['y_t981']):.3e})")
+    assert r_sep <= 2e-2 and r_orc <= 2e-2
