@@ -146,6 +146,15 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
       p.trace[(((size_t)blockIdx.x * CF::NW + wave) * 2 + (item - item_first)) * 10 + i] = __builtin_amdgcn_s_memtime();
   };
   stamp(0);
+  if (p.stagger > 0) {
+    // A/B: co-resident workgroups start their item loops `slot` x stagger x 64 clocks apart, so that one
+    // stages / stores while another runs its passes.  slot = the wave's slot on its SIMD (HW_ID bits 3:0): the three (N = 32) /
+    // four (N = 16) four-wave workgroups of a CU sit in consecutive slots.
+    int hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    const int slot = hwid & 15;
+    for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+  }
 
   // ---- GroupNorm scale / shift of an item's CH channels, buffered for two items (gscb / gshb[buf]).
   // One wave per group touched by the item's channels (usually 2-4): the cpg x S per-channel partial sums strided over
@@ -1305,6 +1314,8 @@ static int af_act_dispatch(const void* x1, int C1, const void* x2, int C2, const
   p.x1 = (const T*)x1; p.x2 = (const T*)x2; p.gs = gs; p.gamma = gamma; p.beta = beta;
   p.U = U; p.D = D; p.y = (T*)y; p.C1 = C1; p.C2 = C2; p.G = G; p.B = B;
   p.trace = g_af_trace;
+  static const int s_stagger = getenv("AFLDM_AF_STAGGER") ? atoi(getenv("AFLDM_AF_STAGGER")) : 0;
+  p.stagger = s_stagger;
   // bit mask 4 / 8: plane sizes run on the VALU kernel instead of the Kronecker MFMA kernel.  N = 4 (default): one thread
   // per plane with the loop over the upsampled rows fully unrolled (all 64 coefficients in SGPRs) beats the MFMA form,
   // whose workgroups each stage a 64 KB constant image: 5.251 -> 5.229 ms/step (same box).  N = 8 needs 256 coefficients

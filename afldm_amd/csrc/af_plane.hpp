@@ -19,6 +19,7 @@ struct AfP {
   int C1, C2, G, B;
   float eps;
   unsigned long long* trace;   // diagnostic (k_af_act_plane): [workgroup][wave][item 0 / 1][10] s_memtime stamps, or NULL
+  int stagger;                 // A/B (AFLDM_AF_STAGGER): s_sleep units (64 clocks) per co-residency slot a workgroup waits before its first item
 };
 
 template <typename T>

@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""FETCH_SIZE calibration (tools/proto/fetch_calib.hip).  Run under the profiler:
+"""FETCH_SIZE / WRITE_SIZE calibration (tools/proto/fetch_calib.hip).  WRITE side (round 5): FC_WRITE=1 under
+   rocprofv3 --kernel-trace --pmc WRITE_SIZE (and, in a second pass, --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum).
+Run under the profiler:
    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/fcal -o fc -- python tools/proto/run_fetch_calib.py
 then `python tools/proto/run_fetch_calib.py report gpurun_out/fcal` prints counter bytes / true bytes per access width."""
 import ctypes, csv, glob, os, subprocess, sys
@@ -9,15 +11,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "report":
     true = P * ROW
     lines = []
     unit = {"FETCH_SIZE": 1024.0, "TCC_MISS_sum": 128.0, "TCC_EA0_RDREQ_sum": 64.0, "TCC_EA0_RDREQ_32B_sum": 32.0, "TCC_BUBBLE_sum": 128.0,
-            "TCC_REQ_sum": 128.0, "TCC_HIT_sum": 128.0}
+            "TCC_REQ_sum": 128.0, "TCC_HIT_sum": 128.0, "WRITE_SIZE": 1024.0, "TCC_EA0_WRREQ_sum": 64.0, "TCC_EA0_WRREQ_64B_sum": 64.0}
     for f in glob.glob(sys.argv[2] + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             n = r["Kernel_Name"]
-            if ("k_pieces" in n or "k_stream" in n) and r["Counter_Name"] in unit:
+            if ("k_pieces" in n or "k_stream" in n or "k_wpieces" in n or "k_wstream" in n) and r["Counter_Name"] in unit:
                 v = float(r["Counter_Value"])
-                lines.append(f"{n[:32]:32s} {r['Counter_Name']:22s} x {unit[r['Counter_Name']]:6.0f} B / true bytes = {v * unit[r['Counter_Name']] / true:.3f}")
+                lines.append(f"{n[:44]:44s} {r['Counter_Name']:22s} x {unit[r['Counter_Name']]:6.0f} B / true bytes = {v * unit[r['Counter_Name']] / true:.3f}")
     print("\n".join(lines))
-    open("gpurun_out/fetch_calib.txt", "w").write("\n".join(lines) + "\n")
+    open(os.environ.get("FC_OUT", "gpurun_out/fetch_calib.txt"), "w").write("\n".join(lines) + "\n")
     sys.exit(0)
 import torch
 SO = os.path.join(HERE, "libfetch_calib.so")
@@ -28,6 +30,16 @@ x = torch.randint(0, 2 ** 31 - 1, (P * ROW // 4,), dtype=torch.int32, device="cu
 junk = torch.randint(0, 2 ** 31 - 1, (P * ROW // 4,), dtype=torch.int32, device="cuda")      # evicts the caches between modes
 out = torch.zeros(4, dtype=torch.int32, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
+if os.environ.get("FC_WRITE"):
+    lib.fc_wrun.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
+    for sc1 in (0, 1):
+        for mode in (0, 128, 64, 32, 16):
+            junk.add_(1)
+            torch.cuda.synchronize()
+            assert lib.fc_wrun(x.data_ptr(), mode, sc1, P, ROW, st) == 0
+            torch.cuda.synchronize()
+    print("done (write)")
+    sys.exit(0)
 for mode in (0, 128, 64, 32, 16, 0, 32):
     junk.add_(1)
     torch.cuda.synchronize()
