@@ -1271,6 +1271,9 @@ static int launch_af_mfma(const AfP<T>& p, hipStream_t st) {
   // (8-channel items read 16-byte pieces of every pixel: only worth it while the tensor stays
   //  cache-resident between the two item passes over a line - measured 1.15x slower per round at 75 MB)
   const size_t bytes = (size_t)p.B * N * N * Ct * sizeof(T);
+  static const int s_ch = getenv("AFLDM_AF_CH") ? atoi(getenv("AFLDM_AF_CH")) : 0;      // A/B: force the item size (8 / 16)
+  if (s_ch == 8 && p.C1 % 8 == 0) return launch_af_plane<T, N, 8>(p, cus, st);
+  if (s_ch == 16) return launch_af_plane<T, N, 16>(p, cus, st);
   if (t8 < t16 && p.C1 % 8 == 0 && bytes <= (40u << 20)) return launch_af_plane<T, N, 8>(p, cus, st);
   return launch_af_plane<T, N, 16>(p, cus, st);
 }

@@ -1609,6 +1609,8 @@ static const Variant kVariants[] = {
     {128, 192, 6, 3},  // 64  32x32 planes, 4 rows x 192 couts per tile, persistent workgroups (two tiles per CU at batch 64)
     {64, 96, 6, 3},    // 65  32x32 planes, 2 rows x 96 couts per tile (small batches)
     {64, 96, 6, 3},    // 66  16x16 planes, 4 rows x 96 couts per tile (small batches)
+    {128, 48, 6, 3},   // 67  8x8 planes: TWO samples x 48 couts per tile (half the weight bytes per workgroup of 51; round 5)
+    {128, 48, 6, 3},   // 68  4x4 planes: EIGHT samples x 48 couts per tile
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -1658,7 +1660,7 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
     if (kVariants[v].ver == 6) {
       // halo-patch kernel: the small-tile variants (51+) may split the CHANNEL BLOCKS over up to 4 slices when the
       // tiles alone leave most CUs idle; the slice count must divide the number of 128-byte channel blocks
-      if (v < 51 || (v >= 57 && v != 65 && v != 66)) return 1;
+      if (v < 51 || (v >= 57 && v != 65 && v != 66 && v != 67 && v != 68)) return 1;
       const int ncb = Ct / (2 * elems_per_row);
       int z = 1;
       static const int s_zmax = getenv("AFLDM_CONV3H_ZMAX") ? atoi(getenv("AFLDM_CONV3H_ZMAX")) : 8;      // (4 -> 8: batch 8 2.410 -> 2.378, batch 1 2.158 -> 2.134 ms/step, same box)
@@ -1720,6 +1722,12 @@ static Plan make_plan(const afldm_conv_args* a, int elems_per_row) {
         else if (a->W == 8 && M >= 64) vid = 51;
         else if (a->W == 4 && M >= 64) vid = 52;
       }
+      // long K at full batch: 128-pixel x 48-cout tiles (67 / 68) stream half the weight bytes per workgroup - bit-identical,
+      // 26.0 vs 28.4 us (768 -> 384), 36.0 vs 41.3 (1152 -> 384), 48.9 vs 56.0 (768 -> 768) at 8^2; 30.3 vs 32.9 (1536 -> 768) at 4^2;
+      // nothing for the 384-channel layers (profiles/r05/conv_small_tiles_ab.txt).  AFLDM_CONV3H_NARROW=0: off (A/B)
+      static const int s_narrow = getenv("AFLDM_CONV3H_NARROW") ? atoi(getenv("AFLDM_CONV3H_NARROW")) : 1;
+      if (s_narrow && bf && vid == 51 && M >= 4096 && M % 128 == 0 && Ct >= 768 && a->Cout % 48 == 0) vid = 67;
+      if (s_narrow && bf && vid == 52 && M >= 1024 && M % 128 == 0 && Ct >= 1152 && a->Cout % 48 == 0) vid = 68;
     }
   }
   {

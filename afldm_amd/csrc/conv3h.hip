@@ -449,6 +449,11 @@ static const H3Variant kH3[] = {
     // Small batches (round 4): 64-pixel tiles, so that batch 8 still gives every CU a workgroup at the 32^2 / 16^2 levels
     {64, 32, 96, 2, 2, 16, 3},        // 65: 32x32 planes, 2 rows x 96 couts, 3 taps per step
     {64, 16, 96, 2, 2, 16, 3},        // 66: 16x16 planes, 4 rows x 96 couts
+    // Fewer weight bytes per workgroup at the low levels (round 5): the 8^2 / 4^2 convolutions are bound by the ~100 GB/s a CU pulls
+    // through LDS-DMA (741 KB per workgroup and launch, profiles/r02/small_tile_step_decomposition.txt); 128-pixel x 48-cout tiles
+    // stream half the weights and twice the (small) patch: 91 instead of 128 KB per channel block
+    {128, 8, 48, 4, 1, 16, 3},        // 67: 8x8 planes, two samples x 48 couts
+    {128, 4, 48, 4, 1, 16, 3},        // 68: 4x4 planes, eight samples x 48 couts
 };
 constexpr int kNumH3 = (int)(sizeof(kH3) / sizeof(kH3[0]));
 
@@ -575,6 +580,8 @@ void conv3h_launch(int variant, int dtype_size, const ConvP& p, hipStream_t st) 
   if (k == 23) { launch_h3_pers<128, 32, 192, 2, 2, false>(p, st); return; }
   if (k == 24) { launch_h3<bf16, 64, 32, 96, 2, 2, 16, 3>(p, st); return; }
   if (k == 25) { launch_h3<bf16, 64, 16, 96, 2, 2, 16, 3>(p, st); return; }
+  if (k == 26) { launch_h3<bf16, 128, 8, 48, 4, 1, 16, 3, 3, false, 2>(p, st); return; }
+  if (k == 27) { launch_h3<bf16, 128, 4, 48, 4, 1, 16, 3, 3, false, 2>(p, st); return; }
   if (dtype_size == 2) launch_h3_variant<bf16>(k, p, st);
   else launch_h3_variant<float>(k, p, st);
 }
