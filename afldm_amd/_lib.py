@@ -25,6 +25,7 @@ class ConvArgs(Structure):
         ("out_mode", c_int), ("dtype", c_int), ("y2", c_void_p), ("split_n", c_int),
         ("stats_out", c_void_p), ("temb_mod", c_int), ("sync", c_void_p), ("sync_bytes", c_size_t),
         ("defer_reduce", c_int), ("w_batch_stride", ctypes.c_longlong),
+        ("y_norm", c_void_p), ("norm_gamma", c_void_p), ("norm_beta", c_void_p), ("norm_groups", c_int), ("norm_eps", c_float),
     ]
 
 
@@ -92,6 +93,7 @@ def _load():
         "afldm_conv2d_tune": ([ip, ip], c_int),
         "afldm_conv2d_fused_splitk": ([ip], c_int),
         "afldm_conv2d_variant": ([POINTER(ConvArgs)], c_int),
+        "afldm_conv2d_norm_ok": ([POINTER(ConvArgs)], c_int),
         "afldm_af_act_conv2d_merged": ([POINTER(AfActArgs), POINTER(ConvArgs)], c_int),
         "afldm_af_act_conv2d": ([POINTER(AfActArgs), POINTER(ConvArgs), vp], c_int),
         "afldm_af_act_conv2d_trace": ([vp], c_int),

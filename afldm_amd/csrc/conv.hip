@@ -2045,6 +2045,18 @@ static int stats_mode(const afldm_conv_args* a, const Exec& e, int* S) {
 
 extern "C" int afldm_gn_stats(const void* x, int C, float* stats, int B, int HW, int dtype, afldm_stream_t stream);
 
+// the epilogue of a halo-patch tile that is one whole 8x8 sample x 96 couts (variant 51, bf16, whole K, statistics from the
+// epilogue) can apply the GroupNorm that follows: its couts must be whole groups
+template <typename T>
+static bool norm_fusable(const afldm_conv_args* a, const Exec& e, int smode) {
+  if (sizeof(T) != 2 || e.pl.kind != 0 || e.splitk != 1 || smode != ST_EPILOGUE || !a->stats_out) return false;
+  if (e.vid != 51 && e.vid != 53) return false;
+  if (a->H != 8 || a->W != 8 || a->out_mode != 0 || a->y2 || a->y_ld != a->Cout) return false;
+  if (a->norm_groups <= 0 || a->Cout % a->norm_groups || !a->norm_gamma || !a->norm_beta) return false;
+  const int cpg = a->Cout / a->norm_groups;
+  return 96 % cpg == 0;
+}
+
 // the argument block of every GEMM-path kernel, from the caller's arguments (plan-independent part)
 template <typename T>
 static void fill_convp(const afldm_conv_args* a, ConvP& p) {
@@ -2080,6 +2092,7 @@ static void fill_convp(const afldm_conv_args* a, ConvP& p) {
     p.m_fast = s_mfast >= 0 ? s_mfast : ((long long)a->Cout * a->KS * a->KS > (long long)p.M ? 1 : 0);
   }
   p.xcd_gn = 0;
+  p.y_norm = nullptr; p.ngamma = nullptr; p.nbeta = nullptr; p.ncpg = 1; p.neps = 0.f;
 }
 
 template <typename T>
@@ -2135,6 +2148,11 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
     }
     p.sync = ex.fused ? a->sync : nullptr;
     if (ex.fused && smode == ST_FUSED) p.stats_out = a->stats_out;
+    if (a->y_norm) {
+      AFLDM_REQUIRE(norm_fusable<T>(a, ex, smode), AFLDM_ESHAPE, "afldm_conv2d: y_norm given but this problem's epilogue cannot apply the GroupNorm (afldm_conv2d_norm_ok)");
+      p.y_norm = a->y_norm; p.ngamma = a->norm_gamma; p.nbeta = a->norm_beta;
+      p.ncpg = a->Cout / a->norm_groups; p.neps = a->norm_eps;
+    }
     if (a->w_batch_stride) {      // per-sample weights: the LDS-DMA GEMM only, whole tiles inside a sample, K not split
       const int ver = kVariants[ex.vid].ver;
       AFLDM_REQUIRE(ver >= 2 && ver <= 4 && p.splitk == 1 && (a->H * a->W) % kVariants[ex.vid].bm == 0, AFLDM_ESHAPE,
@@ -2277,6 +2295,15 @@ extern "C" int afldm_conv2d_variant(const afldm_conv_args* a0) {
   if (skinny_stats_splits(a)) return -16;        // skinny.hip
   if (e.pl.kind != 0) return -1 - e.pl.kind;
   return e.vid | (e.splitk << 8) | (e.fused << 16);
+}
+
+extern "C" int afldm_conv2d_norm_ok(const afldm_conv_args* a) {
+  if (!a || a->dtype != AFLDM_BF16 || conv_batch_chunk(a) != a->B || !a->stats_out) return 0;
+  if (lin_wreg_bm(a) || skinny_stats_splits(a)) return 0;
+  const Exec e = resolve_exec<bf16>(a);
+  int S = 0;
+  const int smode = stats_mode<bf16>(a, e, &S);
+  return norm_fusable<bf16>(a, e, smode) ? 1 : 0;
 }
 
 extern "C" int afldm_conv2d_stats_splits(const afldm_conv_args* a0) {

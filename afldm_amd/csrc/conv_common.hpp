@@ -34,6 +34,13 @@ struct ConvP {
   int xcd_gn;    // conv3h tile order: the XCDs as a (8 / xcd_gn) x xcd_gn grid over (m, n) tiles; 0 = contiguous runs, n fastest
   unsigned* sync;   // in-kernel split-K reduction: 2 zero-initialised words per output tile (arrivals, departures), or NULL
   long long w_bstride;   // elements between the weight tensors of consecutive samples (0: shared weights); k_igemm2 only
+  // the NEXT GroupNorm applied by the epilogue of a halo-patch tile that holds a whole sample (8x8 planes): y_norm [M][Cout] =
+  // GroupNorm(y) with this tile's own statistics (groups of ncpg channels inside the tile's couts), or NULL
+  void* y_norm;
+  const float* ngamma;
+  const float* nbeta;
+  int ncpg;
+  float neps;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;

@@ -390,6 +390,14 @@ class ResnetBlock2D(nn.Module):
             out = self._conv2_to_next_norm_fused(h, res, next_gn)
             if out is not None:
                 return out
+            # 8x8 planes: the attention block's GroupNorm from the epilogue of conv2 itself (one tile = one whole sample)
+            gamma, beta = packed_norm(next_gn)
+            out = conv_forward(self.conv2, h, residual=res, want_stats=True,
+                               norm_out=(gamma, beta, next_gn.num_groups, next_gn.eps))
+            hn = getattr(out, "norm_applied", None)
+            if hn is not None:
+                out.gn_applied = (hn, next_gn)
+            return out
         return conv_forward(self.conv2, h, residual=res, want_stats=True)
 
 

@@ -710,8 +710,11 @@ def conv_args(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None
     return a
 
 
+_CONV_NORM = os.environ.get("AFLDM_NO_CONV_NORM", "0") != "1"
+
+
 def conv2d(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, out=None, out_mode=0,
-           workspace=None, want_stats=False, temb_mod=0, w_batch_stride=0):
+           workspace=None, want_stats=False, temb_mod=0, w_batch_stride=0, norm_out=None):
     """stride-1 'same' conv (KS in {1,3}) / linear on NHWC input with packed OHWI weights.
     out_mode 1 returns the channel-major [B, Cout, H*W] tensor (V^T for attention).
     want_stats: also emit the per-channel GroupNorm partial sums of the output (from the GEMM
@@ -737,8 +740,21 @@ def conv2d(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, o
         S = lib.afldm_conv2d_stats_splits(ctypes.byref(a))
         st = torch.empty((a.B, S, Cout, 2), dtype=torch.float32, device=x1.device)
         a.stats_out = ptr(st)
+    hn = None
+    if norm_out is not None and _CONV_NORM and st is not None:
+        # norm_out = (gamma, beta, G, eps) of the GroupNorm that consumes this output next: applied by the convolution's own
+        # epilogue where a tile holds a whole sample and whole groups (afldm_conv2d_norm_ok); the result rides on the output
+        # as `.norm_applied`
+        gamma, beta, G, eps = norm_out
+        a.norm_gamma, a.norm_beta, a.norm_groups, a.norm_eps = ptr(gamma), ptr(beta), int(G), float(eps)
+        if lib.afldm_conv2d_norm_ok(ctypes.byref(a)):
+            hn = torch.empty_like(out)
+            a.y_norm = ptr(hn)
+            a.keep = a.keep + (hn, gamma, beta)
     tok = _begin()
     check(lib.afldm_conv2d(ctypes.byref(a), stream_ptr()), "conv2d")
+    if hn is not None:
+        out.norm_applied = hn
     if st is not None:
         if st.shape[1] > _MAX_SPLITS and st.shape[1] % _MAX_SPLITS == 0:
             # one split per 128-pixel tile is 512 per sample on a 256^2 plane: fold before the consumers walk them

@@ -270,8 +270,19 @@ typedef struct {
    * GEMM of the AF-VAE's single-head d = 512 attention (af_vae.py / diffusers AttnProcessor2_0): scores = Q_b K_b^T with K_b as
    * the weights, then P_b V_b with V_b^T as the weights - one launch for the batch instead of one per sample. */
   long long w_batch_stride;
+  /* optional: the GroupNorm that FOLLOWS this convolution (diffusers Attention.group_norm behind ResnetBlock2D.conv2), applied by the
+   * convolution's own epilogue where one tile holds a whole sample and whole groups (8x8 planes, bf16): y_norm [B*H*W][Cout] =
+   * (y - mean_g) rstd_g gamma + beta with the statistics of the stored (rounded) y; y itself is written as usual.  Only honoured when
+   * afldm_conv2d_norm_ok(args) == 1 (set y_norm = NULL otherwise and run afldm_gn_apply). */
+  void* y_norm;
+  const float* norm_gamma;
+  const float* norm_beta;
+  int norm_groups;
+  float norm_eps;
 } afldm_conv_args;
 int afldm_conv2d(const afldm_conv_args* args, afldm_stream_t stream);
+/* 1: afldm_conv2d(args) will apply the GroupNorm described by norm_gamma / norm_beta / norm_groups / norm_eps into y_norm itself. */
+int afldm_conv2d_norm_ok(const afldm_conv_args* args);
 /* Tuning hook (benchmarks only): force tile/pipeline variant `variant` (>= 0) and/or a split-K
  * factor (>= 1) for subsequent afldm_conv2d calls; -1 restores the automatic choice. */
 int afldm_conv2d_tune(int variant, int splitk);

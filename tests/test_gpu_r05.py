@@ -200,3 +200,30 @@ def test_cooperative_2x2_level_vs_separate_launches_and_oracle(golden, B, monkey
     print(f"[cooperative 2x2 level] B={B}: vs separate launches {r_sep:.3e}, sample 0 vs oracle fixture {r_orc:.3e} "
           f"(separate launches: {rel_rms(y_sep[:1].float(), g['y_t981']):.3e})")
     assert r_sep <= 2e-2 and r_orc <= 2e-2
+
+
+def test_conv2_epilogue_applies_the_attention_groupnorm_at_8x8(golden, monkeypatch):
+    """afldm_conv_args.y_norm: at the 8x8 level one halo tile is a whole sample x whole groups, so conv2's epilogue applies the
+    GroupNorm of the attention block behind it (diffusers Attention.group_norm) instead of a stand-alone afldm_gn_apply launch:
+    same UNet output as the separate launch, five
+    launches fewer per forward, fixture tolerance kept."""
+    from afldm_amd import ops
+    g = golden("g6_ffhq_unet.npz")
+    unet, _, _ = build_unet("ffhq", torch.bfloat16)
+    x = torch.randn(64, 4, 32, 32, generator=torch.Generator().manual_seed(77))      # (full batch: small batches split K at 8x8)
+    x[0] = torch.from_numpy(g["x"])[0]
+    x = x.cuda()
+    calls = []
+    real = ops.gn_apply
+    monkeypatch.setattr(ops, "gn_apply", lambda *a, **k: (calls.append(tuple(a[0].shape)), real(*a, **k))[1])
+    monkeypatch.setattr(ops, "_CONV_NORM", False)
+    y_sep = unet(x, 981).sample
+    n_sep = len(calls)
+    monkeypatch.setattr(ops, "_CONV_NORM", True)
+    del calls[:]
+    y_fus = unet(x, 981).sample
+    n_fus = len(calls)
+    r = rel_rms(y_fus.float(), y_sep.float().cpu())
+    print(f"[conv2 -> attention GroupNorm in the epilogue] gn_apply launches {n_sep} -> {n_fus}; fused vs separate rel-RMS {r:.3e}; "
+          f"vs oracle fixture {rel_rms(y_fus[:1].float(), g['y_t981']):.3e}")
+    assert n_sep - n_fus == 5 and r <= 2e-3 and rel_rms(y_fus[:1].float(), g["y_t981"]) <= 2e-2
