@@ -1344,10 +1344,104 @@ static int af_act_dispatch(const void* x1, int C1, const void* x2, int C2, const
   return AFLDM_ESHAPE;
 }
 
+// y = M x M^T per (sample, channel) plane for the SMALL resampling sites (2 <-> 4, 4 <-> 8, 8 <-> 16) in ONE launch (round 5):
+// one thread per plane, lanes = channels (the coefficients are wave-uniform scalar operands).  Exactly the two passes of
+// k_axis_contract_reg - H first into an fp32 intermediate, then W, every sum an fmaf chain over ascending k from 0 - with
+// the intermediate in registers instead of an fp32 tensor in memory and a second launch: bit-identical results and
+// statistics (one split per output row).  A <= 8: the plane lives in registers, output row by output row; A = 16 (-> 8): the
+// output accumulates column by column (64 accumulators) - correct but 3x slower than the two passes (128 coefficients do not fit the
+// scalar registers), not dispatched.
+template <typename T, int A, int R>
+__global__ void __launch_bounds__(256) k_resample_small(const T* __restrict__ in, T* __restrict__ out, const float* __restrict__ M,
+                                                        int B, int C, float* __restrict__ stats) {
+  const size_t total = (size_t)B * C;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int b = (int)(i / C), c = (int)(i - (size_t)b * C);
+  const T* xp = in + (size_t)b * A * A * C + c;
+  T* yp = out + (size_t)b * R * R * C + c;
+  if constexpr (A <= 8) {
+    float x[A][A];
+#pragma unroll
+    for (int h = 0; h < A; ++h)
+#pragma unroll
+      for (int w = 0; w < A; ++w) x[h][w] = to_f32(xp[(size_t)(h * A + w) * C]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float t[A];
+#pragma unroll
+      for (int w = 0; w < A; ++w) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < A; ++k) a = fmaf(M[r * A + k], x[k][w], a);
+        t[w] = a;
+      }
+      float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+      for (int s_ = 0; s_ < R; ++s_) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < A; ++k) a = fmaf(M[s_ * A + k], t[k], a);
+        const T o = from_f32<T>(a);
+        yp[(size_t)(r * R + s_) * C] = o;
+        const float q = to_f32(o);
+        p1 += q;
+        p2 = fmaf(q, q, p2);
+      }
+      if (stats) *reinterpret_cast<f32x2*>(stats + (((size_t)b * R + r) * C + c) * 2) = f32x2{p1, p2};
+    }
+  } else {
+    float yacc[R][R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int s_ = 0; s_ < R; ++s_) yacc[r][s_] = 0.f;
+#pragma unroll 2
+    for (int w = 0; w < A; ++w) {
+      float xc[A];
+#pragma unroll
+      for (int h = 0; h < A; ++h) xc[h] = to_f32(xp[(size_t)(h * A + w) * C]);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < A; ++k) a = fmaf(M[r * A + k], xc[k], a);
+#pragma unroll
+        for (int s_ = 0; s_ < R; ++s_) yacc[r][s_] = fmaf(M[s_ * A + w], a, yacc[r][s_]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+      for (int s_ = 0; s_ < R; ++s_) {
+        const T o = from_f32<T>(yacc[r][s_]);
+        yp[(size_t)(r * R + s_) * C] = o;
+        const float q = to_f32(o);
+        p1 += q;
+        p2 = fmaf(q, q, p2);
+      }
+      if (stats) *reinterpret_cast<f32x2*>(stats + (((size_t)b * R + r) * C + c) * 2) = f32x2{p1, p2};
+    }
+  }
+}
+
 template <typename T>
 static int resample_dispatch(const void* x, const float* M, void* y, float* ws, int B, int N, int C, int Rout,
                              hipStream_t st, float* stats = nullptr) {
   // pass 1 contracts H into the fp32 workspace [B][Rout][N][C]; pass 2 contracts W
+  {
+    // the small sites in one launch (k_resample_small; AFLDM_NO_RESAMPLE_SMALL=1: the two-pass form, for A/B)
+    static const bool s_off = getenv("AFLDM_NO_RESAMPLE_SMALL") && atoi(getenv("AFLDM_NO_RESAMPLE_SMALL")) != 0;
+    const int grid = (int)(((size_t)B * C + 255) / 256);
+#define AFLDM_RSS(A_, R_)                                                                                     \
+  if (!s_off && N == A_ && Rout == R_) {                                                                      \
+    k_resample_small<T, A_, R_><<<grid, 256, 0, st>>>((const T*)x, (T*)y, M, B, C, stats);                    \
+    return check_launch("afldm_af_resample(small)");                                                          \
+  }
+    AFLDM_RSS(2, 4) AFLDM_RSS(4, 8) AFLDM_RSS(8, 16) AFLDM_RSS(4, 2) AFLDM_RSS(8, 4)      // (16 -> 8 measured 3x SLOWER this way: 47.6 vs 14.7 us)
+#undef AFLDM_RSS
+  }
   if (C % 4 == 0 && (Rout == 2 * N || 2 * Rout == N) && N >= 2 && N <= 32 && (N & (N - 1)) == 0) {
     const size_t t1 = (size_t)B * N * (C / 4), t2 = (size_t)B * Rout * (C / 4);
     const int g1 = (int)((t1 + 255) / 256 < 8192 ? (t1 + 255) / 256 : 8192);
