@@ -105,6 +105,8 @@ def _load():
         "afldm_af_act_conv2d_mode": ([ip], c_int),
         "afldm_attention": ([vp, ip, vp, ip, vp, vp, ip, ip, ip, ip, ip, ip, ip, fp, ip, vp], c_int),
         "afldm_attn_block_fused_supported": ([ip, ip, ip, ip], c_int),
+        "afldm_attn_small_fused_supported": ([ip, ip, ip, ip], c_int),
+        "afldm_attn_small_fused": ([vp, vp, vp, vp, ip, ip, ip, ip, fp, ip, vp], c_int),
         "afldm_attn_block_fused_trace": ([vp], c_int),
         "afldm_af_act_trace": ([vp], c_int),
         "afldm_attn_block_fused": ([vp, vp, ip, vp, vp, ip, fp, vp, vp, vp, ip, ip, ip, ip, fp, ip, vp], c_int),

@@ -12,14 +12,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(OUT_DIR, "libafldm_hip.so")
-SOURCES = ["api.hip", "misc.hip", "gn.hip", "af.hip", "sep.hip", "conv.hip", "conv3h.hip", "actconv.hip", "trunk.hip", "attn.hip", "attnf.hip", "fir.hip", "lin.hip", "skinny.hip", "convout.hip"]
+SOURCES = ["api.hip", "misc.hip", "gn.hip", "af.hip", "sep.hip", "conv.hip", "conv3h.hip", "actconv.hip", "trunk.hip", "attn.hip", "attnf.hip", "attns.hip", "fir.hip", "lin.hip", "skinny.hip", "convout.hip"]
 ARCH = "gfx950"
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # Kernels whose MFMA accumulators are post-processed by VALU code (softmax, SiLU, GroupNorm affine):
 # keep the accumulators in architectural VGPRs.  By default the compiler parks them in AGPRs and
 # pays a v_accvgpr_read/write per element around every VALU use (144 of them per 64-key chunk of
 # the attention loop: as many cycles as the exponentials).  AFLDM_VGPR_FORM=all|none overrides.
-VGPR_FORM = {"attn.hip", "attnf.hip", "af.hip", "sep.hip"}       # (actconv.hip: A/B below)
+VGPR_FORM = {"attn.hip", "attnf.hip", "attns.hip", "af.hip", "sep.hip"}       # (actconv.hip: A/B below)
 VGPR_FORM_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 # Sources whose OUTPUT tensors are stored write-through (sc1: st16_out in common.hpp).  Measured in the step, same box
 # (profiles/r02/write_through_ab.txt): the convolution epilogues gain (nothing is left dirty in the XCD L2s for the

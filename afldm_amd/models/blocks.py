@@ -445,6 +445,11 @@ class AttnProcessor2_0:
             vt = linear_forward(attn.to_v, src, out_mode=1)
             o = ops.attention_dense(q, k, vt, attn.scale)
             return linear_forward(attn.to_out[0], o.view(B, H, W, C), residual=hidden_states, want_stats=True)
+        if encoder_hidden_states is None and ops.attn_small_fused_ok(tokens, attn.heads):
+            # 8^2 / 4^2 levels, bf16: projection + attention in ONE launch on the normalised tokens (csrc/attns.hip)
+            w, b = packed_qkv(attn, tokens.dtype, ("q", "k", "v"))
+            o = ops.attn_small_fused(tokens, w, b, attn.heads, attn.scale)
+            return linear_forward(attn.to_out[0], o.view(B, H, W, C), residual=hidden_states, want_stats=True)
         if encoder_hidden_states is None:
             # fused Q|K|V projection: one GEMM reads the normed tokens once; Q and K land token-major
             # side by side, V channel-major (the attention kernel's V^T operand)

@@ -1042,6 +1042,38 @@ def attn_block_fused(x, stats, gamma, beta, G, eps, w_qkv, bias_qkv, heads, scal
     return out
 
 
+_ATTN_SMALL = os.environ.get("AFLDM_NO_ATTN_SMALL", "0") != "1"
+# token counts the policy sends to the fused small-plane launch.  EMPTY by default: correct (tests) but not faster in the step -
+# 4.662 / 4.665 ms without, 4.676 / 4.670 with the 4x4 sites, 4.718 with the 8x8 sites too (profiles/r05/attn_small_ab.txt: on
+# its own 20.1 us at 4x4 against 17 + 8, 27.0 against 22.2 at 8x8 where the per-lane VALU attention over 64 keys is 12 us of it).
+# AFLDM_ATTN_SMALL_T=16,64 enables it.
+_ATTN_SMALL_T = tuple(int(v) for v in os.environ.get("AFLDM_ATTN_SMALL_T", "").split(",") if v)
+
+
+def attn_small_fused_ok(x, heads):
+    """True when afldm_attn_small_fused has a kernel for the (already normalised) tokens x [B, T, C]."""
+    if not _ATTN_SMALL or x.dtype != torch.bfloat16 or x.ndim != 3:
+        return False
+    B, T, C = x.shape
+    if T not in _ATTN_SMALL_T:
+        return False
+    return bool(lib.afldm_attn_small_fused_supported(B, T, C, int(heads)))
+
+
+def attn_small_fused(x, w_qkv, bias_qkv, heads, scale, out=None):
+    """q | k | v projection + attention of the 8x8 / 4x4 levels in ONE launch; x [B, T, C] = the GroupNorm-ed tokens."""
+    _dev(x, "x")
+    B, T, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    tok = _begin()
+    check(lib.afldm_attn_small_fused(ptr(x), ptr(w_qkv), ptr(bias_qkv), ptr(out), B, T, C, int(heads), float(scale), _code(x),
+                                     stream_ptr()), "attn_small_fused")
+    d = C // heads
+    _end(tok, "attn_small", 2.0 * B * T * 3 * C * C + 4.0 * B * heads * T * T * d, (2 * B * T * C + 3 * C * C) * x.element_size())
+    return out
+
+
 # ----------------------------------------------------------------------------- DDIM
 def ddim_step(x, eps_nhwc, coef, step_idx, advance=False, out=None):
     """x NCHW fp32, eps NHWC dtype; coef float[4*nsteps] and step_idx int32[1] on device."""

@@ -373,6 +373,16 @@ int afldm_attention(const void* q, int ldq, const void* k, int ldk, const void* 
                     int B, int Bk, int heads, int Tq, int Tk, int d, float scale, int dtype,
                     afldm_stream_t stream);
 
+/* ---- small planes: q | k | v projection + attention in one launch ------------------------------
+ * to_q | to_k | to_v -> scaled_dot_product_attention of diffusers' AttnProcessor2_0 (reference cross_frame_attn.py:66-77, IDLE
+ * branch) at the 8x8 (T = 64, C = 384) and 4x4 (T = 16, C = 768) levels, head_dim 24, bf16 (csrc/attns.hip): x [B,T,C] are the
+ * tokens AFTER Attention.group_norm (the producing convolution / slab consumer applies it: afldm_conv_args.y_norm,
+ * afldm_af_act_slabs), w_qkv [3C,C] / bias_qkv [3C] the packed projections, o [B,T,C] the input of to_out.  q | k | v are
+ * rounded to bf16 as the three-launch path stores them and never leave the CU. */
+int afldm_attn_small_fused_supported(int B, int T, int C, int heads);
+int afldm_attn_small_fused(const void* x, const void* w_qkv, const float* bias_qkv, void* o, int B, int T, int C, int heads,
+                           float scale, int dtype, afldm_stream_t stream);
+
 /* ---- attention block front end, fused ------------------------------------------------------
  * group_norm -> to_q | to_k | to_v -> scaled_dot_product_attention of diffusers' AttnProcessor2_0 on the deprecated
  * attention-block configuration (the self-attention path of reference cross_frame_attn.py:66-77 in IDLE / STORE state;

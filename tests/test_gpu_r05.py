@@ -227,3 +227,31 @@ def test_conv2_epilogue_applies_the_attention_groupnorm_at_8x8(golden, monkeypat
     print(f"[conv2 -> attention GroupNorm in the epilogue] gn_apply launches {n_sep} -> {n_fus}; fused vs separate rel-RMS {r:.3e}; "
           f"vs oracle fixture {rel_rms(y_fus[:1].float(), g['y_t981']):.3e}")
     assert n_sep - n_fus == 5 and r <= 2e-3 and rel_rms(y_fus[:1].float(), g["y_t981"]) <= 2e-2
+
+
+@pytest.mark.parametrize("T,C,heads,B", [(64, 384, 16, 64), (16, 768, 32, 64), (64, 384, 16, 4), (16, 768, 32, 8)])
+def test_attn_small_fused_vs_two_launch_path_and_reference(T, C, heads, B):
+    """afldm_attn_small_fused (csrc/attns.hip): to_q | to_k | to_v + scaled_dot_product_attention of the 8x8 / 4x4 levels in ONE
+    launch against (a) the fp32 restatement of diffusers' processor on the same normalised tokens and (b) the two launches it
+    replaces (projection GEMM + afldm_attention); bf16 per-op tolerance 2e-2, bit-identical reruns."""
+    from afldm_amd import ops
+    g = torch.Generator().manual_seed(T + C + B)
+    x = torch.randn(B, T, C, generator=g).cuda().to(torch.bfloat16)
+    w = (torch.randn(3 * C, C, generator=g) * C ** -0.5).cuda()
+    b = (0.1 * torch.randn(3 * C, generator=g)).cuda()
+    wp = ops.pack_weight(w, torch.bfloat16)
+    from afldm_amd import _lib
+    assert _lib.lib.afldm_attn_small_fused_supported(B, T, C, heads) == 1      # (the policy keeps it off: measured no faster in the step)
+    scale = 24 ** -0.5
+    o1 = ops.attn_small_fused(x, wp, b, heads, scale)
+    o2 = ops.attn_small_fused(x, wp, b, heads, scale)
+    qk, vt = ops.linear_split(x, wp, b, 2 * C)
+    o_two = ops.attention(qk[:, :, :C], qk[:, :, C:], vt, heads, scale=scale)
+    torch.cuda.synchronize()
+    xf, wf = x.float(), wp.reshape(3 * C, C).float()
+    q, k, v = [(xf @ wf[i * C:(i + 1) * C].T + b[i * C:(i + 1) * C]).view(B, T, heads, 24).transpose(1, 2) for i in range(3)]
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).transpose(1, 2).reshape(B, T, C)
+    r_ref, r_two = rel_rms(o1.float(), ref.cpu()), rel_rms(o1.float(), o_two.float().cpu())
+    print(f"[attn_small_fused] T={T} C={C} B={B}: vs fp32 reference {r_ref:.3e} (two launches: {rel_rms(o_two.float(), ref.cpu()):.3e}), vs two launches {r_two:.3e}")
+    assert torch.equal(o1, o2) and r_ref <= 2e-2 and r_two <= 2e-2
+    assert _lib.lib.afldm_attn_small_fused_supported(3, T, C, heads) == 0
