@@ -367,8 +367,8 @@ class ResnetBlock2D(nn.Module):
         """next_gn: the GroupNorm module of an attention block that consumes this block's output next (the block loops
         pass it): lets conv2 hand its result over already normalised where that saves launches."""
         x1, x2 = _pair(input_tensor)
-        if x1.ndim == 4 and x1.shape[1] in (16, 32):
-            # 32^2 / 16^2 levels: norm -> activation -> conv pairs as merged launches where there is a kernel for them
+        if x1.ndim == 4 and x1.shape[1] in ops._ACTCONV_N:
+            # 32^2 / 16^2 levels, opt-in (AFLDM_ACTCONV_N): norm -> activation -> conv pairs as merged launches where there is a kernel for them
             h = self._norm_act_conv(self.norm1, input_tensor, self.conv1, temb=temb_proj, temb_stride=temb_stride, want_stats=True)
             res = conv_forward(self.conv_shortcut, input_tensor) if self.conv_shortcut is not None else x1
             assert self.conv_shortcut is not None or x2 is None
