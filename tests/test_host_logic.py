@@ -184,6 +184,27 @@ print("OK", rank)
 """
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _torchrun(nproc, args, timeout):
+    """`torch.distributed.run` on an OS-assigned free port; ONE retry on a failed run (a rendezvous port can be taken
+    between the probe and the launch, and the first `import torch` of several processes at once can be slow)."""
+    r = None
+    for _ in range(2):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port())] + [str(a) for a in args]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, OMP_NUM_THREADS="1"))
+        if r.returncode == 0:
+            break
+    return r
+
+
+
 @pytest.mark.parametrize("n", [16, 5])
 def test_two_process_gloo_harness_offset_sharding(tmp_path, n):
     """harness.shift_ldm's multi-GPU leg (SURVEY.md 8e 'Harness variant'): offsets interleaved over ranks, results merged
@@ -194,10 +215,7 @@ def test_two_process_gloo_harness_offset_sharding(tmp_path, n):
     assert src.count("parallel.interleaved(") == 2 and src.count("parallel.gather_indexed(") == 2
     script = tmp_path / "worker_offsets.py"
     script.write_text(_WORKER_OFFSETS)
-    port = 29950 + (os.getpid() % 40) + n
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), str(script), ROOT, str(n)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    r = _torchrun(2, [script, ROOT, n], 240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("OK") == 2
 
@@ -206,11 +224,7 @@ def test_two_process_gloo_harness_offset_sharding(tmp_path, n):
 def test_two_process_gloo_sharded_sampling(tmp_path, total):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    port = 29600 + (os.getpid() % 300) + total
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), str(script), ROOT, str(total)]
-    env = dict(os.environ, OMP_NUM_THREADS="1")
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+    r = _torchrun(2, [script, ROOT, total], 240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("OK") == 2
 
@@ -245,10 +259,7 @@ def test_eight_process_gloo_sharded_sampling_and_record(tmp_path, total):
     (the world = 8 bookkeeping exercised before the first real SCALE record)."""
     script = tmp_path / "worker8.py"
     script.write_text(_WORKER8)
-    port = 29300 + (os.getpid() % 200) + (total % 7)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), str(script), ROOT, str(total)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    r = _torchrun(8, [script, ROOT, total], 400)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("OK") == 8
 
