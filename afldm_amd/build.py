@@ -102,7 +102,27 @@ def build(force=False, verbose=True):
             raise RuntimeError("libafldm_hip.so has unresolved afldm symbols: " + ", ".join(missing[:4]))
         if verbose:
             print("[afldm_amd.build] linked", LIB, flush=True)
+    build_aql(force, verbose)
     return LIB
+
+
+AQL_LIB = os.path.join(OUT_DIR, "libafldm_aql.so")
+
+
+def build_aql(force=False, verbose=True):
+    """libafldm_aql.so (csrc/aqlq.cpp): host-only C++ on the ROCr tools interface - the AQL packet view of the step."""
+    src = os.path.join(CSRC, "aqlq.cpp")
+    if not (force or _stale(AQL_LIB, [src])):
+        return AQL_LIB
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-DAMD_INTERNAL_BUILD",
+           f"-I{rocm}/include", f"-I{rocm}/include/hsa", src, "-o", AQL_LIB]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"g++ failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print("[afldm_amd.build] linked", AQL_LIB, flush=True)
+    return AQL_LIB
 
 
 if __name__ == "__main__":

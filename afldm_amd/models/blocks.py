@@ -19,7 +19,12 @@ import os
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import aql, ops
+
+# AFLDM_SHORTCUT_ORDER: where a ResnetBlock2D issues its 1x1 conv_shortcut (independent of norm1 -> conv1 -> norm2):
+# 0 (default) between the second activation and conv2, 1 behind the first activation, 2 in front of it.  Same results;
+# with an AQL policy armed (afldm_amd/aql.py) the launch marked `independent` runs beside its neighbour.
+_SC_ORDER = int(os.environ.get("AFLDM_SHORTCUT_ORDER", "0"))
 
 
 def _pair(x):
@@ -373,7 +378,17 @@ class ResnetBlock2D(nn.Module):
             res = conv_forward(self.conv_shortcut, input_tensor) if self.conv_shortcut is not None else x1
             assert self.conv_shortcut is not None or x2 is None
             return self._norm_act_conv(self.norm2, h, self.conv2, residual=res, want_stats=True)
-        h = self._norm_act(self.norm1, input_tensor)
+        res = None
+        if self.conv_shortcut is not None and _SC_ORDER == 2:
+            # shortcut first, the activation beside it (AQL policy: afldm_amd/aql.py; tools/aql_shortcut_ab.py)
+            res = conv_forward(self.conv_shortcut, input_tensor)
+            with aql.independent("act1"):
+                h = self._norm_act(self.norm1, input_tensor)
+        else:
+            h = self._norm_act(self.norm1, input_tensor)
+        if self.conv_shortcut is not None and _SC_ORDER == 1:
+            with aql.independent("shortcut"):
+                res = conv_forward(self.conv_shortcut, input_tensor)
         fused = self._conv1_norm2_act_fused(h, temb_proj, temb_stride)
         if fused is not None:
             h = fused
@@ -381,8 +396,11 @@ class ResnetBlock2D(nn.Module):
             # (the convs whose outputs feed a GroupNorm emit its statistics from their epilogue)
             h = conv_forward(self.conv1, h, temb=temb_proj, temb_stride=temb_stride, want_stats=True)
             h = self._norm_act(self.norm2, h)
-        if self.conv_shortcut is not None:
-            res = conv_forward(self.conv_shortcut, input_tensor)
+        if res is not None:
+            pass
+        elif self.conv_shortcut is not None:
+            with aql.independent("shortcut"):
+                res = conv_forward(self.conv_shortcut, input_tensor)
         else:
             assert x2 is None
             res = x1
