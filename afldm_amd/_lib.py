@@ -4,7 +4,7 @@ The library is the ONLY compute path of afldm_amd: if it cannot be loaded, impor
 module raises — there is no CPU fallback."""
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 import torch  # noqa: F401  (imported first so torch's libamdhip64.so.7 is the one HIP runtime in-process)
 
@@ -110,6 +110,9 @@ def _load():
         "afldm_attn_block_fused_trace": ([vp], c_int),
         "afldm_af_act_trace": ([vp], c_int),
         "afldm_attn_block_fused": ([vp, vp, ip, vp, vp, ip, fp, vp, vp, vp, ip, ip, ip, ip, fp, ip, vp], c_int),
+        "afldm_attn_block_fused_out_supported": ([ip, ip, ip, ip, ip], c_int),
+        "afldm_attn_block_fused_out": ([vp, vp, ip, vp, vp, ip, fp, vp, vp, vp, vp, vp, vp, vp, vp, c_longlong, ip, ip, ip, ip, fp, ip,
+                                        vp], c_int),
         "afldm_ddim_step": ([vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, vp], c_int),
         "afldm_ddim_step_flat": ([vp, vp, vp, fp, fp, fp, fp, c_size_t, vp], c_int),
         "afldm_select_timestep": ([vp, vp, vp, ip, vp], c_int),

@@ -41,7 +41,20 @@ struct AttnFP {
   int force_slow;      // testing / A-B: always take the loop that tracks the row maxima
   int stagger;         // s_sleep units (64 cycles) the second half of the waves waits before the attention phase
   unsigned long long* trace;   // diagnostic: [workgroup][wave][8] s_memtime stamps (afldm_attn_block_fused_trace), or NULL
+  // phase C (template OUT): to_out + residual + GroupNorm partial sums of the block's output inside the same launch
+  const bf16* wo;      // [C][C] to_out rows
+  const float* bias_o; // [C]
+  bf16* y;             // [B][T][C] = to_out(o) + x
+  float* stats_out;    // [B][heads][C][2] per-channel partial sums of y over the workgroup's token block
+  unsigned* sync;      // hand-over counters: one 128-byte line per sample (word 0 arrivals, word 1 departures, word 2 XCD mask)
+  unsigned* err;       // error word (1: a cluster timed out, 2: a cluster straddles XCDs)
 };
+
+__device__ __forceinline__ int attnf_xcc_id() {
+  int v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 7;
+}
 
 static unsigned long long* g_attnf_trace = nullptr;
 
@@ -77,7 +90,7 @@ struct AttnFCfg {
 
 // DBG (AFLDM_ATTNF_DBG, timing decomposition, garbage results): 1 no attention phase, 2 no exponentials, 4 no projection MFMAs,
 // 8 no token-tile reloads in the projection, 16 no W' fragment reads in the projection
-template <int D, int NW, int TPW, int CK, int DBG = 0, bool LEAN = false>
+template <int D, int NW, int TPW, int CK, int DBG = 0, bool LEAN = false, bool OUT = false>
 __global__ void __launch_bounds__(NW * 64, LEAN ? 2 : 1) k_attn_fused(AttnFP p) {
   typedef AttnFCfg<D, NW, TPW, CK, LEAN> CF;
   constexpr int T = CF::T, NT = CF::NT, C = CF::C, RK = CF::RK, RW = CF::RW, NU = CF::NU, NTHR = NW * 64;
@@ -554,17 +567,153 @@ __global__ void __launch_bounds__(NW * 64, LEAN ? 2 : 1) k_attn_fused(AttnFP p) 
     }
   }
   stamp(7);
+
+  // ------------------------------------------------------------------ phase C: to_out + residual + statistics
+  // The heads of a sample are `heads` workgroups with consecutive work ids on ONE XCD (xcd_remap), dispatched together.  Each
+  // has just stored its head's 24 channels of o for ALL tokens; once the sample's workgroups have all arrived (one L2 atomic
+  // each; their stores are in the XCD's L2 when acknowledged), workgroup h owns the token block [h T / heads, (h + 1) T / heads)
+  // of the sample and finishes the attention block there:  y = o Wo^T + bias + x,  with the per-channel partial sums of the
+  // rounded y for the next GroupNorm (split h of `heads`).  What the stand-alone to_out launch did - a 75 MB pass at
+  // 32 x 32 - becomes ~5 us at the end of a launch whose o rows are still in the L2.  A workgroup waits only for workgroups
+  // of its own sample, which the dispatcher placed before or together with it: no cluster is ever partly resident for long.
+  if constexpr (OUT) {
+    constexpr int HEADS = C / D, TB = T / HEADS, NTT = TB / 32, NCH = NW / NTT, CW = C / NCH, NTL = CW / 32;
+    constexpr int RWO = C * 2 + 16, WO_BYTES = C * RWO, OROW = C + 8;
+    constexpr int WPT = (C * C / 8) / NTHR;                    // 16-byte pieces of Wo per thread
+    static_assert(T % HEADS == 0 && TB % 32 == 0 && NTT * NCH == NW && CW % 32 == 0 && (C * C / 8) % NTHR == 0, "phase C tiling");
+    static_assert(WO_BYTES + TB * OROW * 2 <= CF::LDS_BYTES, "Wo + staging tile fit the attention phase's LDS");
+    char* sWo = smem;
+    bf16* sO = reinterpret_cast<bf16*>(smem + WO_BYTES);
+    // Wo -> registers while the other waves finish (independent of the siblings)
+    bf16x8 wreg[WPT];
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) wreg[j] = ld16<bf16x8>(p.wo + (size_t)(tid + NTHR * j) * 8);
+    // ... and so are the residual rows (x left the L2 long ago: their latency runs under the wait for the siblings).
+    // wave (token tile tt, cout slice chh): [channel x token] tiles, rows permuted by sigma so that registers 8c .. 8c+7 of
+    // lane (token, half) are the 8 consecutive channels 16c + 8 half + e of the tile
+    const int tt = wave % NTT, chh = wave / NTT;
+    const int trow = h * TB + tt * 32 + ln;                    // this lane's token (within the sample)
+    const bf16* xres = p.x + ((size_t)b * T + trow) * C;
+    bf16x8 rx[NTL][2];
+#pragma unroll
+    for (int tl = 0; tl < NTL; ++tl)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) rx[tl][c] = ld16<bf16x8>(xres + chh * CW + tl * 32 + 16 * c + 8 * hi);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this thread's o stores are acknowledged by the L2
+    __syncthreads();                                           // K / V^T are dead, every wave's stores are out
+    if (tid == 0) {
+      unsigned* cnt = p.sync + (size_t)b * 32;
+      __hip_atomic_fetch_or(cnt + 2, 1u << attnf_xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+      const int i = tid + NTHR * j, row = i / (C / 8), pc = i - row * (C / 8);
+      st16<bf16x8>(sWo + row * RWO + (pc << 4), wreg[j]);
+    }
+    if (tid == 0) {
+      unsigned* cnt = p.sync + (size_t)b * 32;
+      unsigned spins = 0;
+      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)HEADS) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 22)) {                            // never hang the device on a lost sibling
+          __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      const unsigned old = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (old == (unsigned)HEADS - 1) {                        // last one out: the line returns to zero for the next launch
+        const unsigned xm = __hip_atomic_exchange(cnt + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (xm & (xm - 1)) __hip_atomic_store(p.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_exchange(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_exchange(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    __syncthreads();
+    stamp(10);
+    const bf16* orow = p.o + ((size_t)b * T + trow) * C + hi * 8;
+    bf16x8 of[CK];
+#pragma unroll
+    for (int kk = 0; kk < CK; ++kk) of[kk] = ld16<bf16x8>(orow + kk * 16);
+    f32x16 acc[NTL];
+#pragma unroll
+    for (int tl = 0; tl < NTL; ++tl) {
+      const int c0 = chh * CW + tl * 32;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const f32x4 b0 = ld16<f32x4>(p.bias_o + c0 + 16 * c + 8 * hi), b1 = ld16<f32x4>(p.bias_o + c0 + 16 * c + 8 * hi + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[tl][8 * c + e] = (float)rx[tl][c][e] + (e < 4 ? b0[e] : b1[e - 4]);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < CK; ++kk) {
+#pragma unroll
+      for (int tl = 0; tl < NTL; ++tl) {
+        const bf16x8 wf = ld16<bf16x8>(sWo + (chh * CW + tl * 32 + sig) * RWO + ((2 * kk + hi) << 4));
+        acc[tl] = mfma32(wf, of[kk], acc[tl]);
+      }
+    }
+#pragma unroll
+    for (int tl = 0; tl < NTL; ++tl)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16)acc[tl][8 * c + e];
+        st16<bf16x8>(sO + (tt * 32 + ln) * OROW + chh * CW + tl * 32 + 16 * c + 8 * hi, v);
+      }
+    __syncthreads();                                           // tile staged; Wo is dead
+    // whole rows out, 16 bytes per lane; per-channel sums of the stored values by the thread that owns the column
+    constexpr int CPR = C / 8, RPI = NTHR / CPR;
+    const bool active = tid < RPI * CPR;
+    const int ch = tid % CPR, tr = tid / CPR;
+    float ss1[8], ss2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss1[e] = ss2[e] = 0.f;
+    if (active) {
+      bf16* yrow = p.y + ((size_t)b * T + h * TB) * C + ch * 8;
+#pragma unroll 4
+      for (int row = tr; row < TB; row += RPI) {
+        const bf16x8 v = ld16<bf16x8>(sO + row * OROW + ch * 8);
+        st16<bf16x8>(yrow + (size_t)row * C, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float vr = (float)v[e];
+          ss1[e] += vr;
+          ss2[e] = fmaf(vr, vr, ss2[e]);
+        }
+      }
+    }
+    float* sR = reinterpret_cast<float*>(smem);                // [RPI][C][2] over the Wo region
+    static_assert(RPI * C * 8 <= WO_BYTES, "statistics scratch");
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) *reinterpret_cast<f32x2*>(sR + ((tr * C) + ch * 8 + e) * 2) = f32x2{ss1[e], ss2[e]};
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += NTHR) {
+      float a1 = 0.f, a2 = 0.f;
+      for (int r = 0; r < RPI; ++r) {
+        const f32x2 v = *reinterpret_cast<const f32x2*>(sR + ((r * C) + c) * 2);
+        a1 += v[0];
+        a2 += v[1];
+      }
+      *reinterpret_cast<f32x2*>(p.stats_out + (((size_t)b * HEADS + h) * C + c) * 2) = f32x2{a1, a2};
+    }
+    stamp(11);
+  }
 }
 
-template <int D, int NW, int TPW, int CK, int DBG = 0, bool LEAN = false>
+template <int D, int NW, int TPW, int CK, int DBG = 0, bool LEAN = false, bool OUT = false>
 static int attnf_launch(const AttnFP& p, hipStream_t st) {
   typedef AttnFCfg<D, NW, TPW, CK, LEAN> CF;
   static unsigned long long once = 0;
   if (first_on_device(once)) {
-    (void)hipFuncSetAttribute((const void*)k_attn_fused<D, NW, TPW, CK, DBG, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)k_attn_fused<D, NW, TPW, CK, DBG, LEAN, OUT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               CF::LDS_BYTES);
   }
-  k_attn_fused<D, NW, TPW, CK, DBG, LEAN><<<p.B * p.heads, NW * 64, CF::LDS_BYTES, st>>>(p);
+  k_attn_fused<D, NW, TPW, CK, DBG, LEAN, OUT><<<p.B * p.heads, NW * 64, CF::LDS_BYTES, st>>>(p);
   return check_launch("afldm_attn_block_fused");
 }
 
@@ -602,9 +751,44 @@ extern "C" int afldm_attn_block_fused_supported(int T, int C, int head_dim, int 
   return 0;
 }
 
+// 1 when afldm_attn_block_fused_out has a kernel for this shape: the 32 x 32 level, and every sample's `heads` workgroups
+// inside one XCD (work ids are dealt to the 8 XCDs in equal contiguous runs: B a multiple of 8)
+extern "C" int afldm_attn_block_fused_out_supported(int B, int T, int C, int head_dim, int G) {
+  if (!afldm_attn_block_fused_supported(T, C, head_dim, G)) return 0;
+  if (!(head_dim == 24 && T == 1024 && C == 192)) return 0;
+  return B > 0 && B <= 512 && B % 8 == 0;
+}
+
+static int attn_block_fused_impl(const void* x, const float* stats, int S, const float* gamma, const float* beta,
+                                 int G, float eps, const void* w_qkv, const float* bias_qkv, void* o, const void* w_out,
+                                 const float* bias_out, void* y, float* stats_out, void* sync, long long sync_bytes, int B,
+                                 int T, int C, int heads, float scale, int dtype, afldm_stream_t stream);
+
+extern "C" int afldm_attn_block_fused_out(const void* x, const float* stats, int S, const float* gamma, const float* beta,
+                                          int G, float eps, const void* w_qkv, const float* bias_qkv, void* o,
+                                          const void* w_out, const float* bias_out, void* y, float* stats_out, void* sync,
+                                          long long sync_bytes, int B, int T, int C, int heads, float scale, int dtype,
+                                          afldm_stream_t stream) {
+  AFLDM_REQUIRE(w_out && bias_out && y && stats_out && sync, AFLDM_ENULL, "afldm_attn_block_fused_out: NULL pointer");
+  AFLDM_REQUIRE(heads > 0 && C % heads == 0 && afldm_attn_block_fused_out_supported(B, T, C, C / heads, G), AFLDM_ESHAPE,
+                "afldm_attn_block_fused_out: no kernel for B=%d T=%d C=%d heads=%d groups=%d", B, T, C, heads, G);
+  AFLDM_REQUIRE(sync_bytes >= (long long)(16384 + 32 * B) * 4, AFLDM_ESHAPE, "afldm_attn_block_fused_out: sync buffer too small");
+  AFLDM_REQUIRE(aligned16(w_out) && aligned16(y) && aligned16(bias_out), AFLDM_EALIGN, "afldm_attn_block_fused_out: pointers must be 16-byte aligned");
+  return attn_block_fused_impl(x, stats, S, gamma, beta, G, eps, w_qkv, bias_qkv, o, w_out, bias_out, y, stats_out, sync, sync_bytes,
+                               B, T, C, heads, scale, dtype, stream);
+}
+
 extern "C" int afldm_attn_block_fused(const void* x, const float* stats, int S, const float* gamma, const float* beta,
                                       int G, float eps, const void* w_qkv, const float* bias_qkv, void* o, int B, int T,
                                       int C, int heads, float scale, int dtype, afldm_stream_t stream) {
+  return attn_block_fused_impl(x, stats, S, gamma, beta, G, eps, w_qkv, bias_qkv, o, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                               B, T, C, heads, scale, dtype, stream);
+}
+
+static int attn_block_fused_impl(const void* x, const float* stats, int S, const float* gamma, const float* beta,
+                                 int G, float eps, const void* w_qkv, const float* bias_qkv, void* o, const void* w_out,
+                                 const float* bias_out, void* y, float* stats_out, void* sync, long long sync_bytes, int B,
+                                 int T, int C, int heads, float scale, int dtype, afldm_stream_t stream) {
   AFLDM_REQUIRE(x && stats && gamma && beta && w_qkv && bias_qkv && o, AFLDM_ENULL, "afldm_attn_block_fused: NULL pointer");
   AFLDM_REQUIRE(dtype == AFLDM_BF16, AFLDM_EDTYPE, "afldm_attn_block_fused: bf16 only (fp32 runs gn_apply + linear + attention)");
   AFLDM_REQUIRE(B > 0 && heads > 0 && C % heads == 0 && S > 0, AFLDM_ESHAPE, "afldm_attn_block_fused: bad shape B=%d heads=%d C=%d S=%d", B, heads, C, S);
@@ -618,6 +802,10 @@ extern "C" int afldm_attn_block_fused(const void* x, const float* stats, int S, 
   p.trace = g_attnf_trace;
   p.o = (bf16*)o; p.B = B; p.heads = heads; p.C = C; p.G = G; p.eps = eps;
   p.qscale = scale * 1.4426950408889634f;
+  p.wo = (const bf16*)w_out; p.bias_o = bias_out; p.y = (bf16*)y; p.stats_out = stats_out;
+  p.sync = sync ? (unsigned*)sync + 16384 : nullptr;
+  p.err = sync ? (unsigned*)sync + 8193 : nullptr;
+  (void)sync_bytes;
   {
     static const int stg = getenv("AFLDM_ATTNF_STAGGER") ? atoi(getenv("AFLDM_ATTNF_STAGGER")) : 0;      // (measured: no effect)
     p.stagger = stg;
@@ -627,6 +815,7 @@ extern "C" int afldm_attn_block_fused(const void* x, const float* stats, int S, 
     p.force_slow = e && atoi(e) != 0;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (d == 24 && T == 1024 && w_out) return attnf_launch<24, 8, 4, 12, 0, false, true>(p, st);
   if (d == 24 && T == 1024) return attnf_launch_dbg<24, 8, 4, 12>(p, st);
   if (d == 24 && T == 256) {
     // 16x16 level: two four-wave workgroups per CU (80 KiB each) unless AFLDM_ATTNF_L16=8 asks for the eight-wave form

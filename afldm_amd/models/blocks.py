@@ -446,6 +446,12 @@ class AttnProcessor2_0:
             # 32^2 / 16^2 levels, bf16: GroupNorm-apply + q | k | v projection + attention in ONE launch (csrc/attnf.hip)
             stats = ops.gn_stats(hidden_states, gn.num_groups)
             w, b = packed_qkv(attn, hidden_states.dtype, ("q", "k", "v"))
+            if ops.attn_block_fused_out_ok(hidden_states.view(B, H * W, C), attn.heads, gn.num_groups):
+                # ... and to_out + the residual connection in the same launch (32^2 level)
+                wo, bo = packed_conv(attn.to_out[0], hidden_states.dtype)
+                y = ops.attn_block_fused_out(hidden_states.view(B, H * W, C), stats, gamma, beta, gn.num_groups, gn.eps, w, b,
+                                             attn.heads, attn.scale, wo, bo)
+                return ops.carry_stats(y.view(B, H, W, C), y)
             o = ops.attn_block_fused(hidden_states.view(B, H * W, C), stats, gamma, beta, gn.num_groups, gn.eps, w, b,
                                      attn.heads, attn.scale)
             return linear_forward(attn.to_out[0], o.view(B, H, W, C), residual=hidden_states, want_stats=True)

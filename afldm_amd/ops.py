@@ -1023,6 +1023,38 @@ def attn_block_fused_ok(x, heads, G):
     return bool(lib.afldm_attn_block_fused_supported(T, C, C // heads, int(G)))
 
 
+# AFLDM_ATTN_FUSED_OUT=0: to_out + residual as its own launch behind the fused front end (A/B; the default carries them in
+# the attention launch where afldm_attn_block_fused_out has a kernel: the 32 x 32 level, batch a multiple of 8)
+_FUSED_ATTN_OUT = os.environ.get("AFLDM_ATTN_FUSED_OUT", "1") != "0"
+
+
+def attn_block_fused_out_ok(x, heads, G):
+    B, T, C = x.shape
+    return bool(_FUSED_ATTN_OUT and lib.afldm_attn_block_fused_out_supported(B, T, C, C // heads, int(G)))
+
+
+def attn_block_fused_out(x, stats, gamma, beta, G, eps, w_qkv, bias_qkv, heads, scale, w_out, bias_out):
+    """The whole attention block in ONE launch: attn_block_fused + to_out + residual.  Returns y [B, T, C] = to_out(o) + x
+    with its GroupNorm partial sums attached (`.gn_partial` [B, heads, C, 2])."""
+    _dev(x, "x")
+    B, T, C = x.shape
+    o = torch.empty_like(x)
+    y = torch.empty_like(x)
+    st = torch.empty((B, heads, C, 2), dtype=torch.float32, device=x.device)
+    sync = _sync_words(x.device)
+    assert stats.st2 is None and stats.st1.shape[2] == C
+    tok = _begin()
+    check(lib.afldm_attn_block_fused_out(ptr(x), ptr(stats.st1), stats.S1, ptr(gamma), ptr(beta), int(G), float(eps),
+                                         ptr(w_qkv), ptr(bias_qkv), ptr(o), ptr(w_out), ptr(bias_out), ptr(y), ptr(st),
+                                         ptr(sync), sync.numel() * 4, B, T, C, heads, float(scale), _code(x), stream_ptr()),
+          "attn_block_fused_out")
+    d = C // heads
+    _end(tok, "attn_fused", 2.0 * B * T * 4 * C * C + 4.0 * B * heads * T * T * d,
+         (3 * B * T * C + 4 * C * C) * x.element_size())
+    y.gn_partial = st
+    return y
+
+
 def attn_block_fused(x, stats, gamma, beta, G, eps, w_qkv, bias_qkv, heads, scale, out=None):
     """GroupNorm-apply -> q | k | v projection -> attention of one attention block in ONE launch.  x [B, T, C] raw
     tokens; stats = GNStats of x; w_qkv [3C, 1, 1, C] / bias_qkv [3C] = packed (to_q | to_k | to_v).  Returns the input

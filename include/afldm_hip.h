@@ -404,6 +404,18 @@ int afldm_attn_block_fused_trace(void* buf);
 int afldm_attn_block_fused(const void* x, const float* stats, int S, const float* gamma, const float* beta, int G,
                            float eps, const void* w_qkv, const float* bias_qkv, void* o, int B, int T, int C,
                            int heads, float scale, int dtype, afldm_stream_t stream);
+/* The same launch carrying the rest of the attention block: y = to_out(o) + x (diffusers Attention.to_out[0] + the
+ * residual connection of the attention-block configuration) and stats_out [B,heads,C,2] = per-channel partial sums of the
+ * rounded y (the next GroupNorm's input; split h covers the token block [h T / heads, (h+1) T / heads)).  The `heads`
+ * workgroups of a sample hand their o slices over inside the launch (one counter line per sample in `sync`, int32 words
+ * [16384 + 32 b, ...), zero between launches; word 8193 = 1 when a workgroup gave up waiting, 2 when a sample's workgroups
+ * were not on one XCD) and workgroup h then runs the to_out GEMM of its token block out of the XCD's L2.  w_out [C,C],
+ * bias_out [C] fp32.  Shapes: afldm_attn_block_fused_out_supported (the 32 x 32 level, B a multiple of 8). */
+int afldm_attn_block_fused_out_supported(int B, int T, int C, int head_dim, int G);
+int afldm_attn_block_fused_out(const void* x, const float* stats, int S, const float* gamma, const float* beta, int G,
+                               float eps, const void* w_qkv, const float* bias_qkv, void* o, const void* w_out,
+                               const float* bias_out, void* y, float* stats_out, void* sync, long long sync_bytes, int B,
+                               int T, int C, int heads, float scale, int dtype, afldm_stream_t stream);
 
 /* ---- DDIM update -------------------------------------------------------------------------
  * DDIMScheduler.step, eta = 0, epsilon prediction, no clipping:

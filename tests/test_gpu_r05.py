@@ -255,3 +255,46 @@ def test_attn_small_fused_vs_two_launch_path_and_reference(T, C, heads, B):
     print(f"[attn_small_fused] T={T} C={C} B={B}: vs fp32 reference {r_ref:.3e} (two launches: {rel_rms(o_two.float(), ref.cpu()):.3e}), vs two launches {r_two:.3e}")
     assert torch.equal(o1, o2) and r_ref <= 2e-2 and r_two <= 2e-2
     assert _lib.lib.afldm_attn_small_fused_supported(3, T, C, heads) == 0
+
+
+@pytest.mark.parametrize("B", [8, 64])
+def test_attn_block_fused_out_vs_front_end_plus_to_out(B):
+    """afldm_attn_block_fused_out (the attention launch that also runs to_out + the residual connection + the next
+    GroupNorm's partial sums, 32^2 level; reference: diffusers AttnProcessor2_0 as configured by cross_frame_attn.py:66-130
+    IDLE branch) against the two launches it replaces on the same bf16 inputs - the front end's o is identical, the
+    GEMM accumulates the same products in another order - and against the fp32 form of to_out on that o; the statistics
+    against sums formed from the stored y itself; bit-identical reruns; hand-over counters back at zero, no error word."""
+    from afldm_amd import ops
+    T, C, heads, G, eps = 1024, 192, 8, 32, 1e-5
+    gen = torch.Generator().manual_seed(B + 5)
+    x = (torch.randn(B, T, C, generator=gen) * (0.7 + torch.rand(1, 1, C, generator=gen)) + 0.3 * torch.randn(1, 1, C, generator=gen))
+    xg = x.to(torch.bfloat16).cuda()
+    gamma, beta = (0.5 + torch.rand(C, generator=gen)).cuda(), (0.3 * torch.randn(C, generator=gen)).cuda()
+    wq = ops.pack_weight((torch.randn(3 * C, C, generator=gen) / C ** 0.5).cuda(), torch.bfloat16)
+    bq = (0.2 * torch.randn(3 * C, generator=gen)).cuda()
+    wo_f = torch.randn(C, C, generator=gen) / C ** 0.5
+    wo = ops.pack_weight(wo_f.cuda(), torch.bfloat16)
+    bo = (0.2 * torch.randn(C, generator=gen)).cuda()
+    scale = (C // heads) ** -0.5
+    stats = ops.gn_stats(xg.view(B, 32, 32, C), G)
+    assert ops.attn_block_fused_out_ok(xg, heads, G)
+    o = ops.attn_block_fused(xg, stats, gamma, beta, G, eps, wq, bq, heads, scale)
+    y_two = ops.conv2d(o.view(B, 32, 32, C), wo, bo, residual=xg.view(B, 32, 32, C), want_stats=True)
+    sync = ops.new_sync_buffer(xg.device)
+    with ops.sync_scope(sync):
+        y = ops.attn_block_fused_out(xg, stats, gamma, beta, G, eps, wq, bq, heads, scale, wo, bo)
+        y2 = ops.attn_block_fused_out(xg, stats, gamma, beta, G, eps, wq, bq, heads, scale, wo, bo)
+    torch.cuda.synchronize()
+    assert int(sync.abs().sum().item()) == 0, "hand-over counters / error word must be back at zero"
+    assert torch.equal(y, y2) and torch.equal(y.gn_partial, y2.gn_partial)
+    y32 = o.float() @ wo.view(C, C).float().t() + bo + xg.float()
+    r_two, r_32, r_two32 = rel_rms(y.float(), y_two.view(B, T, C).float().cpu()), rel_rms(y.float(), y32.cpu()), rel_rms(y_two.view(B, T, C).float(), y32.cpu())
+    same = float((y == y_two.view(B, T, C)).float().mean())
+    print(f"[attn fused + to_out] B={B}: vs two launches {r_two:.3e} ({same * 100:.2f} % of the elements bit-equal), vs fp32 to_out {r_32:.3e} "
+          f"(two launches {r_two32:.3e})")
+    assert r_32 <= 3e-3 and r_32 <= 1.2 * r_two32 + 1e-4 and r_two <= 3e-3 and same >= 0.98
+    st = y.gn_partial.double().sum(1).cpu()                          # [B, C, 2]
+    yd = y.double().cpu()
+    direct = torch.stack([yd.sum(1), (yd * yd).sum(1)], -1)
+    assert y.gn_partial.shape == (B, heads, C, 2)
+    assert float((st - direct).abs().max() / direct.abs().max()) <= 1e-5
