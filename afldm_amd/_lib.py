@@ -26,6 +26,7 @@ class ConvArgs(Structure):
         ("stats_out", c_void_p), ("temb_mod", c_int), ("sync", c_void_p), ("sync_bytes", c_size_t),
         ("defer_reduce", c_int), ("w_batch_stride", ctypes.c_longlong),
         ("y_norm", c_void_p), ("norm_gamma", c_void_p), ("norm_beta", c_void_p), ("norm_groups", c_int), ("norm_eps", c_float),
+        ("x_layout", c_int), ("y_layout", c_int),
     ]
 
 
@@ -71,6 +72,7 @@ def _load():
         "afldm_gn_stats": ([vp, ip, vp, ip, ip, ip, vp], c_int),
         "afldm_gn_apply": ([vp, ip, vp, ip, vp, ip, vp, ip, vp, vp, vp, ip, ip, ip, fp, ip, ip, vp], c_int),
         "afldm_af_act": ([vp, ip, vp, ip, vp, ip, vp, ip, vp, vp, ip, fp, vp, vp, vp, vp, ip, ip, ip, vp], c_int),
+        "afldm_af_act_c8": ([vp, ip, vp, ip, vp, ip, vp, ip, vp, vp, ip, fp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp], c_int),
         "afldm_af_act_slabs": ([vp, ip, vp, vp, ip, vp, vp, vp, vp, ip, fp, ip, vp, vp, vp, ip, ip, ip, ip, vp], c_int),
         "afldm_conv_out_fused": ([vp, vp, ip, vp, vp, ip, fp, vp, vp, vp, ip, ip, ip, ip, ip, vp], c_int),
         "afldm_af_pack_bytes": ([ip, ip], c_size_t),
@@ -93,6 +95,7 @@ def _load():
         "afldm_conv2d_tune": ([ip, ip], c_int),
         "afldm_conv2d_fused_splitk": ([ip], c_int),
         "afldm_conv2d_variant": ([POINTER(ConvArgs)], c_int),
+        "afldm_conv2d_c8_ok": ([POINTER(ConvArgs)], c_int),
         "afldm_conv2d_norm_ok": ([POINTER(ConvArgs)], c_int),
         "afldm_af_act_conv2d_merged": ([POINTER(AfActArgs), POINTER(ConvArgs)], c_int),
         "afldm_af_act_conv2d": ([POINTER(AfActArgs), POINTER(ConvArgs), vp], c_int),

@@ -129,7 +129,8 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
         const int cq = u % CQ, w = (u / CQ) % N, hq = u / (CQ * N);
 #pragma unroll
         for (int e = 0; e < PX; ++e)
-          pre[k][e] = ld16<Chunk>(xsrc + ((size_t)(b * N + hq * PX + e) * N + w) * Cs_ + cs0 + cq * EPC);
+          pre[k][e] = p.x_blocked ? ld16<Chunk>(xsrc + (((size_t)b * (Cs_ / EPC) + cs0 / EPC + cq) * N * N + (hq * PX + e) * N + w) * EPC)
+                                  : ld16<Chunk>(xsrc + ((size_t)(b * N + hq * PX + e) * N + w) * Cs_ + cs0 + cq * EPC);
       }
     }
   };
@@ -422,7 +423,9 @@ __global__ void __launch_bounds__(256) k_af_act_plane(AfP<T> p) {
       for (int i = tid; i < N * N * CPP; i += NT) {
         const int pix = i / CPP, q = i - pix * CPP;
         const int h = pix / N, w = pix - h * N;
-        st16_out<Chunk>(p.y + ((size_t)b * N * N + pix) * Ct + c0 + q * EPC, ld16<Chunk>(Ys + h * YRP + w * CH + q * EPC));
+        T* dst = p.y_blocked ? p.y + (((size_t)b * (Ct / EPC) + c0 / EPC + q) * N * N + pix) * EPC
+                             : p.y + ((size_t)b * N * N + pix) * Ct + c0 + q * EPC;
+        st16_out<Chunk>(dst, ld16<Chunk>(Ys + h * YRP + w * CH + q * EPC));
       }
     }
     stamp(9);
@@ -1310,7 +1313,7 @@ static int launch_af_small(const AfP<T>& p, hipStream_t st) {
 template <typename T>
 static int af_act_dispatch(const void* x1, int C1, const void* x2, int C2, const GnStats& gs, const float* gamma,
                            const float* beta, int G, float eps, const float* U, const float* D, const void* packed,
-                           void* y, int B, int N, hipStream_t st) {
+                           void* y, int B, int N, hipStream_t st, int x_layout = 0, int y_layout = 0) {
   AfP<T> p;
   p.packed = packed;
   p.eps = eps;
@@ -1319,6 +1322,8 @@ static int af_act_dispatch(const void* x1, int C1, const void* x2, int C2, const
   p.trace = g_af_trace;
   static const int s_stagger = getenv("AFLDM_AF_STAGGER") ? atoi(getenv("AFLDM_AF_STAGGER")) : 0;
   p.stagger = s_stagger;
+  p.y_blocked = y_layout == 1 ? 1 : 0;
+  p.x_blocked = x_layout == 1 ? 1 : 0;
   // bit mask 4 / 8: plane sizes run on the VALU kernel instead of the Kronecker MFMA kernel.  N = 4 (default): one thread
   // per plane with the loop over the upsampled rows fully unrolled (all 64 coefficients in SGPRs) beats the MFMA form,
   // whose workgroups each stage a 64 KB constant image: 5.251 -> 5.229 ms/step (same box).  N = 8 needs 256 coefficients
@@ -1539,6 +1544,23 @@ extern "C" int afldm_af_act(const void* x1, int C1, const void* x2, int C2, cons
   if (dtype == AFLDM_BF16) return af_act_dispatch<bf16>(x1, C1, x2, C2, gs, gamma, beta, G, eps, U, D, packed, y, B, N, st);
   set_error("afldm_af_act: unknown dtype %d", dtype);
   return AFLDM_EDTYPE;
+}
+
+// afldm_af_act with the tensors in 8-channel blocks (layout 1 of afldm_conv_args): N = 16 / 32 (the plane kernel), bf16
+extern "C" int afldm_af_act_c8(const void* x1, int C1, const void* x2, int C2, const float* stats1, int S1,
+                               const float* stats2, int S2, const float* gamma, const float* beta, int G, float eps,
+                               const float* U, const float* D, const void* packed, void* y, int B, int N, int dtype,
+                               int x_layout, int y_layout, afldm_stream_t stream) {
+  AFLDM_REQUIRE(x1 && U && D && y && packed, AFLDM_ENULL, "afldm_af_act_c8: NULL pointer");
+  AFLDM_REQUIRE(dtype == AFLDM_BF16 && (N == 16 || N == 32), AFLDM_ESHAPE, "afldm_af_act_c8: bf16 planes of 16^2 / 32^2 only (N=%d dtype=%d)", N, dtype);
+  AFLDM_REQUIRE((x_layout == 0 || x_layout == 1) && (y_layout == 0 || y_layout == 1) && (x_layout == 0 || C2 == 0), AFLDM_ESHAPE,
+                "afldm_af_act_c8: layouts are 0 / 1, a blocked input is a single tensor");
+  AFLDM_REQUIRE(C1 > 0 && C2 >= 0 && (C2 == 0 || x2) && C1 % 16 == 0 && C2 % 16 == 0 && B > 0, AFLDM_ESHAPE, "afldm_af_act_c8: bad C1=%d C2=%d B=%d", C1, C2, B);
+  AFLDM_REQUIRE(!stats1 || (gamma && beta && G > 0 && (C1 + C2) % G == 0 && S1 > 0 && (C2 == 0 || (stats2 && S2 > 0))), AFLDM_ESHAPE,
+                "afldm_af_act_c8: GroupNorm fusion needs gamma/beta, statistics of both tensors and C %% G == 0 (C=%d G=%d)", C1 + C2, G);
+  AFLDM_REQUIRE(aligned16(x1) && aligned16(x2) && aligned16(y), AFLDM_EALIGN, "afldm_af_act_c8: pointers must be 16-byte aligned");
+  const GnStats gs{stats1, stats2, C1, C2, S1, S2};
+  return af_act_dispatch<bf16>(x1, C1, x2, C2, gs, gamma, beta, G, eps, U, D, packed, y, B, N, (hipStream_t)stream, x_layout, y_layout);
 }
 
 extern "C" size_t afldm_af_pack_bytes(int N, int dtype) {

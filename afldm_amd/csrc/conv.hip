@@ -2093,10 +2093,31 @@ static void fill_convp(const afldm_conv_args* a, ConvP& p) {
   }
   p.xcd_gn = 0;
   p.y_norm = nullptr; p.ngamma = nullptr; p.nbeta = nullptr; p.ncpg = 1; p.neps = 0.f;
+  p.x_c8 = a->x_layout == 1 ? 1 : 0;
+  p.y_c8 = a->y_layout == 1 ? 1 : 0;
+}
+
+// 8-channel-block operands (afldm_conv_args.x_layout / y_layout = 1): only where afldm_conv2d is ONE halo-patch launch with the
+// whole K per workgroup, bf16, tiles inside one sample and the one-pass bf16 epilogue (no second output, NHWC residual is fine)
+template <typename T>
+static bool c8_ok(const afldm_conv_args* a) {
+  if (sizeof(T) != 2 || a->C2 != 0 || a->x2 || a->y2 || a->out_mode != 0 || a->y_norm || a->y_ld != a->Cout || a->Cout % 8 || a->C1 % 64) return false;
+  // (the conditions of plan_h3 below: one k_conv3h launch, statistics - if any - from its epilogue; callers pass whole batches:
+  //  afldm_conv2d_c8_ok checks the batch chunking)
+  if (a->w_batch_stride || a->defer_reduce || a->KS != 3 || lin_wreg_bm(a) || skinny_stats_splits(a)) return false;
+  const Exec ex = resolve_exec<T>(a);
+  if (ex.pl.kind != 0 || kVariants[ex.vid].ver != 6 || ex.splitk != 1 || ex.fused) return false;
+  if (a->stats_out) {
+    int S = 0;
+    if (stats_mode<T>(a, ex, &S) != ST_EPILOGUE) return false;
+  }
+  return a->H == a->W && a->W <= 32 && a->H * a->W >= kVariants[ex.vid].bm;
 }
 
 template <typename T>
 static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
+  AFLDM_REQUIRE((a->x_layout == 0 && a->y_layout == 0) || c8_ok<T>(a), AFLDM_ESHAPE,
+                "afldm_conv2d: x_layout / y_layout = 1 (8-channel blocks) is not available for this problem (afldm_conv2d_c8_ok)");
   ConvP p;
   fill_convp<T>(a, p);
   const Exec ex = resolve_exec<T>(a);
@@ -2295,6 +2316,11 @@ extern "C" int afldm_conv2d_variant(const afldm_conv_args* a0) {
   if (skinny_stats_splits(a)) return -16;        // skinny.hip
   if (e.pl.kind != 0) return -1 - e.pl.kind;
   return e.vid | (e.splitk << 8) | (e.fused << 16);
+}
+
+extern "C" int afldm_conv2d_c8_ok(const afldm_conv_args* a) {
+  if (!a || a->dtype != AFLDM_BF16 || conv_validate(a) || conv_batch_chunk(a) != a->B) return 0;
+  return c8_ok<bf16>(a) ? 1 : 0;
 }
 
 extern "C" int afldm_conv2d_norm_ok(const afldm_conv_args* a) {

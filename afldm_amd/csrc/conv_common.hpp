@@ -41,6 +41,11 @@ struct ConvP {
   const float* nbeta;
   int ncpg;
   float neps;
+  // 8-channel-block layout [B][C / EPC][H][W][EPC] (EPC = 16 bytes of elements) instead of NHWC, halo-patch kernel only, one whole
+  // K per workgroup, tiles inside one sample: x_c8 for the pixel operand (the patch loader reads 16-byte chunks either way),
+  // y_c8 for the output rows.  The tensors between the alias-free activations and the 3x3 convolutions of a ResnetBlock2D
+  // travel in this layout: an activation item (8 / 16 channels of one sample) is then one / two contiguous runs.
+  int x_c8, y_c8;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;

@@ -25,6 +25,11 @@ from .. import aql, ops
 # 0 (default) between the second activation and conv2, 1 behind the first activation, 2 in front of it.  Same results;
 # with an AQL policy armed (afldm_amd/aql.py) the launch marked `independent` runs beside its neighbour.
 _SC_ORDER = int(os.environ.get("AFLDM_SHORTCUT_ORDER", "0"))
+# Edges of a ResnetBlock2D that travel in 8-channel blocks at the 32^2 / 16^2 levels: 1 act1 -> conv1, 2 conv1 -> act2, 4 act2 -> conv2.
+# Default 5: the activations WRITE blocks (an item's output is one contiguous run: -9 % per launch) and the convolutions read
+# them; a convolution writing blocks loses more in its epilogue (16-byte pieces to 24 planes per row) than the activation
+# behind it gains: 4.804 (0) / 4.785 (7) / 4.827 (2) / 4.754 (5) ms/step, same box (profiles/r05/c8_layout_ab.txt).
+_C8_EDGES = int(os.environ.get("AFLDM_C8_EDGES", "5"))
 
 
 def _pair(x):
@@ -277,7 +282,29 @@ class ResnetBlock2D(nn.Module):
         if self.use_in_shortcut:
             self.conv_shortcut = nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0, bias=True)
 
-    def _norm_act(self, norm, x):
+    def _c8_plan(self, input_tensor, temb_proj):
+        """(conv1 takes / writes 8-channel blocks, conv2 takes them): the layout of the tensors between this block's
+        alias-free activations and its 3x3 convolutions at the 32^2 / 16^2 levels (ops._C8; afldm_conv2d_c8_ok)."""
+        from ..af_modules.af_blocks import WarpedNonlinearity
+        x1, x2 = _pair(input_tensor)
+        if (not ops._C8 or x1.ndim != 4 or x1.dtype != torch.bfloat16 or x1.shape[1] != x1.shape[2] or x1.shape[1] not in (16, 32)
+                or not isinstance(self.nonlinearity, WarpedNonlinearity) or not self.nonlinearity.fused_silu
+                or tuple(self.conv1.kernel_size) != (3, 3) or tuple(self.conv2.kernel_size) != (3, 3)):
+            return False, False
+        B, N = x1.shape[0], x1.shape[1]
+        cin = x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
+        key = (B, N, cin, x1.device)
+        cache = self.__dict__.setdefault("_afldm_c8", {})
+        if key not in cache:
+            w1, b1 = packed_conv(self.conv1, x1.dtype)
+            w2, b2 = packed_conv(self.conv2, x1.dtype)
+            a_in = torch.empty((B, N, N, cin), dtype=x1.dtype, device=x1.device)
+            h_in = torch.empty((B, N, N, self.out_channels), dtype=x1.dtype, device=x1.device)
+            cache[key] = (ops.conv2d_c8_ok(a_in, w1, b1, temb=temb_proj, temb_stride=0),
+                          ops.conv2d_c8_ok(h_in, w2, b2, residual=h_in))
+        return cache[key]
+
+    def _norm_act(self, norm, x, out_c8=False):
         """norm -> self.nonlinearity fused: GroupNorm statistics, then either the fused
         GN + WarpedNonlinearity kernel (alias-free model) or GN + SiLU."""
         from ..af_modules.af_blocks import WarpedNonlinearity
@@ -286,7 +313,7 @@ class ResnetBlock2D(nn.Module):
         stats = ops.gn_stats(x1, norm.num_groups, x2=x2)
         if isinstance(self.nonlinearity, WarpedNonlinearity):
             if self.nonlinearity.fused_silu:
-                return ops.af_act(x1, x2, stats, gamma, beta, norm.num_groups, norm.eps)
+                return ops.af_act(x1, x2, stats, gamma, beta, norm.num_groups, norm.eps, out_c8=out_c8)
             # a wrapped module other than SiLU: GroupNorm pass, then the module's own (unfused) alias-free form
             return self.nonlinearity(ops.gn_apply(x1, stats, gamma, beta, norm.num_groups, norm.eps, act=0, x2=x2))
         return ops.gn_apply(x1, stats, gamma, beta, norm.num_groups, norm.eps, act=1, x2=x2)
@@ -378,14 +405,17 @@ class ResnetBlock2D(nn.Module):
             res = conv_forward(self.conv_shortcut, input_tensor) if self.conv_shortcut is not None else x1
             assert self.conv_shortcut is not None or x2 is None
             return self._norm_act_conv(self.norm2, h, self.conv2, residual=res, want_stats=True)
+        c8_1, c8_2 = self._c8_plan(input_tensor, temb_proj)
+        # which of the three edges travel in blocks (AFLDM_C8_EDGES, A/B): 1 act1 -> conv1, 2 conv1 -> act2, 4 act2 -> conv2
+        e1, e2, e3 = c8_1 and bool(_C8_EDGES & 1), c8_1 and bool(_C8_EDGES & 2), c8_2 and bool(_C8_EDGES & 4)
         res = None
         if self.conv_shortcut is not None and _SC_ORDER == 2:
             # shortcut first, the activation beside it (AQL policy: afldm_amd/aql.py; tools/aql_shortcut_ab.py)
             res = conv_forward(self.conv_shortcut, input_tensor)
             with aql.independent("act1"):
-                h = self._norm_act(self.norm1, input_tensor)
+                h = self._norm_act(self.norm1, input_tensor, out_c8=e1)
         else:
-            h = self._norm_act(self.norm1, input_tensor)
+            h = self._norm_act(self.norm1, input_tensor, out_c8=e1)
         if self.conv_shortcut is not None and _SC_ORDER == 1:
             with aql.independent("shortcut"):
                 res = conv_forward(self.conv_shortcut, input_tensor)
@@ -394,8 +424,8 @@ class ResnetBlock2D(nn.Module):
             h = fused
         else:
             # (the convs whose outputs feed a GroupNorm emit its statistics from their epilogue)
-            h = conv_forward(self.conv1, h, temb=temb_proj, temb_stride=temb_stride, want_stats=True)
-            h = self._norm_act(self.norm2, h)
+            h = conv_forward(self.conv1, h, temb=temb_proj, temb_stride=temb_stride, want_stats=True, out_c8=e2)
+            h = self._norm_act(self.norm2, h, out_c8=e3)
         if res is not None:
             pass
         elif self.conv_shortcut is not None:

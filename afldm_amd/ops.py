@@ -262,6 +262,7 @@ def _tensor_stats(x, out=None):
     st = getattr(x, "gn_partial", None)
     if st is not None and out is None:
         return st
+    assert not getattr(x, "c8", False), "a tensor in 8-channel blocks carries its producer's statistics (no stand-alone pass)"
     _dev(x, "x")
     B, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C)
@@ -324,13 +325,37 @@ def gn_apply(x1, stats, gamma, beta, G, eps, act=0, x2=None, out=None):
 
 
 # ----------------------------------------------------------------------------- alias-free ops
-def af_act(x1, x2=None, stats=None, gamma=None, beta=None, G=0, eps=0.0, out=None):
-    """[GroupNorm-apply ->] WarpedNonlinearity(SiLU) on an NHWC tensor (virtual concat x1|x2)."""
+# AFLDM_NO_C8=1: every tensor NHWC (A/B).  Default: inside a ResnetBlock2D of the 32^2 / 16^2 levels the tensors between the
+# alias-free activations and the 3x3 convolutions travel in 8-channel blocks [B][C/8][N][N][8] (`.c8 = True` on the tensor
+# object; same shape, same values): an activation item is a contiguous run then (profiles/r05/c8_layout_ab.txt).
+_C8 = os.environ.get("AFLDM_NO_C8", "0") != "1"
+
+
+def is_c8(x):
+    return bool(getattr(x, "c8", False))
+
+
+def af_act(x1, x2=None, stats=None, gamma=None, beta=None, G=0, eps=0.0, out=None, out_c8=False):
+    """[GroupNorm-apply ->] WarpedNonlinearity(SiLU) on an NHWC tensor (virtual concat x1|x2).  out_c8: the output in
+    8-channel blocks (tagged `.c8`); an input tagged `.c8` is read in that layout (N = 16 / 32, bf16)."""
     C1, x2, C2 = _cat_args(x1, x2)
     B, N, N2, _ = x1.shape
     assert N == N2, "the reference's ideal filters assume square planes (ideal_lpf.py:80)"
     if out is None:
         out = torch.empty((B, N, N, C1 + C2), dtype=x1.dtype, device=x1.device)
+    if out_c8 or is_c8(x1):
+        assert N in (16, 32) and x1.dtype == torch.bfloat16 and (x2 is None or not is_c8(x1)) and not is_c8(x2)
+        U, D = filter_matrices(N, x1.device)
+        packed = packed_filters(N, x1.dtype, x1.device)
+        p1, S1, p2, S2 = _stats_ptrs(stats)
+        tok = _begin()
+        check(lib.afldm_af_act_c8(ptr(x1), C1, ptr(x2), C2, p1, S1, p2, S2, ptr(gamma), ptr(beta), int(G), float(eps), ptr(U),
+                                  ptr(D), ptr(packed), ptr(out), B, N, _code(x1), 1 if is_c8(x1) else 0, 1 if out_c8 else 0,
+                                  stream_ptr()), "af_act_c8")
+        _end(tok, f"af_act_N{N}", 24.0 * N ** 3 * B * (C1 + C2), 2 * B * N * N * (C1 + C2) * x1.element_size())
+        if out_c8:
+            out.c8 = True
+        return out
     if N > 32:
         if x2 is not None:
             raise RuntimeError("afldm_amd: the large-plane activation path (N > 32) does not take a virtual concat")
@@ -707,14 +732,33 @@ def conv_args(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None
     sync = _sync_words(x1.device)
     a.sync, a.sync_bytes = ptr(sync), sync.numel() * 4
     a.keep = (x1, x2, w, bias, temb, residual, out, workspace, sync)
+    a.x_layout = 1 if is_c8(x1) else 0
+    assert not is_c8(x2) and not is_c8(residual), "8-channel-block tensors are convolution inputs only"
     return a
 
 
 _CONV_NORM = os.environ.get("AFLDM_NO_CONV_NORM", "0") != "1"
 
 
+def conv2d_c8_ok(x1, w, bias=None, temb=None, temb_stride=0, residual=None):
+    """True when afldm_conv2d on this problem reads / writes 8-channel blocks (one halo-patch launch, bf16, 16^2 / 32^2)."""
+    if not _C8 or x1.ndim != 4 or x1.dtype != torch.bfloat16 or x1.shape[1] != x1.shape[2] or x1.shape[1] not in (16, 32):
+        return False
+    key = (tuple(x1.shape), tuple(w.shape), temb is not None, residual is not None, str(x1.device))
+    if key not in _C8_OK:
+        a = conv_args(x1, w, bias, None, temb, temb_stride, residual, None)
+        a.y = ptr(x1)                 # (a non-NULL, aligned placeholder: the queries do not dereference it)
+        a.x_layout = 0
+        # (a plan that would split K given the room is not the one-launch halo kernel)
+        _C8_OK[key] = (not lib.afldm_conv2d_workspace(ctypes.byref(a))) and bool(lib.afldm_conv2d_c8_ok(ctypes.byref(a)))
+    return _C8_OK[key]
+
+
+_C8_OK = {}
+
+
 def conv2d(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, out=None, out_mode=0,
-           workspace=None, want_stats=False, temb_mod=0, w_batch_stride=0, norm_out=None):
+           workspace=None, want_stats=False, temb_mod=0, w_batch_stride=0, norm_out=None, out_c8=False):
     """stride-1 'same' conv (KS in {1,3}) / linear on NHWC input with packed OHWI weights.
     out_mode 1 returns the channel-major [B, Cout, H*W] tensor (V^T for attention).
     want_stats: also emit the per-channel GroupNorm partial sums of the output (from the GEMM
@@ -727,6 +771,9 @@ def conv2d(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None, o
             B = x1.shape[0]
             out = torch.empty((B, Cout, x1.numel() // (B * x1.shape[-1])), dtype=x1.dtype, device=x1.device)
     a = conv_args(x1, w, bias, x2, temb, temb_stride, residual, out, out_mode, workspace, temb_mod=temb_mod)
+    if out_c8:
+        a.y_layout = 1
+        out.c8 = True
     a.w_batch_stride = int(w_batch_stride)   # per-sample weights (elements between samples' weight tensors; `w` = sample 0's)
     if out_mode == 1 and x1.ndim == 3:      # [B, T, C] tokens: treat T as the pixel axis
         a.B, a.H, a.W = x1.shape[0], x1.shape[1], 1

@@ -123,6 +123,13 @@ int afldm_af_act(const void* x1, int C1, const void* x2, int C2, const float* st
                  const float* stats2, int S2, const float* gamma, const float* beta, int G, float eps,
                  const float* U, const float* D, const void* packed, void* y, int B, int N, int dtype,
                  afldm_stream_t stream);
+/* The same with x1 and / or y in 8-channel blocks [B][C/8][N][N][8] (x_layout / y_layout = 1; afldm_conv_args.x_layout): N = 16 / 32,
+ * bf16.  An item of the kernel - 8 (16) channels of one sample - is then one (two) contiguous 16 KB run instead of N^2 16-byte
+ * pieces at a stride of 2 C bytes; the 3x3 convolutions of the block read / write the layout directly (afldm_conv2d_c8_ok). */
+int afldm_af_act_c8(const void* x1, int C1, const void* x2, int C2, const float* stats1, int S1, const float* stats2,
+                    int S2, const float* gamma, const float* beta, int G, float eps, const float* U, const float* D,
+                    const void* packed, void* y, int B, int N, int dtype, int x_layout, int y_layout,
+                    afldm_stream_t stream);
 /* A convolution's split-K slabs straight into the GroupNorm that follows it, on the 2x2 / 4x4 planes (diffusers
  * resnet.py / attention_processor.py): the slabs a deferred afldm_conv2d left in its workspace ([nslab][B*N*N][C]
  * fp32) are summed in slab order, + bias[c] + temb[b*temb_stride + c] + residual, rounded to `dtype` (the value the
@@ -279,8 +286,16 @@ typedef struct {
   const float* norm_beta;
   int norm_groups;
   float norm_eps;
+  /* Operand layouts: 0 = NHWC (x [B,H,W,C], y [B,H,W,Cout]); 1 = 8-channel blocks [B][C/8][H][W][8] (bf16; 16 bytes per pixel and
+   * block: what afldm_af_act writes / reads with y_layout / x_layout = 1).  The activation <-> 3x3 convolution tensors inside a
+   * ResnetBlock2D travel in layout 1 where afldm_conv2d_c8_ok(args) == 1: an activation item (8 channels of a sample) is one
+   * contiguous run instead of H*W 16-byte pieces.  Same values, same arithmetic. */
+  int x_layout;
+  int y_layout;
 } afldm_conv_args;
 int afldm_conv2d(const afldm_conv_args* args, afldm_stream_t stream);
+/* 1: afldm_conv2d(args) accepts x_layout = 1 and / or y_layout = 1 (asked with both at 0 or 1: the answer does not depend on them). */
+int afldm_conv2d_c8_ok(const afldm_conv_args* args);
 /* 1: afldm_conv2d(args) will apply the GroupNorm described by norm_gamma / norm_beta / norm_groups / norm_eps into y_norm itself. */
 int afldm_conv2d_norm_ok(const afldm_conv_args* args);
 /* Tuning hook (benchmarks only): force tile/pipeline variant `variant` (>= 0) and/or a split-K

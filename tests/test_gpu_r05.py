@@ -298,3 +298,76 @@ def test_attn_block_fused_out_vs_front_end_plus_to_out(B):
     direct = torch.stack([yd.sum(1), (yd * yd).sum(1)], -1)
     assert y.gn_partial.shape == (B, heads, C, 2)
     assert float((st - direct).abs().max() / direct.abs().max()) <= 1e-5
+
+
+def _c8_to_nhwc(t):
+    B, N, _, C = t.shape
+    return t.reshape(B, C // 8, N, N, 8).permute(0, 2, 3, 1, 4).reshape(B, N, N, C)
+
+
+def _nhwc_to_c8(t):
+    B, N, _, C = t.shape
+    out = t.reshape(B, N, N, C // 8, 8).permute(0, 3, 1, 2, 4).contiguous().view(B, N, N, C)
+    out.c8 = True
+    return out
+
+
+@pytest.mark.parametrize("N,C1,C2,Cout,B", [(32, 192, 0, 192, 64), (16, 384, 192, 384, 64), (32, 384, 192, 192, 8), (16, 192, 0, 384, 16)])
+def test_c8_layout_activation_and_convolution_bit_identical(N, C1, C2, Cout, B):
+    """The 8-channel-block layout [B][C/8][N][N][8] between the alias-free activations and the 3x3 convolutions of a
+    ResnetBlock2D (afldm_af_act_c8, afldm_conv_args.x_layout / y_layout): same values, bit for bit, as the NHWC tensors -
+    activation NHWC -> c8, c8 -> c8; convolution c8 -> c8 (with time embedding and statistics), c8 -> NHWC (with residual)."""
+    from afldm_amd import ops
+    gen = torch.Generator().manual_seed(N + C1 + C2)
+    G, eps = 32, 1e-5
+    x1 = (torch.randn(B, N, N, C1, generator=gen) * 1.3 + 0.2).to(torch.bfloat16).cuda()
+    x2 = (torch.randn(B, N, N, C2, generator=gen) * 0.7 - 0.1).to(torch.bfloat16).cuda() if C2 else None
+    C = C1 + C2
+    gamma, beta = (0.5 + torch.rand(C, generator=gen)).cuda(), (0.3 * torch.randn(C, generator=gen)).cuda()
+    st = ops.gn_stats(x1, G, x2=x2)
+    a_ref = ops.af_act(x1, x2, st, gamma, beta, G, eps)
+    a_c8 = ops.af_act(x1, x2, st, gamma, beta, G, eps, out_c8=True)
+    assert ops.is_c8(a_c8) and torch.equal(_c8_to_nhwc(a_c8), a_ref)
+    w1 = ops.pack_weight((torch.randn(Cout, C, 3, 3, generator=gen) / (3 * C ** 0.5)).cuda(), torch.bfloat16)
+    b1 = (0.1 * torch.randn(Cout, generator=gen)).cuda()
+    temb = (0.5 * torch.randn(B, Cout, generator=gen)).to(torch.bfloat16).cuda()
+    if not ops.conv2d_c8_ok(a_ref, w1, b1, temb=temb, temb_stride=Cout):
+        pytest.skip("no 8-channel-block convolution for this shape (policy)")
+    h_ref = ops.conv2d(a_ref, w1, b1, temb=temb, temb_stride=Cout, want_stats=True)
+    h_c8 = ops.conv2d(a_c8, w1, b1, temb=temb, temb_stride=Cout, want_stats=True, out_c8=True)
+    assert torch.equal(_c8_to_nhwc(h_c8), h_ref) and torch.equal(h_c8.gn_partial, h_ref.gn_partial)
+    g2, be2 = (0.5 + torch.rand(Cout, generator=gen)).cuda(), (0.3 * torch.randn(Cout, generator=gen)).cuda()
+    a2_ref = ops.af_act(h_ref, None, ops.gn_stats(h_ref, G), g2, be2, G, eps)
+    a2_c8 = ops.af_act(h_c8, None, ops.gn_stats(h_c8, G), g2, be2, G, eps, out_c8=True)
+    assert torch.equal(_c8_to_nhwc(a2_c8), a2_ref)
+    w2 = ops.pack_weight((torch.randn(Cout, Cout, 3, 3, generator=gen) / (3 * Cout ** 0.5)).cuda(), torch.bfloat16)
+    res = (torch.randn(B, N, N, Cout, generator=gen)).to(torch.bfloat16).cuda()
+    y_ref = ops.conv2d(a2_ref, w2, None, residual=res, want_stats=True)
+    y_c8in = ops.conv2d(a2_c8, w2, None, residual=res, want_stats=True)
+    assert not ops.is_c8(y_c8in) and torch.equal(y_c8in, y_ref) and torch.equal(y_c8in.gn_partial, y_ref.gn_partial)
+
+
+def test_resnet_block_c8_flow_bit_identical_to_nhwc(monkeypatch):
+    """ResnetBlock2D at the 32^2 level (batch 64, bf16, alias-free): the default flow - tensors between activations and
+    convolutions in 8-channel blocks - equals the all-NHWC flow bit for bit, with and without a conv_shortcut."""
+    from afldm_amd import ops
+    from afldm_amd.models.blocks import ResnetBlock2D
+    from afldm_amd.af_modules.af_api import wrap_nonlinearity
+    torch.manual_seed(3)
+    for cin, cout in ((192, 192), (384, 192)):
+        blk = ResnetBlock2D(in_channels=cin, out_channels=cout, temb_channels=768, groups=32, eps=1e-5).to(torch.bfloat16).cuda()
+        blk.nonlinearity = wrap_nonlinearity(blk.nonlinearity)
+        x = (torch.randn(64, 32, 32, cin) * 1.2).to(torch.bfloat16).cuda()
+        temb = (0.3 * torch.randn(1, cout)).to(torch.bfloat16).cuda()
+        calls = []
+        real = ops.af_act
+        monkeypatch.setattr(ops, "af_act", lambda *a, **k: (calls.append(bool(k.get("out_c8"))), real(*a, **k))[1])
+        monkeypatch.setattr(ops, "_C8", True)
+        y1 = blk(x, temb, 0)
+        assert calls == [True, True], calls          # both activations write 8-channel blocks (AFLDM_C8_EDGES default 5)
+        monkeypatch.setattr(ops, "_C8", False)
+        blk.__dict__.pop("_afldm_c8", None)
+        y0 = blk(x, temb, 0)
+        assert calls[2:] == [False, False]
+        assert torch.equal(y0, y1) and torch.equal(y0.gn_partial, y1.gn_partial)
+        monkeypatch.undo()
