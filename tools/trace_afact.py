@@ -12,7 +12,10 @@ from bench_kernels import timeit
 NAMES = ["start -> item top (constants, fetch issue)", "stats in line + barrier", "tile -> LDS (waits for the fetch)",
          "barrier", "MFMA passes (+ next fetch issue)", "stats fold + barrier", "output staging", "barrier",
          "output stores issued"]
-for N, C in ((32, 192), (16, 384)):
+SHAPES = ((32, 192), (16, 384))
+if os.environ.get("SHAPES"):          # e.g. SHAPES=32x576,32x384
+    SHAPES = tuple(tuple(int(v) for v in sh.split("x")) for sh in os.environ["SHAPES"].split(","))
+for N, C in SHAPES:
     B, G = 64, 32
     x = (torch.randn(B, N, N, C) * 1.3 + 0.2).to(torch.bfloat16).cuda()
     S = 2 if N == 16 else 4
