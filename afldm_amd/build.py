@@ -102,7 +102,11 @@ def build(force=False, verbose=True):
             raise RuntimeError("libafldm_hip.so has unresolved afldm symbols: " + ", ".join(missing[:4]))
         if verbose:
             print("[afldm_amd.build] linked", LIB, flush=True)
-    build_aql(force, verbose)
+    try:
+        build_aql(force, verbose)
+    except Exception as e:          # a diagnostic library (AQL packet view): the product never loads it
+        if verbose:
+            print(f"[afldm_amd.build] libafldm_aql.so not built ({e}); only tools/aql_*.py need it", flush=True)
     return LIB
 
 
