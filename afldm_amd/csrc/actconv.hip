@@ -50,12 +50,6 @@ __device__ __forceinline__ int hw_xcc_id() {
   return v & 7;
 }
 
-template <typename V>
-__device__ __forceinline__ void st16_wt(void* p, const V& v) {       // write-through (sc1) 16-byte store
-  typedef __attribute__((ext_vector_type(4))) unsigned int u4;
-  const u4 d = __builtin_bit_cast(u4, v);
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
-}
 
 constexpr int kActConvMaxCh = 1024;     // channels of one workgroup's items (scale / shift table in LDS)
 constexpr int kActConvMaxG = 64;

@@ -676,7 +676,7 @@ __global__ void __launch_bounds__(NW * 64, LEAN ? 2 : 1) k_attn_fused(AttnFP p) 
 #pragma unroll 4
       for (int row = tr; row < TB; row += RPI) {
         const bf16x8 v = ld16<bf16x8>(sO + row * OROW + ch * 8);
-        st16<bf16x8>(yrow + (size_t)row * C, v);
+        st16_wt<bf16x8>(yrow + (size_t)row * C, v);        // whole rows, write-through (nothing left dirty for the release)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float vr = (float)v[e];

@@ -131,6 +131,14 @@ __device__ __forceinline__ void st16_out(void* p, const V& v) {
 #endif
 }
 
+// 16-byte write-through (sc1) store whatever the translation unit's AFLDM_WT: for outputs that leave as whole contiguous lines
+template <typename V>
+__device__ __forceinline__ void st16_wt(void* p, const V& v) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+  const u4 d = __builtin_bit_cast(u4, v);
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+}
+
 // Pack 4 fp32 values as 4 consecutive T elements and store (8 B for bf16, 16 B for fp32).
 template <typename T>
 __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
