@@ -1357,13 +1357,17 @@ static int af_act_dispatch(const void* x1, int C1, const void* x2, int C2, const
 // statistics (one split per output row).  A <= 8: the plane lives in registers, output row by output row; A = 16 (-> 8): the
 // output accumulates column by column (64 accumulators) - correct but 3x slower than the two passes (128 coefficients do not fit the
 // scalar registers), not dispatched.
-template <typename T, int A, int R>
+// SPLIT: threads per plane (A <= 8 form): thread `part` of a plane computes the output rows [part R / SPLIT, (part + 1) R / SPLIT) -
+// rows are independent chains, so the values are the same bit for bit; the 8 -> 16 site (24 576 planes at batch 64, 3 072 fmas each)
+// was 96 workgroups of one-wave-per-SIMD serial work (17.4 us)
+template <typename T, int A, int R, int SPLIT = 1>
 __global__ void __launch_bounds__(256) k_resample_small(const T* __restrict__ in, T* __restrict__ out, const float* __restrict__ M,
                                                         int B, int C, float* __restrict__ stats) {
-  const size_t total = (size_t)B * C;
+  static_assert(SPLIT == 1 || (A <= 8 && R % SPLIT == 0), "row split");
+  const size_t total = (size_t)B * C * SPLIT;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int b = (int)(i / C), c = (int)(i - (size_t)b * C);
+  const int c = (int)(i % C), bp = (int)(i / C), b = bp / SPLIT, part = bp - b * SPLIT;
   const T* xp = in + (size_t)b * A * A * C + c;
   T* yp = out + (size_t)b * R * R * C + c;
   if constexpr (A <= 8) {
@@ -1373,7 +1377,8 @@ __global__ void __launch_bounds__(256) k_resample_small(const T* __restrict__ in
 #pragma unroll
       for (int w = 0; w < A; ++w) x[h][w] = to_f32(xp[(size_t)(h * A + w) * C]);
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+    for (int rr = 0; rr < R / SPLIT; ++rr) {
+      const int r = part * (R / SPLIT) + rr;
       float t[A];
 #pragma unroll
       for (int w = 0; w < A; ++w) {
@@ -1440,6 +1445,12 @@ static int resample_dispatch(const void* x, const float* M, void* y, float* ws, 
     // the small sites in one launch (k_resample_small; AFLDM_NO_RESAMPLE_SMALL=1: the two-pass form, for A/B)
     static const bool s_off = getenv("AFLDM_NO_RESAMPLE_SMALL") && atoi(getenv("AFLDM_NO_RESAMPLE_SMALL")) != 0;
     const int grid = (int)(((size_t)B * C + 255) / 256);
+    static const int s_split = getenv("AFLDM_RESAMPLE_SPLIT") ? atoi(getenv("AFLDM_RESAMPLE_SPLIT")) : 4;      // threads per plane at 8 -> 16 (1 / 2 / 4; A/B)
+    if (!s_off && N == 8 && Rout == 16 && s_split > 1) {
+      if (s_split == 2) k_resample_small<T, 8, 16, 2><<<(int)(((size_t)B * C * 2 + 255) / 256), 256, 0, st>>>((const T*)x, (T*)y, M, B, C, stats);
+      else k_resample_small<T, 8, 16, 4><<<(int)(((size_t)B * C * 4 + 255) / 256), 256, 0, st>>>((const T*)x, (T*)y, M, B, C, stats);
+      return check_launch("afldm_af_resample(small)");
+    }
 #define AFLDM_RSS(A_, R_)                                                                                     \
   if (!s_off && N == A_ && Rout == R_) {                                                                      \
     k_resample_small<T, A_, R_><<<grid, 256, 0, st>>>((const T*)x, (T*)y, M, B, C, stats);                    \

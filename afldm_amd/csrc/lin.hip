@@ -220,6 +220,9 @@ int lin_wreg_bm(const afldm_conv_args* a) {
   const long long M = (long long)a->B * a->H * a->W;
   const int HW = a->H * a->W;
   if (M < 4096 || M % BM || HW % BM || a->Cout % BN || M * K * 2 >= (1ll << 31)) return 0;
+  // the 8 x 8 level (its only remaining site at batch 64 since the 32^2 / 16^2 projections moved into k_attn_fused): the general
+  // kernel's 128 x 64 tiles are ~2.5 us faster per launch there - 4.619 -> 4.606 ms/step, same box, four alternating rounds
+  if (HW <= 64) return 0;
   // the fused q|k|v projection only: to_out (residual + statistics) measured faster on the general kernel
   if (!a->y2 || a->residual || a->stats_out || a->split_n % BN || a->split_n <= 0 || a->split_n >= a->Cout || HW % 8) return 0;
   if (a->y_ld % 8) return 0;
