@@ -73,6 +73,7 @@ def _load():
         "afldm_gn_apply": ([vp, ip, vp, ip, vp, ip, vp, ip, vp, vp, vp, ip, ip, ip, fp, ip, ip, vp], c_int),
         "afldm_af_act": ([vp, ip, vp, ip, vp, ip, vp, ip, vp, vp, ip, fp, vp, vp, vp, vp, ip, ip, ip, vp], c_int),
         "afldm_af_act_c8": ([vp, ip, vp, ip, vp, ip, vp, ip, vp, vp, ip, fp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp], c_int),
+        "afldm_af_act_const2": ([vp, ip, vp, ip, vp, ip, vp, ip, vp, vp, ip, fp, vp, vp, vp, ip, ip, vp], c_int),
         "afldm_af_act_slabs": ([vp, ip, vp, vp, ip, vp, vp, vp, vp, ip, fp, ip, vp, vp, vp, ip, ip, ip, ip, vp], c_int),
         "afldm_conv_out_fused": ([vp, vp, ip, vp, vp, ip, fp, vp, vp, vp, ip, ip, ip, ip, ip, vp], c_int),
         "afldm_af_pack_bytes": ([ip, ip], c_size_t),
@@ -97,19 +98,8 @@ def _load():
         "afldm_conv2d_variant": ([POINTER(ConvArgs)], c_int),
         "afldm_conv2d_c8_ok": ([POINTER(ConvArgs)], c_int),
         "afldm_conv2d_norm_ok": ([POINTER(ConvArgs)], c_int),
-        "afldm_af_act_conv2d_merged": ([POINTER(AfActArgs), POINTER(ConvArgs)], c_int),
-        "afldm_af_act_conv2d": ([POINTER(AfActArgs), POINTER(ConvArgs), vp], c_int),
-        "afldm_af_act_conv2d_trace": ([vp], c_int),
-        "afldm_trunk_phase_bytes": ([], c_int),
-        "afldm_trunk_trace": ([vp], c_int),
-        "afldm_trunk_run": ([vp, ip, vp, vp, vp, ip, vp, vp, vp, c_size_t, vp], c_int),
-        "afldm_act_conv_act_merged": ([POINTER(AfActArgs), POINTER(ConvArgs), POINTER(AfActArgs)], c_int),
-        "afldm_act_conv_act": ([POINTER(AfActArgs), POINTER(ConvArgs), POINTER(AfActArgs), vp, vp], c_int),
-        "afldm_af_act_conv2d_mode": ([ip], c_int),
         "afldm_attention": ([vp, ip, vp, ip, vp, vp, ip, ip, ip, ip, ip, ip, ip, fp, ip, vp], c_int),
         "afldm_attn_block_fused_supported": ([ip, ip, ip, ip], c_int),
-        "afldm_attn_small_fused_supported": ([ip, ip, ip, ip], c_int),
-        "afldm_attn_small_fused": ([vp, vp, vp, vp, ip, ip, ip, ip, fp, ip, vp], c_int),
         "afldm_attn_block_fused_trace": ([vp], c_int),
         "afldm_af_act_trace": ([vp], c_int),
         "afldm_attn_block_fused": ([vp, vp, ip, vp, vp, ip, fp, vp, vp, vp, ip, ip, ip, ip, fp, ip, vp], c_int),

@@ -12,7 +12,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(OUT_DIR, "libafldm_hip.so")
-SOURCES = ["api.hip", "misc.hip", "gn.hip", "af.hip", "sep.hip", "conv.hip", "conv3h.hip", "actconv.hip", "trunk.hip", "attn.hip", "attnf.hip", "attns.hip", "fir.hip", "lin.hip", "skinny.hip", "convout.hip"]
+SOURCES = ["api.hip", "misc.hip", "gn.hip", "af.hip", "sep.hip", "conv.hip", "conv3h.hip", "attn.hip", "attnf.hip", "fir.hip", "lin.hip", "skinny.hip", "convout.hip"]
+# Experiments (include/afldm_hip_experimental.h): built, bit-identical to the launches they replace, measured slower - a library of
+# their own that links against the product library and that the default path never loads
+EXP_LIB = os.path.join(OUT_DIR, "libafldm_exp.so")
+EXP_SOURCES = ["actconv.hip", "trunk.hip", "attns.hip"]
 ARCH = "gfx950"
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # Kernels whose MFMA accumulators are post-processed by VALU code (softmax, SiLU, GroupNorm affine):
@@ -56,18 +60,20 @@ def build(force=False, verbose=True):
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, h) for h in ("common.hpp", "conv_common.hpp", "conv3h_tile.hpp", "conv3h_body.inc", "af_plane.hpp",
                                                "af_plane_passes.inc")] + [os.path.join(HERE, "..", "include", "afldm_hip.h")]
+    exp_headers = headers + [os.path.join(HERE, "..", "include", "afldm_hip_experimental.h")]
     def command(src, obj):
         mode = os.environ.get("AFLDM_VGPR_FORM", "")
         vg = mode == "all" or (mode != "none" and os.path.basename(src) in VGPR_FORM)
         wt = ["-DAFLDM_WT=1"] if os.path.basename(src) in WRITE_THROUGH and os.environ.get("AFLDM_NO_WT") is None else []
         return [hipcc] + FLAGS + (VGPR_FORM_FLAGS if vg else []) + wt + ["-c", src, "-o", obj]
 
-    objs, jobs = [], []
-    for s in SOURCES:
+    objs, exp_objs, jobs = [], [], []
+    for s in SOURCES + EXP_SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OUT_DIR, s.replace(".hip", ".o"))
-        objs.append(obj)
-        fp = _fingerprint([os.path.basename(c) if os.sep in c else c for c in command(src, obj)], [src] + headers)
+        (exp_objs if s in EXP_SOURCES else objs).append(obj)
+        fp = _fingerprint([os.path.basename(c) if os.sep in c else c for c in command(src, obj)],
+                          [src] + (exp_headers if s in EXP_SOURCES else headers))
         stamp = obj + ".sha256"
         same = os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == fp
         if force or not same:
@@ -88,7 +94,7 @@ def build(force=False, verbose=True):
             for done in ex.map(cc, jobs):
                 if verbose:
                     print("[afldm_amd.build] compiled", os.path.basename(done), flush=True)
-    if force or jobs or _stale(LIB, objs):
+    if force or _stale(LIB, objs):
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -102,6 +108,14 @@ def build(force=False, verbose=True):
             raise RuntimeError("libafldm_hip.so has unresolved afldm symbols: " + ", ".join(missing[:4]))
         if verbose:
             print("[afldm_amd.build] linked", LIB, flush=True)
+    if force or _stale(EXP_LIB, exp_objs + [LIB]):
+        # the experiments call into the product library (afldm_conv2d, afldm_af_act, conv3h_plan, the error string): link against it
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", EXP_LIB] + exp_objs + [f"-L{OUT_DIR}", "-lafldm_hip", "-Wl,-rpath,$ORIGIN"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link of libafldm_exp.so failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print("[afldm_amd.build] linked", EXP_LIB, flush=True)
     try:
         build_aql(force, verbose)
     except Exception as e:          # a diagnostic library (AQL packet view): the product never loads it

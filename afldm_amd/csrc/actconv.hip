@@ -29,6 +29,7 @@
 // cluster, which have neighbouring ids (b, b + 8, b + 16, b + 24): with in-order dispatch a cluster is never partly
 // resident for longer than it takes the dispatcher to reach its last member.
 #include "af_plane.hpp"
+#include "../../include/afldm_hip_experimental.h"      // (libafldm_exp.so: not part of the product library)
 #include "conv3h_tile.hpp"
 
 namespace afldm {

@@ -820,6 +820,14 @@ __global__ void __launch_bounds__(256) k_af_act_small(AfP<T> p) {
         for (int h = 0; h < N; ++h) Y[h][w] = fmaf(D[h * H2 + hp], a, Y[h][w]);
       }
     }
+    if constexpr (N == 2) {
+      // plane-constant form (afldm_af_act_const2): D = C(lpf(4))[::2] is 1/4 everywhere (ideal_lpf.py:17-21: lpf(4) = [1,0,0,0]), so the
+      // four outputs are the same fmaf chain over the same operands - bit-equal - and ONE value per plane is stored: y [B][C]
+      if (p.y_blocked == 2) {
+        p.y[(size_t)b * Ct + c] = from_f32<T>(Y[0][0]);
+        return;
+      }
+    }
 #pragma unroll
     for (int h = 0; h < N; ++h)
 #pragma unroll
@@ -847,6 +855,7 @@ struct AfSlabP {
   T* y_raw;            // optional: the finished (rounded) convolution output itself, for its other consumers
   int nslab, temb_stride, B, C, G, gpb;
   float eps;
+  int compact;         // N = 2, ACT = 1: store the plane-constant result once, y [B][C] (afldm_af_act_slabs act = 2)
 };
 
 // ACT: 1 = WarpedNonlinearity after the GroupNorm (a resnet's norm2 / norm1), 0 = GroupNorm only (Attention.group_norm)
@@ -961,6 +970,12 @@ __global__ void __launch_bounds__(256) k_af_act_slabs(AfSlabP<T> p) {
       for (int wp = 0; wp < H2; ++wp) a = fmaf(D[w * H2 + wp], sz[wp], a);
 #pragma unroll
       for (int h = 0; h < N; ++h) Y[h][w] = fmaf(D[h * H2 + hp], a, Y[h][w]);
+    }
+  }
+  if constexpr (N == 2) {
+    if (p.compact) {                                        // act = 2: the plane-constant value once, y [B][C] (see k_af_act_small)
+      p.y[(size_t)b * p.C + c] = from_f32<T>(Y[0][0]);
+      return;
     }
   }
 #pragma unroll
@@ -1323,7 +1338,7 @@ static int af_act_dispatch(const void* x1, int C1, const void* x2, int C2, const
   p.trace = g_af_trace;
   static const int s_stagger = getenv("AFLDM_AF_STAGGER") ? atoi(getenv("AFLDM_AF_STAGGER")) : 0;
   p.stagger = s_stagger;
-  p.y_blocked = y_layout == 1 ? 1 : 0;
+  p.y_blocked = y_layout == 1 ? 1 : (y_layout == 2 && N == 2 ? 2 : 0);      // 2: plane-constant output of the 2 x 2 kernel
   p.x_blocked = x_layout == 1 ? 1 : 0;
   // bit mask 4 / 8: plane sizes run on the VALU kernel instead of the Kronecker MFMA kernel.  N = 4 (default): one thread
   // per plane with the loop over the upsampled rows fully unrolled (all 64 coefficients in SGPRs) beats the MFMA form,
@@ -1497,6 +1512,7 @@ static int af_act_slabs_launch(const float* slabs, int nslab, const float* bias,
   p.slabs = slabs; p.bias = bias; p.temb = (const T*)temb; p.gamma = gamma; p.beta = beta; p.U = U; p.D = D; p.y = (T*)y;
   p.residual = (const T*)residual; p.y_raw = (T*)y_raw;
   p.nslab = nslab; p.temb_stride = temb_stride; p.B = B; p.C = C; p.G = G; p.eps = eps;
+  p.compact = act == 2 ? 1 : 0;
   const int cpg = C / G;
   int gpb = 0;
   for (int k = 1; k <= G && k <= 32; ++k)
@@ -1517,6 +1533,7 @@ extern "C" int afldm_af_act_slabs(const float* slabs, int nslab, const float* bi
                                   afldm_stream_t stream) {
   AFLDM_REQUIRE(slabs && gamma && beta && y && (!act || (U && D)), AFLDM_ENULL, "afldm_af_act_slabs: NULL pointer");
   AFLDM_REQUIRE(N == 2 || N == 4, AFLDM_ESHAPE, "afldm_af_act_slabs: plane size N=%d not in {2,4}", N);
+  AFLDM_REQUIRE(act >= 0 && act <= 2 && (act != 2 || N == 2), AFLDM_ESHAPE, "afldm_af_act_slabs: act=%d (2 = plane-constant output, N = 2 only)", act);
   AFLDM_REQUIRE(B > 0 && C > 0 && G > 0 && C % G == 0 && nslab >= 1 && nslab <= 64, AFLDM_ESHAPE,
                 "afldm_af_act_slabs: bad shape B=%d C=%d G=%d nslab=%d", B, C, G, nslab);
   AFLDM_REQUIRE(!temb || temb_stride == 0 || temb_stride >= C, AFLDM_ESHAPE, "afldm_af_act_slabs: temb_stride=%d (0 = one row for all samples, else >= C=%d)", temb_stride, C);
@@ -1573,6 +1590,22 @@ extern "C" int afldm_af_act_c8(const void* x1, int C1, const void* x2, int C2, c
   AFLDM_REQUIRE(aligned16(x1) && aligned16(x2) && aligned16(y), AFLDM_EALIGN, "afldm_af_act_c8: pointers must be 16-byte aligned");
   const GnStats gs{stats1, stats2, C1, C2, S1, S2};
   return af_act_dispatch<bf16>(x1, C1, x2, C2, gs, gamma, beta, G, eps, U, D, packed, y, B, N, (hipStream_t)stream, x_layout, y_layout);
+}
+
+// afldm_af_act on 2 x 2 planes with the plane-constant result stored once (y [B][C1 + C2]): see k_af_act_small
+extern "C" int afldm_af_act_const2(const void* x1, int C1, const void* x2, int C2, const float* stats1, int S1,
+                                   const float* stats2, int S2, const float* gamma, const float* beta, int G, float eps,
+                                   const float* U, const float* D, void* y, int B, int dtype, afldm_stream_t stream) {
+  AFLDM_REQUIRE(x1 && U && D && y, AFLDM_ENULL, "afldm_af_act_const2: NULL pointer");
+  AFLDM_REQUIRE(C1 > 0 && C2 >= 0 && (C2 == 0 || x2) && B > 0, AFLDM_ESHAPE, "afldm_af_act_const2: bad C1=%d C2=%d B=%d", C1, C2, B);
+  AFLDM_REQUIRE(!stats1 || (gamma && beta && G > 0 && (C1 + C2) % G == 0 && S1 > 0 && (C2 == 0 || (stats2 && S2 > 0))), AFLDM_ESHAPE,
+                "afldm_af_act_const2: GroupNorm fusion needs gamma/beta, statistics of both tensors and C %% G == 0 (C=%d G=%d)", C1 + C2, G);
+  const GnStats gs{stats1, stats2, C1, C2, S1, S2};
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == AFLDM_F32) return af_act_dispatch<float>(x1, C1, x2, C2, gs, gamma, beta, G, eps, U, D, nullptr, y, B, 2, st, 0, 2);
+  if (dtype == AFLDM_BF16) return af_act_dispatch<bf16>(x1, C1, x2, C2, gs, gamma, beta, G, eps, U, D, nullptr, y, B, 2, st, 0, 2);
+  set_error("afldm_af_act_const2: unknown dtype %d", dtype);
+  return AFLDM_EDTYPE;
 }
 
 extern "C" size_t afldm_af_pack_bytes(int N, int dtype) {

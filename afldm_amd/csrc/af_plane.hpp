@@ -20,7 +20,7 @@ struct AfP {
   float eps;
   unsigned long long* trace;   // diagnostic (k_af_act_plane): [workgroup][wave][item 0 / 1][10] s_memtime stamps, or NULL
   int stagger;                 // A/B (AFLDM_AF_STAGGER): s_sleep units (64 clocks) per co-residency slot a workgroup waits before its first item
-  int y_blocked;               // output layout: 0 = NHWC [B][N][N][C]; 1 = 16-byte channel blocks [B][C/EPC][N][N][EPC] (afldm_conv_args.x_layout = 1)
+  int y_blocked;               // output layout: 0 = NHWC [B][N][N][C]; 2 = one value per plane [B][C] (N = 2: the result is plane-constant); 1 = 16-byte channel blocks [B][C/EPC][N][N][EPC] (afldm_conv_args.x_layout = 1)
   int x_blocked;               // the same for the input x1 (no virtual concat then: C2 == 0)
 };
 

@@ -631,10 +631,23 @@ __global__ void __launch_bounds__(NW * 64, LEAN ? 2 : 1) k_attn_fused(AttnFP p) 
     }
     __syncthreads();
     stamp(10);
+    // The siblings' o rows: published by plain stores acknowledged by the XCD's L2 and awaited through relaxed atomics, so the
+    // loads are the ACQUIRE side - sc1 (agent scope: never served by this CU's vector L1) instead of relying on the L1 not
+    // having seen those lines yet in this kernel.  The L2 serves them as before.
     const bf16* orow = p.o + ((size_t)b * T + trow) * C + hi * 8;
     bf16x8 of[CK];
+    {
+      typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+      u4 raw[CK];
 #pragma unroll
-    for (int kk = 0; kk < CK; ++kk) of[kk] = ld16<bf16x8>(orow + kk * 16);
+      for (int kk = 0; kk < CK; ++kk) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(raw[kk]) : "v"(orow + kk * 16) : "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int kk = 0; kk < CK; ++kk) {
+        asm volatile("" : "+v"(raw[kk]));                     // (ties every use to the wait above)
+        of[kk] = __builtin_bit_cast(bf16x8, raw[kk]);
+      }
+    }
     f32x16 acc[NTL];
 #pragma unroll
     for (int tl = 0; tl < NTL; ++tl) {

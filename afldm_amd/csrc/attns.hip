@@ -16,6 +16,7 @@
 //     the weights rounded to bf16 before P V (k_attn's rounding points), one rounding of the output, 48 contiguous bytes per
 //     token.  No workgroup barrier after the weights have landed; q | k | v never exist in memory.
 #include "common.hpp"
+#include "../../include/afldm_hip_experimental.h"      // (libafldm_exp.so: not part of the product library)
 
 namespace afldm {
 

@@ -27,6 +27,7 @@
 // a second cooperative launch in flight on another stream could starve both (DenoiseEngine(cooperative=False) for
 // concurrent engines).
 #include "conv_common.hpp"
+#include "../../include/afldm_hip_experimental.h"      // (libafldm_exp.so: not part of the product library)
 
 namespace afldm {
 

@@ -68,6 +68,9 @@ class DenoiseEngine:
         nb = int(os.environ.get("AFLDM_BRANCHES", branches))
         self.branches = nb if nb > 1 and batch_size % nb == 0 else 1
         self._side = [torch.cuda.Stream() for _ in range(self.branches - 1)]
+        if self.branches > 1:
+            from . import trunk
+            trunk.block("DenoiseEngine with parallel branches")      # (the experimental cooperative trunk needs the GPU to itself)
         # counters of in-kernel reductions / cluster hand-overs: private to this engine (one per branch), so that its
         # captured graphs can replay next to another engine's on a different stream
         self._sync = [ops.new_sync_buffer(dev) for _ in range(self.branches)]
@@ -108,6 +111,7 @@ class DenoiseEngine:
             self._step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self.check_errors()                           # (the warm-up step ran every hand-over once: free to look, we just synchronised)
         self.step_idx.fill_(-1)
         self.lat.copy_(keep)
         g = torch.cuda.CUDAGraph()
@@ -124,6 +128,23 @@ class DenoiseEngine:
             self.graph_multi = gm
         self.step_idx.fill_(-1)
         self.lat.copy_(keep)
+
+    def check_errors(self):
+        """Read (and clear) the error words of this engine's sync buffers.  The attention block's in-launch hand-over
+        (afldm_attn_block_fused_out, csrc/attnf.hip phase C) gives up after a bounded spin instead of hanging the device and
+        then finishes on incomplete data: that must never pass silently.  On a hit the fused tail is switched off
+        for the process, this engine's graphs are dropped (the next step re-captures on the two-launch path) and a
+        RuntimeError says that the latents of this run are invalid.  Synchronises."""
+        sk, ho = ops.sync_errors(self._sync)
+        if not (sk or ho):
+            return
+        self.graph = self.graph_multi = None
+        if ho:
+            ops._FUSED_ATTN_OUT = False
+        raise RuntimeError(
+            f"afldm_amd: an in-launch hand-over gave up (split-K word {sk}, hand-over word {ho}: 1 = a workgroup waited out its "
+            "cluster, 2 = a cluster straddled XCDs): the latents of this run are INVALID.  The fused attention tail is now off "
+            "(two launches per block); run again.  Causes: a CU mask / partitioned device, or many concurrent heavy streams.")
 
     def refresh_if_stale(self):
         """The captured graphs hold the packed-weight pointers and the time-embedding table of the model AS IT WAS at
@@ -169,4 +190,6 @@ class DenoiseEngine:
     def run(self, latents):
         self.reset(latents)
         self.step(self.n)
-        return self.lat.clone()
+        out = self.lat.clone()
+        self.check_errors()                           # one 8-byte read per run: a run whose hand-over failed must not return latents
+        return out

@@ -115,6 +115,29 @@ def packed_conv_dense2x2(conv, dtype, C1, C2):
     return cache[key]
 
 
+# The alias-free activation of a 2x2 plane is plane-constant (lpf(4) = [1,0,0,0]: reference ideal_lpf.py:17-21), so the 3x3 convolutions
+# behind it are dense layers over Cin columns with tap-summed weights (packed_conv_dense2x2_const): a quarter of the 2x2 level's weight
+# bytes (330 -> 83 MB per step).  AFLDM_NO_CONST2=1: the full flattened-plane form (A/B).
+_CONST2 = os.environ.get("AFLDM_NO_CONST2", "0") != "1"
+
+
+def packed_conv_dense2x2_const(conv, dtype):
+    """A 3x3 'same' convolution of a PLANE-CONSTANT 2x2 input a[b, c] (the output of WarpedNonlinearity at N = 2): output pixel
+    p = (oh, ow) sees every input pixel q through tap (ih - oh + 1, iw - ow + 1), and all four carry the same value, so
+    y[b, (p, n)] = sum_c (sum_q W[n, c, tap(p, q)]) a[b, c]: the dense layer of packed_conv_dense2x2 with its four column blocks
+    added up - Ws[(p, n), c] = W[n, c, 1-oh : 3-oh, 1-ow : 3-ow].sum().  Summed in fp64, rounded once to `dtype`."""
+    cache = conv.__dict__.setdefault("_afldm_cache", {})
+    key = ("dense2x2_const", dtype)
+    if key not in cache:
+        W = conv.weight.detach().double()                      # [Cout, Cin, 3, 3]
+        assert tuple(W.shape[2:]) == (3, 3)
+        blocks = [W[:, :, 1 - oh:3 - oh, 1 - ow:3 - ow].sum((2, 3)) for oh in (0, 1) for ow in (0, 1)]
+        ws = torch.cat(blocks, 0).float().contiguous()         # [4 * Cout, Cin], row = pixel * Cout + n
+        b2 = None if conv.bias is None else conv.bias.detach().float().repeat(4).contiguous()
+        cache[key] = (ops.pack_weight(ws, dtype), b2)
+    return cache[key]
+
+
 def conv_forward(conv: nn.Conv2d, x, **kw):
     """F.conv2d(x, conv.weight, conv.bias, stride 1, 'same') on NHWC (or a virtual concat)."""
     x1, x2 = _pair(x)
@@ -250,6 +273,22 @@ class Upsample2D(nn.Module):
             "nearest-neighbour Upsample2D has no HIP path")
 
 
+def _bias_f32(conv):
+    cache = conv.__dict__.setdefault("_afldm_cache", {})
+    if "bias_f32" not in cache:
+        cache["bias_f32"] = None if conv.bias is None else conv.bias.detach().to(torch.float32).contiguous()
+    return cache["bias_f32"]
+
+
+def _plane2_view(y, B, Cout):
+    """[B, 4 * Cout] output of a flattened-plane dense layer as the NHWC tensor [B, 2, 2, Cout], statistics carried along."""
+    out = y.view(B, 2, 2, Cout)
+    st = getattr(y, "gn_partial", None)
+    if st is not None:                                      # [B, S, 4*Cout, 2] -> per-pixel splits of Cout channels
+        out.gn_partial = st.reshape(B, st.shape[1] * 4, Cout, 2)
+    return out
+
+
 # ----------------------------------------------------------------------------- resnet
 class ResnetBlock2D(nn.Module):
     """diffusers ResnetBlock2D (time_embedding_norm='default', no up/down, output_scale 1).
@@ -282,7 +321,7 @@ class ResnetBlock2D(nn.Module):
         if self.use_in_shortcut:
             self.conv_shortcut = nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0, bias=True)
 
-    def _c8_plan(self, input_tensor, temb_proj):
+    def _c8_plan(self, input_tensor, temb_proj, temb_stride=0):
         """(conv1 takes / writes 8-channel blocks, conv2 takes them): the layout of the tensors between this block's
         alias-free activations and its 3x3 convolutions at the 32^2 / 16^2 levels (ops._C8; afldm_conv2d_c8_ok)."""
         from ..af_modules.af_blocks import WarpedNonlinearity
@@ -293,18 +332,18 @@ class ResnetBlock2D(nn.Module):
             return False, False
         B, N = x1.shape[0], x1.shape[1]
         cin = x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
-        key = (B, N, cin, x1.device)
+        key = (B, N, cin, x1.device, int(temb_stride))
         cache = self.__dict__.setdefault("_afldm_c8", {})
         if key not in cache:
             w1, b1 = packed_conv(self.conv1, x1.dtype)
             w2, b2 = packed_conv(self.conv2, x1.dtype)
             a_in = torch.empty((B, N, N, cin), dtype=x1.dtype, device=x1.device)
             h_in = torch.empty((B, N, N, self.out_channels), dtype=x1.dtype, device=x1.device)
-            cache[key] = (ops.conv2d_c8_ok(a_in, w1, b1, temb=temb_proj, temb_stride=0),
+            cache[key] = (ops.conv2d_c8_ok(a_in, w1, b1, temb=temb_proj, temb_stride=temb_stride),
                           ops.conv2d_c8_ok(h_in, w2, b2, residual=h_in))
         return cache[key]
 
-    def _norm_act(self, norm, x, out_c8=False):
+    def _norm_act(self, norm, x, out_c8=False, out_const=False):
         """norm -> self.nonlinearity fused: GroupNorm statistics, then either the fused
         GN + WarpedNonlinearity kernel (alias-free model) or GN + SiLU."""
         from ..af_modules.af_blocks import WarpedNonlinearity
@@ -313,18 +352,18 @@ class ResnetBlock2D(nn.Module):
         stats = ops.gn_stats(x1, norm.num_groups, x2=x2)
         if isinstance(self.nonlinearity, WarpedNonlinearity):
             if self.nonlinearity.fused_silu:
-                return ops.af_act(x1, x2, stats, gamma, beta, norm.num_groups, norm.eps, out_c8=out_c8)
+                return ops.af_act(x1, x2, stats, gamma, beta, norm.num_groups, norm.eps, out_c8=out_c8, out_const=out_const)
             # a wrapped module other than SiLU: GroupNorm pass, then the module's own (unfused) alias-free form
             return self.nonlinearity(ops.gn_apply(x1, stats, gamma, beta, norm.num_groups, norm.eps, act=0, x2=x2))
         return ops.gn_apply(x1, stats, gamma, beta, norm.num_groups, norm.eps, act=1, x2=x2)
 
-    def _norm_act_conv(self, norm, x, conv, **kw):
+    def _norm_act_conv(self, norm, x, conv, force=False, **kw):
         """conv(nonlinearity(norm(x))): ONE merged launch at the 32^2 / 16^2 levels of the alias-free bf16 model
         (ops.af_act_conv2d, csrc/actconv.hip), else the activation kernel followed by the convolution."""
         from ..af_modules.af_blocks import WarpedNonlinearity
         x1, x2 = _pair(x)
         if (isinstance(self.nonlinearity, WarpedNonlinearity) and self.nonlinearity.fused_silu and x1.ndim == 4
-                and x1.dtype == torch.bfloat16 and x1.shape[1] in ops._ACTCONV_N and tuple(conv.kernel_size) == (3, 3)):
+                and x1.dtype == torch.bfloat16 and (force or x1.shape[1] in ops._ACTCONV_N) and tuple(conv.kernel_size) == (3, 3)):
             gamma, beta = packed_norm(norm)
             stats = ops.gn_stats(x1, norm.num_groups, x2=x2)
             w, b = packed_conv(conv, x1.dtype)
@@ -395,21 +434,70 @@ class ResnetBlock2D(nn.Module):
         y.gn_applied = (hn, next_gn)
         return y
 
+    def _const2_ok(self, input_tensor):
+        from ..af_modules.af_blocks import WarpedNonlinearity
+        x1, x2 = _pair(input_tensor)
+        return (_CONST2 and not os.environ.get("AFLDM_NO_DENSE2X2") and x1.ndim == 4 and x1.shape[1] == 2 and x1.shape[2] == 2
+                and isinstance(self.nonlinearity, WarpedNonlinearity) and self.nonlinearity.fused_silu
+                and tuple(self.conv1.kernel_size) == (3, 3) and tuple(self.conv2.kernel_size) == (3, 3)
+                and x1.shape[-1] % 8 == 0 and (x2 is None or x2.shape[-1] % 8 == 0) and self.out_channels % 8 == 0
+                and self.out_channels % self.norm2.num_groups == 0)
+
+    def _forward_const2(self, input_tensor, temb_proj, temb_stride, next_gn):
+        """The block on 2x2 planes: both alias-free activations are plane-constant there, so they are stored once per plane
+        ([B, C]) and conv1 / conv2 run as dense layers over Cin / Cout columns with tap-summed weights
+        (packed_conv_dense2x2_const) - same function, a quarter of the weight bytes and of the GEMM's K."""
+        x1, x2 = _pair(input_tensor)
+        B, dt, Cout = x1.shape[0], x1.dtype, self.out_channels
+        a = self._norm_act(self.norm1, input_tensor, out_const=True)                 # [B, Cin]
+        w1, b1 = packed_conv_dense2x2_const(self.conv1, dt)
+        g2, be2 = packed_norm(self.norm2)
+        h = None
+        got = None if os.environ.get("AFLDM_NO_FUSED_ACT") else ops.conv2d_slabs(a, w1)
+        if got is not None:                                                          # the plan splits K: the slabs' consumer finishes them
+            slabs, nslab = got
+            h = ops.af_act_slabs(slabs, nslab, _bias_f32(self.conv1), temb_proj, temb_stride, g2, be2, self.norm2.num_groups,
+                                 self.norm2.eps, B, 2, Cout, dt, act=2)
+        else:
+            kw = dict(temb=temb_proj, temb_stride=temb_stride, temb_mod=Cout) if temb_proj is not None else {}
+            y = ops.conv2d(a, w1, b1, want_stats=True, **kw)                         # [B, 4 * Cout]
+            h = self._norm_act(self.norm2, _plane2_view(y, B, Cout), out_const=True)
+        res = conv_forward(self.conv_shortcut, input_tensor) if self.conv_shortcut is not None else x1
+        assert self.conv_shortcut is not None or x2 is None
+        w2, b2 = packed_conv_dense2x2_const(self.conv2, dt)
+        if (next_gn is not None and not os.environ.get("AFLDM_NO_FUSED_ACT") and Cout % next_gn.num_groups == 0
+                and next_gn.num_channels == Cout and res.shape[-1] == Cout and res.is_contiguous()):
+            got = ops.conv2d_slabs(h, w2)
+            if got is not None:                # conv2 (+ shortcut) straight into the attention block's GroupNorm (see _conv2_to_next_norm_fused)
+                slabs, nslab = got
+                gamma, beta = packed_norm(next_gn)
+                hn, y = ops.af_act_slabs(slabs, nslab, _bias_f32(self.conv2), None, 0, gamma, beta, next_gn.num_groups, next_gn.eps,
+                                         B, 2, Cout, dt, residual=res, want_raw=True, act=False)
+                y.gn_applied = (hn, next_gn)
+                return y
+        y = ops.conv2d(h, w2, b2, residual=res.reshape(B, 4 * Cout), want_stats=True)
+        return _plane2_view(y, B, Cout)
+
     def forward(self, input_tensor, temb_proj=None, temb_stride=0, next_gn=None):
         """next_gn: the GroupNorm module of an attention block that consumes this block's output next (the block loops
         pass it): lets conv2 hand its result over already normalised where that saves launches."""
         x1, x2 = _pair(input_tensor)
+        if self._const2_ok(input_tensor):
+            return self._forward_const2(input_tensor, temb_proj, temb_stride, next_gn)
         if x1.ndim == 4 and x1.shape[1] in ops._ACTCONV_N:
             # 32^2 / 16^2 levels, opt-in (AFLDM_ACTCONV_N): norm -> activation -> conv pairs as merged launches where there is a kernel for them
             h = self._norm_act_conv(self.norm1, input_tensor, self.conv1, temb=temb_proj, temb_stride=temb_stride, want_stats=True)
             res = conv_forward(self.conv_shortcut, input_tensor) if self.conv_shortcut is not None else x1
             assert self.conv_shortcut is not None or x2 is None
             return self._norm_act_conv(self.norm2, h, self.conv2, residual=res, want_stats=True)
-        c8_1, c8_2 = self._c8_plan(input_tensor, temb_proj)
+        c8_1, c8_2 = self._c8_plan(input_tensor, temb_proj, temb_stride)
         # which of the three edges travel in blocks (AFLDM_C8_EDGES, A/B): 1 act1 -> conv1, 2 conv1 -> act2, 4 act2 -> conv2
         e1, e2, e3 = c8_1 and bool(_C8_EDGES & 1), c8_1 and bool(_C8_EDGES & 2), c8_2 and bool(_C8_EDGES & 4)
         res = None
-        if self.conv_shortcut is not None and _SC_ORDER == 2:
+        merged1 = bool(ops._ACTCONV_SITES) and x1.ndim == 4 and (x1.shape[1], x1.shape[-1] + (0 if x2 is None else x2.shape[-1])) in ops._ACTCONV_SITES
+        if merged1:
+            h = None
+        elif self.conv_shortcut is not None and _SC_ORDER == 2:
             # shortcut first, the activation beside it (AQL policy: afldm_amd/aql.py; tools/aql_shortcut_ab.py)
             res = conv_forward(self.conv_shortcut, input_tensor)
             with aql.independent("act1"):
@@ -419,9 +507,13 @@ class ResnetBlock2D(nn.Module):
         if self.conv_shortcut is not None and _SC_ORDER == 1:
             with aql.independent("shortcut"):
                 res = conv_forward(self.conv_shortcut, input_tensor)
-        fused = self._conv1_norm2_act_fused(h, temb_proj, temb_stride)
+        fused = self._conv1_norm2_act_fused(h, temb_proj, temb_stride) if h is not None else None
         if fused is not None:
             h = fused
+        elif h is None:
+            # per-site policy (ops._ACTCONV_SITES): norm1 -> activation -> conv1 as the merged launch (experimental library)
+            h = self._norm_act_conv(self.norm1, input_tensor, self.conv1, force=True, temb=temb_proj, temb_stride=temb_stride, want_stats=True)
+            h = self._norm_act(self.norm2, h, out_c8=e3)
         else:
             # (the convs whose outputs feed a GroupNorm emit its statistics from their epilogue)
             h = conv_forward(self.conv1, h, temb=temb_proj, temb_stride=temb_stride, want_stats=True, out_c8=e2)
@@ -465,13 +557,19 @@ class AttnProcessor2_0:
     encoder_hidden_states, when given, is the already group-normed K/V source [Bk, HW, C]
     (the protocol CrossFrameAttnProcessor uses, reference cross_frame_attn.py:125)."""
 
-    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None):
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, kv=None, kv_sink=None):
+        """kv / kv_sink (CrossFrameAttnProcessor with cache_kv): `kv_sink(k, vt)` receives this call's projected keys
+        [B, T, C] (a view) and channel-major values [B, C, T] - the self-attention then runs on the three-launch path, where
+        they exist in memory; `kv = (k, vt)` runs the attention against such a stored pair (Bk divides B) instead of projecting
+        an encoder_hidden_states map: K / V of the stored pass are the same numbers whichever pass projects them."""
         assert attention_mask is None
         B, H, W, C = hidden_states.shape
         gamma, beta = packed_norm(attn.group_norm)
         gn = attn.group_norm
         pre = getattr(hidden_states, "gn_applied", None)
-        if (pre is None and encoder_hidden_states is None and C // attn.heads <= 32
+        plain = kv is None and kv_sink is None
+        assert kv is None or encoder_hidden_states is None
+        if (plain and pre is None and encoder_hidden_states is None and C // attn.heads <= 32
                 and ops.attn_block_fused_ok(hidden_states.view(B, H * W, C), attn.heads, gn.num_groups)):
             # 32^2 / 16^2 levels, bf16: GroupNorm-apply + q | k | v projection + attention in ONE launch (csrc/attnf.hip)
             stats = ops.gn_stats(hidden_states, gn.num_groups)
@@ -493,23 +591,29 @@ class AttnProcessor2_0:
         tokens = hn.view(B, H * W, C)
         if C // attn.heads > 32:
             # large head_dim (the VAE mid block: one head of 512): GEMM - row softmax - GEMM per sample
+            assert plain, "kv / kv_sink cover head_dim <= 32 (the UNet's attention blocks)"
             src = tokens if encoder_hidden_states is None else encoder_hidden_states
             q = linear_forward(attn.to_q, tokens)
             k = linear_forward(attn.to_k, src)
             vt = linear_forward(attn.to_v, src, out_mode=1)
             o = ops.attention_dense(q, k, vt, attn.scale)
             return linear_forward(attn.to_out[0], o.view(B, H, W, C), residual=hidden_states, want_stats=True)
-        if encoder_hidden_states is None and ops.attn_small_fused_ok(tokens, attn.heads):
+        if plain and encoder_hidden_states is None and ops.attn_small_fused_ok(tokens, attn.heads):
             # 8^2 / 4^2 levels, bf16: projection + attention in ONE launch on the normalised tokens (csrc/attns.hip)
             w, b = packed_qkv(attn, tokens.dtype, ("q", "k", "v"))
             o = ops.attn_small_fused(tokens, w, b, attn.heads, attn.scale)
             return linear_forward(attn.to_out[0], o.view(B, H, W, C), residual=hidden_states, want_stats=True)
-        if encoder_hidden_states is None:
+        if kv is not None:
+            q = linear_forward(attn.to_q, tokens)
+            k, vt = kv
+        elif encoder_hidden_states is None:
             # fused Q|K|V projection: one GEMM reads the normed tokens once; Q and K land token-major
             # side by side, V channel-major (the attention kernel's V^T operand)
             w, b = packed_qkv(attn, tokens.dtype, ("q", "k", "v"))
             qk, vt = ops.linear_split(tokens, w, b, 2 * C)
             q, k = qk[:, :, :C], qk[:, :, C:]
+            if kv_sink is not None:
+                kv_sink(k, vt)
         else:
             q = linear_forward(attn.to_q, tokens)
             w, b = packed_qkv(attn, tokens.dtype, ("k", "v"))

@@ -7,7 +7,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _exp, _lib
 from ._lib import AfActArgs, ConvArgs, DTYPE_CODE, SepArgs, check, stream_ptr
 
 _FILTER_CACHE = {}
@@ -335,12 +335,25 @@ def is_c8(x):
     return bool(getattr(x, "c8", False))
 
 
-def af_act(x1, x2=None, stats=None, gamma=None, beta=None, G=0, eps=0.0, out=None, out_c8=False):
+def af_act(x1, x2=None, stats=None, gamma=None, beta=None, G=0, eps=0.0, out=None, out_c8=False, out_const=False):
     """[GroupNorm-apply ->] WarpedNonlinearity(SiLU) on an NHWC tensor (virtual concat x1|x2).  out_c8: the output in
-    8-channel blocks (tagged `.c8`); an input tagged `.c8` is read in that layout (N = 16 / 32, bf16)."""
+    8-channel blocks (tagged `.c8`); an input tagged `.c8` is read in that layout (N = 16 / 32, bf16).
+    out_const (N = 2 only): the result of a 2 x 2 plane is plane-constant (lpf(4) = [1,0,0,0], ideal_lpf.py:17-21) - return
+    it once per plane as [B, C] tagged `.const2` (afldm_af_act_const2)."""
     C1, x2, C2 = _cat_args(x1, x2)
     B, N, N2, _ = x1.shape
     assert N == N2, "the reference's ideal filters assume square planes (ideal_lpf.py:80)"
+    if out_const:
+        assert N == 2 and out is None and not is_c8(x1)
+        out = torch.empty((B, C1 + C2), dtype=x1.dtype, device=x1.device)
+        U, D = filter_matrices(2, x1.device)
+        p1, S1, p2, S2 = _stats_ptrs(stats)
+        tok = _begin()
+        check(lib.afldm_af_act_const2(ptr(x1), C1, ptr(x2), C2, p1, S1, p2, S2, ptr(gamma), ptr(beta), int(G), float(eps), ptr(U),
+                                      ptr(D), ptr(out), B, _code(x1), stream_ptr()), "af_act_const2")
+        _end(tok, "af_act_N2", 24.0 * 8 * B * (C1 + C2), B * 5 * (C1 + C2) * x1.element_size())
+        out.const2 = True
+        return out
     if out is None:
         out = torch.empty((B, N, N, C1 + C2), dtype=x1.dtype, device=x1.device)
     if out_c8 or is_c8(x1):
@@ -632,8 +645,10 @@ _SYNC = {}
 _SYNC_SPARE = {}
 
 
-SYNC_WORDS = 32768        # int32 words of a sync buffer: [0, 8192) split-K tile counters, [8192] error word,
-                          # [16384, 32768) cluster hand-over counters of the merged launches (one 128-byte line per sample)
+SYNC_WORDS = 32768        # int32 words of a sync buffer: [0, 8192) split-K tile counters, [8192] split-K error word, [8193] error word
+                          # of the in-launch hand-overs (attention phase C, merged launches: 1 = gave up waiting, 2 = cluster
+                          # straddles XCDs, 3 = a barrier of the experimental cooperative trunk timed out), [8200, 8201] that
+                          # trunk's grid barrier, [16384, 32768) hand-over counters (one 128-byte line per sample)
 _SYNC_OVERRIDE = None
 _SCOPED_SYNC = []
 
@@ -740,14 +755,18 @@ def conv_args(x1, w, bias=None, x2=None, temb=None, temb_stride=0, residual=None
 _CONV_NORM = os.environ.get("AFLDM_NO_CONV_NORM", "0") != "1"
 
 
-def conv2d_c8_ok(x1, w, bias=None, temb=None, temb_stride=0, residual=None):
-    """True when afldm_conv2d on this problem reads / writes 8-channel blocks (one halo-patch launch, bf16, 16^2 / 32^2)."""
+def conv2d_c8_ok(x1, w, bias=None, temb=None, temb_stride=0, residual=None, want_stats=True):
+    """True when afldm_conv2d on this problem reads / writes 8-channel blocks (one halo-patch launch, bf16, 16^2 / 32^2).
+    The probe carries what the real launch will carry - the time-embedding stride and a statistics output (the blocked layouts
+    need the statistics formed in the epilogue, which depends on both: ADVICE r05)."""
     if not _C8 or x1.ndim != 4 or x1.dtype != torch.bfloat16 or x1.shape[1] != x1.shape[2] or x1.shape[1] not in (16, 32):
         return False
-    key = (tuple(x1.shape), tuple(w.shape), temb is not None, residual is not None, str(x1.device))
+    key = (tuple(x1.shape), tuple(w.shape), temb is not None, int(temb_stride), residual is not None, bool(want_stats), str(x1.device))
     if key not in _C8_OK:
         a = conv_args(x1, w, bias, None, temb, temb_stride, residual, None)
         a.y = ptr(x1)                 # (a non-NULL, aligned placeholder: the queries do not dereference it)
+        if want_stats and w.shape[0] % 4 == 0:
+            a.stats_out = ptr(x1)
         a.x_layout = 0
         # (a plan that would split K given the room is not the one-launch halo kernel)
         _C8_OK[key] = (not lib.afldm_conv2d_workspace(ctypes.byref(a))) and bool(lib.afldm_conv2d_c8_ok(ctypes.byref(a)))
@@ -826,6 +845,10 @@ _ACTCONV = os.environ.get("AFLDM_NO_ACTCONV", "0") != "1"
 # and measured SLOWER in the step (profiles/r05/actconv_ab.txt: 4.99 -> 5.01 ms with the 16^2 pairs, 5.09 with 32^2 too);
 # AFLDM_ACTCONV_N=16,32 turns them on (tests call the op directly)
 _ACTCONV_N = tuple(int(v) for v in os.environ.get("AFLDM_ACTCONV_N", "").split(",") if v)
+# per-site policy: "N:Cin,..." - the norm1 -> activation -> conv1 pair of the blocks whose (plane size, input channels) is listed
+# runs as the merged launch, everything else separately (the isolated A/B showed the merged act -> conv ahead only on the
+# concatenated inputs of the 16^2 up blocks: profiles/r05/actconv_ab.txt)
+_ACTCONV_SITES = frozenset(tuple(int(x) for x in v.split(":")) for v in os.environ.get("AFLDM_ACTCONV_SITES", "").split(",") if v)
 
 
 def act_conv_act(x1, x2, pre, w, bias=None, temb=None, temb_stride=0, residual=None, want_stats=False, post=None):
@@ -838,7 +861,7 @@ def act_conv_act(x1, x2, pre, w, bias=None, temb=None, temb_stride=0, residual=N
     Returns (conv_out, post_out) - conv_out carries `.gn_partial` when want_stats or post needs them and `.act_input`
     (the activated input) when pre is given - or None when there is no merged kernel for the chain (the caller runs the
     separate ops).  Bit-identical to them."""
-    if (not _ACTCONV or x1.ndim != 4 or x1.dtype != torch.bfloat16 or x1.shape[1] != x1.shape[2] or x1.shape[1] not in (16, 32)
+    if (not _ACTCONV or not _exp.available() or x1.ndim != 4 or x1.dtype != torch.bfloat16 or x1.shape[1] != x1.shape[2] or x1.shape[1] not in (16, 32)
             or (pre is None and post is None)):
         return None
     C1, x2, C2 = _cat_args(x1, x2)
@@ -889,11 +912,11 @@ def act_conv_act(x1, x2, pre, w, bias=None, temb=None, temb_stride=0, residual=N
         keep += [pp, gamma2, beta2, post_out]
     ra = ctypes.byref(aa) if aa is not None else None
     rp = ctypes.byref(pp) if pp is not None else None
-    if not lib.afldm_act_conv_act_merged(ra, ctypes.byref(a), rp):
+    if not _exp.lib().afldm_act_conv_act_merged(ra, ctypes.byref(a), rp):
         return None
     keep = tuple(keep)
     tok = _begin()
-    check(lib.afldm_act_conv_act(ra, ctypes.byref(a), rp, ptr(post_out), stream_ptr()), "act_conv_act")
+    check(_exp.lib().afldm_act_conv_act(ra, ctypes.byref(a), rp, ptr(post_out), stream_ptr()), "act_conv_act")
     if st is not None:
         out.gn_partial = st
     if tok is not None:
@@ -905,7 +928,7 @@ def act_conv_act(x1, x2, pre, w, bias=None, temb=None, temb_stride=0, residual=N
         name = ("af_act_" if pre is not None else "") + "conv3x3" + ("_af_act" if post is not None else "") + f"_N{N}"
 
         def replay(ra=ra, rp=rp, a=a, post_out=post_out, keep=keep):
-            check(lib.afldm_act_conv_act(ra, ctypes.byref(a), rp, ptr(post_out), stream_ptr()), "act_conv_act")
+            check(_exp.lib().afldm_act_conv_act(ra, ctypes.byref(a), rp, ptr(post_out), stream_ptr()), "act_conv_act")
         _end(tok, name, fl, by, replay=replay)
     if pre is not None:
         out.act_input = act_out          # the activated tensor (kept alive with the output; tests read it)
@@ -969,13 +992,17 @@ def af_act_slabs(slabs, nslab, bias, temb, temb_stride, gamma, beta, G, eps, B, 
     act=True -> GroupNorm + WarpedNonlinearity (conv1 -> norm2 of a resnet), act=False -> GroupNorm only (conv2 ->
     Attention.group_norm).  Returns the [B, N, N, C] result, or (result, raw) with the finished convolution output
     itself when want_raw."""
-    out = torch.empty((B, N, N, C), dtype=dtype, device=slabs.device)
+    const = act == 2       # N = 2: the plane-constant activation stored once, [B, C] tagged `.const2` (af_act out_const)
+    assert not const or N == 2
+    out = torch.empty((B, C) if const else (B, N, N, C), dtype=dtype, device=slabs.device)
     raw = torch.empty((B, N, N, C), dtype=dtype, device=slabs.device) if want_raw else None
     U, D = filter_matrices(N, slabs.device)
     tok = _begin()
     check(lib.afldm_af_act_slabs(ptr(slabs), int(nslab), ptr(bias), ptr(temb), int(temb_stride), ptr(residual), ptr(raw),
-                                 ptr(gamma), ptr(beta), int(G), float(eps), 1 if act else 0, ptr(U), ptr(D), ptr(out), B, C, N,
-                                 _code(out), stream_ptr()), "af_act_slabs")
+                                 ptr(gamma), ptr(beta), int(G), float(eps), 2 if const else (1 if act else 0), ptr(U), ptr(D),
+                                 ptr(out), B, C, N, _code(out), stream_ptr()), "af_act_slabs")
+    if const:
+        out.const2 = True
     _end(tok, f"af_act_N{N}" if act else "gn_apply", 24.0 * N ** 3 * B * C if act else 0.0,
          B * N * N * C * (4 * nslab + out.element_size() * (2 if want_raw else 1)))
     return (out, raw) if want_raw else out
@@ -1075,9 +1102,41 @@ def attn_block_fused_ok(x, heads, G):
 _FUSED_ATTN_OUT = os.environ.get("AFLDM_ATTN_FUSED_OUT", "1") != "0"
 
 
+_HANDOVER_DEVICES = {}
+
+
+def handover_device_ok(device):
+    """The in-launch hand-over of afldm_attn_block_fused_out relies on the dispatcher dealing consecutive workgroup ids round
+    robin to the 8 XCDs of an UNPARTITIONED, UNMASKED MI355X (a sample's 8 head workgroups then share one XCD and its L2):
+    256 CUs visible and no CU mask in the environment.  Anything else (a partitioned device, HSA_CU_MASK / ROC_GLOBAL_CU_MASK)
+    takes the two-launch path."""
+    key = str(device)
+    if key not in _HANDOVER_DEVICES:
+        masked = any(os.environ.get(v) for v in ("HSA_CU_MASK", "ROC_GLOBAL_CU_MASK", "HSA_CU_MASK_SKIP_INIT"))
+        props = torch.cuda.get_device_properties(device)
+        _HANDOVER_DEVICES[key] = (not masked) and props.multi_processor_count == 256
+    return _HANDOVER_DEVICES[key]
+
+
 def attn_block_fused_out_ok(x, heads, G):
     B, T, C = x.shape
-    return bool(_FUSED_ATTN_OUT and lib.afldm_attn_block_fused_out_supported(B, T, C, C // heads, int(G)))
+    return bool(_FUSED_ATTN_OUT and handover_device_ok(x.device)
+                and lib.afldm_attn_block_fused_out_supported(B, T, C, C // heads, int(G)))
+
+
+def sync_errors(bufs, clear=True):
+    """(split-K error, hand-over error) over sync buffers: words 8192 / 8193 (see SYNC_WORDS), read with ONE device
+    synchronisation per buffer.  A non-zero hand-over word means a launch finished on incomplete data: with `clear` the
+    error words AND the hand-over counter lines are zeroed so that later launches start from a clean buffer."""
+    sk = ho = 0
+    for buf in bufs:
+        w = buf[8192:8194].cpu()
+        a, b = int(w[0]), int(w[1])
+        if (a or b) and clear:
+            buf[8192:8194].zero_()
+            buf[16384:].zero_()
+        sk, ho = max(sk, a), max(ho, b)
+    return sk, ho
 
 
 def attn_block_fused_out(x, stats, gamma, beta, G, eps, w_qkv, bias_qkv, heads, scale, w_out, bias_out):
@@ -1136,7 +1195,7 @@ def attn_small_fused_ok(x, heads):
     B, T, C = x.shape
     if T not in _ATTN_SMALL_T:
         return False
-    return bool(lib.afldm_attn_small_fused_supported(B, T, C, int(heads)))
+    return bool(_exp.lib().afldm_attn_small_fused_supported(B, T, C, int(heads)))
 
 
 def attn_small_fused(x, w_qkv, bias_qkv, heads, scale, out=None):
@@ -1146,7 +1205,7 @@ def attn_small_fused(x, w_qkv, bias_qkv, heads, scale, out=None):
     if out is None:
         out = torch.empty_like(x)
     tok = _begin()
-    check(lib.afldm_attn_small_fused(ptr(x), ptr(w_qkv), ptr(bias_qkv), ptr(out), B, T, C, int(heads), float(scale), _code(x),
+    check(_exp.lib().afldm_attn_small_fused(ptr(x), ptr(w_qkv), ptr(bias_qkv), ptr(out), B, T, C, int(heads), float(scale), _code(x),
                                      stream_ptr()), "attn_small_fused")
     d = C // heads
     _end(tok, "attn_small", 2.0 * B * T * 3 * C * C + 4.0 * B * heads * T * T * d, (2 * B * T * C + 3 * C * C) * x.element_size())

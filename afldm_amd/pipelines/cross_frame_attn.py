@@ -54,11 +54,18 @@ class AttnState:
 
 
 class CrossFrameAttnProcessor(AttnProcessor2_0):
-    def __init__(self, attn_state: AttnState, enable_interp=False):
+    """cache_kv (not in the reference; the graph-replayed harness sets it): a STORE pass also keeps the keys / values it
+    projects from its own hidden states, and a LOAD pass attends to them directly instead of group-norming and projecting the
+    stored map again every step (reference cross_frame_attn.py:88-125 recomputes them: same layer, same input, same numbers).
+    Without interpolation only; `maps` is still filled as the reference does."""
+
+    def __init__(self, attn_state: AttnState, enable_interp=False, cache_kv=False):
         super().__init__()
         self.attn_state = attn_state
         self.maps = [dict(), dict()]
+        self.kv = [dict(), dict()]
         self.enable_interp = enable_interp
+        self.cache_kv = bool(cache_kv) and not enable_interp
 
     def _kv_source(self, attn, stored, batch):
         """group-normed [Bk, HW, C] tokens of a stored NHWC map; Bk must divide the batch (the
@@ -80,8 +87,17 @@ class CrossFrameAttnProcessor(AttnProcessor2_0):
         if st == AttnState.IDLE:
             return super().__call__(attn, hidden_states, None, attention_mask, temb)
         if st == AttnState.STORE:
-            self.maps[self.attn_state.store_id][t] = hidden_states.detach().clone()
-            return super().__call__(attn, hidden_states, None, attention_mask, temb)
+            sid = self.attn_state.store_id
+            # (under graph capture the tensor lives in the graph's pool for as long as this dict holds it and nobody writes it
+            #  in place: no copy launch; eager passes keep the reference's clone)
+            capturing = torch.cuda.is_current_stream_capturing()
+            self.maps[sid][t] = hidden_states.detach() if capturing else hidden_states.detach().clone()
+            if not self.cache_kv:
+                return super().__call__(attn, hidden_states, None, attention_mask, temb)
+            return super().__call__(attn, hidden_states, None, attention_mask, temb,
+                                    kv_sink=lambda k, vt: self.kv[sid].__setitem__(t, (k, vt)))
+        if self.cache_kv and t in self.kv[0] and hidden_states.shape[0] % self.kv[0][t][0].shape[0] == 0:
+            return super().__call__(attn, hidden_states, None, attention_mask, temb, kv=self.kv[0][t])
         map0 = self._kv_source(attn, self.maps[0][t], hidden_states.shape[0])
         if not self.enable_interp:
             return super().__call__(attn, hidden_states, map0, attention_mask, temb)

@@ -13,7 +13,7 @@ import os
 
 import torch
 
-from . import ops
+from . import _exp, ops
 from ._lib import check, stream_ptr
 
 # OFF by default: built, correct, deterministic - and 2x SLOWER than the 51 launches it replaces (profiles/r05/trunk_coop.txt:
@@ -73,7 +73,7 @@ def eligible(unet, x):
     from .models import blocks as Bk
     if not _ENABLED or x.dtype != torch.bfloat16 or x.ndim != 4 or x.shape[1] != 2 or x.shape[2] != 2 or x.shape[0] > 64:
         return False
-    if lib_missing():
+    if lib_missing() or _BLOCKED:
         return False
     down, mid, up = unet.down_blocks[-1], unet.mid_block, unet.up_blocks[0]
     C = x.shape[-1]
@@ -95,7 +95,16 @@ def eligible(unet, x):
 
 
 def lib_missing():
-    return not hasattr(ops._lib.lib, "afldm_trunk_run")
+    return not _exp.available()
+
+
+# The cooperative launch needs the GPU to itself (spin grid barriers between resident workgroups): an engine that runs its batch
+# as parallel graph branches blocks it for the process - two persistent kernels would starve each other's barriers.
+_BLOCKED = set()
+
+
+def block(reason):
+    _BLOCKED.add(reason)
 
 
 class LowResTrunk:
@@ -104,7 +113,7 @@ class LowResTrunk:
     def __init__(self, unet, B, C, temb_offsets):
         from .models import blocks as Bk
         dev, dt = unet.device, torch.bfloat16
-        assert ctypes.sizeof(Phase) == ops._lib.lib.afldm_trunk_phase_bytes(), "Phase layout differs from csrc/trunk.hip"
+        assert ctypes.sizeof(Phase) == _exp.lib().afldm_trunk_phase_bytes(), "Phase layout differs from csrc/trunk.hip"
         self.B, self.C = B, C
         self.keep = []
         P4 = 4 * C
@@ -271,7 +280,7 @@ class LowResTrunk:
         out = torch.empty_like(x)
         sync = ops._SYNC_OVERRIDE if ops._SYNC_OVERRIDE is not None else self.sync
         tok = ops._begin()
-        check(ops.lib.afldm_trunk_run(self.program.data_ptr(), self.nphases, ops.ptr(x), ops.ptr(out), temb_ptr, int(temb_stride),
+        check(_exp.lib().afldm_trunk_run(self.program.data_ptr(), self.nphases, ops.ptr(x), ops.ptr(out), temb_ptr, int(temb_stride),
                                       ops.ptr(self.U), ops.ptr(self.D), ops.ptr(sync), sync.numel() * 4, stream_ptr()), "trunk_run")
         ops._end(tok, "trunk_2x2", 0.0, 0.0)
         return out

@@ -10,7 +10,8 @@ N > 1: launched by torch.distributed.run, one rank per GPU, batch-sharded (weak 
 GPU), no per-step communication, ONE RCCL all-gather of the final latents inside the timed
 region.  Rank 0 prints one JSON line.  At N = 1 the same line also carries, timed inside this run: the other
 single-GPU configurations of north_star (batch 1 / 8 bf16, batch 64 / 1 fp32: `other_configs`), BASELINE configs[3]
-(the AF-VAE at 256^2 x 128 with its shift-equivariance check: `vae_c4`; also `--workload vae` on its own), the
+(the AF-VAE at 256^2 x 128 with its shift-equivariance check: `vae_c4`; also `--workload vae` on its own), the north-star
+harness procedure of BASELINE configs[0] on the graph-replayed path (`harness_c1`; `--workload harness`), the
 roofline of the dominant kernel family and the CPU baseline on BASELINE configs[0].
 """
 import argparse
@@ -461,6 +462,66 @@ def vae_workload(batch=128, dtype=torch.bfloat16, passes=3):
                 equivariance=eq, outputs_finite=finite)
 
 
+def harness_c1(dtype=torch.bfloat16, steps=50, offsets=16):
+    """The north-star harness itself (reference scripts/shift_ldm_ffhq.py:49-159 = BASELINE configs[0]'s procedure): one
+    STORE pass at batch 1, `offsets` fractional shifts denoised in LOAD mode, every result decoded by the AF-VAE and compared
+    with the shifted un-shifted image - FFHQ AF-UNet + the full AF-VAE, seeded random weights, no GIF.  Timed on the
+    graph-replayed path (afldm_amd.harness.CrossFrameSampler; the first call captures and is reported as `first_call_s`):
+    wall time per call with its UNet and VAE parts, for the batched LOAD pass (one batch-16 run) and for the reference's
+    one-run-per-offset loop, next to 50 x the plain batch-1 / batch-16 step of the same process."""
+    from afldm_amd.engine import DenoiseEngine
+    from afldm_amd.harness import shift_ldm
+    from afldm_amd.pipelines.ldm_pipeline import MyLDMPipeline
+    from afldm_amd.schedulers.ddim import ffhq_ddim_scheduler
+    dev = torch.device("cuda", torch.cuda.current_device())
+    unet, vae = build_unet(dtype, dev), build_vae(dtype, dev)
+    pipe = MyLDMPipeline(vae, unet, ffhq_ddim_scheduler())
+    pipe.set_progress_bar_config(disable=True)
+    out = {"procedure": f"shift_ldm: STORE pass + {offsets} shifted LOAD passes, {steps} DDIM steps, batch 1, AF-VAE decode of "
+                        f"{1 + offsets} latents, masked metrics (reference scripts/shift_ldm_ffhq.py:85-151)",
+           "dtype": "bf16" if dtype == torch.bfloat16 else "fp32"}
+    for name, batched in (("batched_load", True), ("sequential_load", False)):
+        recs = []
+        for rep in range(3):
+            tm = {}
+            t0 = time.perf_counter()
+            _, errs = shift_ldm(pipe, steps, offsets, output_path=None, generator=torch.Generator().manual_seed(5 + rep),
+                                batch_offsets=batched, reference_exact=False, timings=tm)
+            tm["wall_s"] = time.perf_counter() - t0
+            recs.append(tm)
+        best = min(recs[1:], key=lambda r: r["total_s"])
+        out[name] = dict(total_s=round(best["total_s"], 4), unet_s=round(best["unet_s"], 4), vae_s=round(best["vae_s"], 4),
+                         other_s=round(best.get("other_s", 0.0), 4), first_call_s=round(recs[0]["total_s"], 3),
+                         mask_mse_first_last=[float(f"{errs[0]:.4e}"), float(f"{errs[-1]:.4e}")])
+    # the plain sampler at the two batch sizes of the procedure (no cross-frame processors, graph replay): the yardstick
+    plain = {}
+    for b in (1, offsets):
+        eng = DenoiseEngine(unet, ffhq_ddim_scheduler(), b, steps, use_graph=True)
+        z = torch.randn(b, 4, 32, 32, generator=torch.Generator().manual_seed(1))
+        eng.run(z)
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.run(z)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        plain[b] = median(ts)
+        del eng
+    out["plain_sampler_s"] = {f"batch_{b}": round(v, 4) for b, v in plain.items()}
+    out["unet_part_over_plain"] = round(out["batched_load"]["unet_s"] / (plain[1] + plain[offsets]), 3)
+    # the eager loop that follows the reference statement by statement (use_graph=False), once warm
+    tm = {}
+    shift_ldm(pipe, steps, offsets, output_path=None, generator=torch.Generator().manual_seed(5), reference_exact=False,
+              use_graph=False)
+    shift_ldm(pipe, steps, offsets, output_path=None, generator=torch.Generator().manual_seed(5), reference_exact=False,
+              use_graph=False, timings=tm)
+    out["eager_batched_load"] = dict(total_s=round(tm["total_s"], 4), unet_s=round(tm["unet_s"], 4), vae_s=round(tm["vae_s"], 4))
+    del pipe, unet, vae
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -469,7 +530,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--regions", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
-    ap.add_argument("--workload", default="unet", choices=["unet", "vae"])
+    ap.add_argument("--workload", default="unet", choices=["unet", "vae", "harness"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -495,6 +556,14 @@ def main():
                               "value": r["value"], "unit": "images/s", "n_gpus": 1, "higher_is_better": True,
                               "dtype": args.dtype, "data": "synthetic (seeded random AF-VAE weights, uniform images)",
                               "config": r}), flush=True)
+        return
+
+    if args.workload == "harness":
+        r = harness_c1(dtype=dtype)
+        if rank == 0:
+            print(json.dumps({"metric": "shift_ldm wall seconds per call (STORE + 16 LOAD passes, 50 steps, FFHQ AF-UNet + AF-VAE)",
+                              "value": r["batched_load"]["total_s"], "unit": "s", "n_gpus": 1, "higher_is_better": False,
+                              "dtype": args.dtype, "data": "synthetic (seeded random weights)", "config": r}), flush=True)
         return
 
     B = args.batch
@@ -574,6 +643,11 @@ def main():
                 roof["frac_of_random_operand_peak"] = round(roof["achieved"] / rp, 4)
             out["roofline"] = roof
             out["kernel_families"] = fam
+            fam_sum = sum(f["ms_per_step"] for f in fam.values())
+            out["kernel_families_note"] = (f"every family is timed as a back-to-back HIP-graph replay of its own launches of one step: the families "
+                                           f"sum to {fam_sum:.3f} ms against the {1e3 * dt / args.steps:.3f} ms timed step (MFMA-heavy launches replayed "
+                                           "back to back run slower than interleaved with the step's other kernels), so per-family ms / tflops and "
+                                           "roofline.frac are slightly pessimistic, never optimistic")
         del eng
         if world == 1 and not args.no_extras:
             # north_star: "batch 1/8/64 on 1 GPU" + the reference's precision, and configs[3], driver-timed in this run
@@ -583,6 +657,7 @@ def main():
                                     side_config(64, torch.float32, steps=10), side_config(1, torch.float32)]
             out["concurrent_jobs"] = [concurrent_engines(2), concurrent_engines(3)]
             out["vae_c4"] = vae_workload()
+            out["harness_c1"] = harness_c1()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

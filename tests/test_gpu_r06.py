@@ -1,0 +1,229 @@
+"""Round-6 parity cases on MI355X.
+
+(a) The plane-constant form of the 2x2 level: WarpedNonlinearity of a 2x2 plane leaves one value in all four pixels
+    (reference ideal_lpf.py:17-21: lpf(4) = [1,0,0,0]), so the activation kernels store it once
+    ([B, C]) and the 3x3 convolutions behind it run as dense layers over Cin columns with tap-summed weights
+    (afldm_af_act_const2, afldm_af_act_slabs act = 2, blocks.packed_conv_dense2x2_const).  Asserted: the four pixels of
+    the full form ARE bit-equal and equal the stored value; a ResnetBlock2D on 2x2 planes gives the full form's output
+    within the rounding of one weight sum; the oracle-anchored forwards (test_gpu_unet / test_gpu_r02 / test_gpu_r05) run
+    with the form on by default.
+(b) The north-star harness on the graph path (reference scripts/shift_ldm_ffhq.py:85-151): CrossFrameSampler's STORE /
+    LOAD graphs against the ORACLE's equivariance fixtures (same budgets as the eager tests: 0.2 dB fp32 / 1 dB bf16),
+    against the eager loop, batched against one-run-per-offset, and replay after a new STORE pass.
+"""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_r02 import build_unet, rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+# ----------------------------------------------------------------------------- (a) plane-constant 2x2 level
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_af_act_const2_is_the_full_forms_value(dtype):
+    from afldm_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, C1, C2, G = 5, 96, 48, 8
+    x1 = torch.randn(B, 2, 2, C1, generator=g).cuda().to(dtype)
+    x2 = (torch.randn(B, 2, 2, C2, generator=g) * 2 + 0.5).cuda().to(dtype)
+    gamma = (torch.rand(C1 + C2, generator=g) + 0.5).cuda()
+    beta = (torch.randn(C1 + C2, generator=g) * 0.3).cuda()
+    for a, b in ((x1, None), (x1, x2)):
+        Ct = C1 + (0 if b is None else C2)
+        st = ops.gn_stats(a, G, x2=b)
+        full = ops.af_act(a, b, st, gamma[:Ct].contiguous(), beta[:Ct].contiguous(), G, 1e-5)
+        const = ops.af_act(a, b, st, gamma[:Ct].contiguous(), beta[:Ct].contiguous(), G, 1e-5, out_const=True)
+        assert const.shape == (B, Ct) and getattr(const, "const2", False)
+        for h in range(2):
+            for w in range(2):
+                assert torch.equal(full[:, h, w, :], const), (h, w)
+        # and without normalisation (a bare WarpedNonlinearity)
+        assert torch.equal(ops.af_act(a, b)[:, 1, 0, :], ops.af_act(a, b, out_const=True))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_af_act_slabs_const2(dtype):
+    from afldm_amd import ops
+    g = torch.Generator().manual_seed(4)
+    B, C, G, ns = 6, 192, 32, 3
+    slabs = torch.randn(ns, B * 4, C, generator=g).cuda()
+    bias = torch.randn(C, generator=g).cuda()
+    temb = torch.randn(B, C, generator=g).cuda().to(dtype)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    full = ops.af_act_slabs(slabs, ns, bias, temb, C, gamma, beta, G, 1e-5, B, 2, C, dtype, act=True)
+    const = ops.af_act_slabs(slabs, ns, bias, temb, C, gamma, beta, G, 1e-5, B, 2, C, dtype, act=2)
+    assert const.shape == (B, C)
+    for p in range(4):
+        assert torch.equal(full.view(B, 4, C)[:, p], const)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize("cin,cout,concat,batch", [(96, 96, False, 64), (96, 192, False, 3), (192, 96, True, 64), (192, 96, True, 1)])
+def test_resnet_block_on_2x2_planes_const_form_vs_full_form(monkeypatch, dtype, tol, cin, cout, concat, batch):
+    """ResnetBlock2D (af_api surgery applied) on 2x2 planes: the plane-constant form against the flattened-plane form
+    (AFLDM_NO_CONST2) - same function, weights summed over the taps before the one rounding instead of after the products."""
+    from afldm_amd.af_modules.af_blocks import WarpedNonlinearity
+    from afldm_amd.models import blocks
+    torch.manual_seed(11)
+    blk = blocks.ResnetBlock2D(in_channels=cin, out_channels=cout, temb_channels=64, groups=8, eps=1e-5)
+    blk.nonlinearity = WarpedNonlinearity(blk.nonlinearity)
+    blk = blk.cuda().to(dtype)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(batch, 2, 2, cin, generator=g).cuda().to(dtype)
+    inp = (x[..., :cin // 2].contiguous(), x[..., cin // 2:].contiguous()) if concat else x
+    temb = torch.randn(1, cout, generator=g).cuda().to(dtype)
+    gn = torch.nn.GroupNorm(8, cout).cuda().to(dtype)
+    outs = {}
+    for form in (True, False):
+        monkeypatch.setattr(blocks, "_CONST2", form)
+        blocks.invalidate_packed(blk)
+        for ngn in (None, gn):
+            y = blk(inp, temb.view(-1), 0, next_gn=ngn)
+            assert y.shape == (batch, 2, 2, cout)
+            outs[(form, ngn is not None)] = (y.float().clone(), getattr(y, "gn_partial", None), getattr(y, "gn_applied", None))
+    for k in (False, True):
+        a, b = outs[(True, k)][0], outs[(False, k)][0]
+        r = rel_rms(a, b.cpu().numpy())
+        assert r <= tol, (k, r)
+    # the statistics the const form hands on describe its own output
+    y, st, _ = outs[(True, False)]
+    assert st is not None
+    s = st.double().sum(1)
+    assert torch.allclose(s[..., 0], y.double().sum((1, 2)), rtol=1e-4, atol=1e-3)
+
+
+def test_ffhq_forward_runs_the_const_form(monkeypatch):
+    """The FFHQ forward takes the plane-constant form for all 14 3x3 convolutions of the 2x2 level (7 ResnetBlock2D)."""
+    from afldm_amd import ops
+    calls = []
+    real = ops.af_act
+    monkeypatch.setattr(ops, "af_act", lambda *a, **k: (calls.append(bool(k.get("out_const"))), real(*a, **k))[1])
+    unet, _, _ = build_unet("ffhq", torch.bfloat16)
+    x = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(1)).cuda()
+    y = unet(x, 500).sample
+    assert torch.isfinite(y).all()
+    assert sum(calls) >= 7, sum(calls)
+
+
+# ----------------------------------------------------------------------------- (b) harness on the graph path
+def _sampler_for(unet, steps):
+    from afldm_amd.harness import CrossFrameSampler
+    from afldm_amd.schedulers.ddim import ffhq_ddim_scheduler
+    return CrossFrameSampler(unet, ffhq_ddim_scheduler(), steps)
+
+
+@pytest.mark.parametrize("dtype,budget_db", [(torch.float32, 0.2), (torch.bfloat16, 1.0)])
+def test_ffhq_equivariance_graph_path_vs_oracle(golden, dtype, budget_db):
+    """test_ffhq_equivariance_vs_oracle (tests/test_gpu_r02.py) on the GRAPH path: the STORE pass and the shifted LOAD passes
+    as replayed unrolled graphs with the stored pass's projected K / V (CrossFrameSampler), against the oracle's latents
+    and its masked equivariance MSE (tests/golden/g13_r03.npz; reference shift_ldm_ffhq.py:124-151)."""
+    from afldm_amd.pipelines.cross_frame_attn import get_unet_attn_processors, set_unet_attn_processor
+    from afldm_amd.shift_utils.metrics import mask_mse
+    from afldm_amd.shift_utils.shifters import ImageShifter
+    g = golden("g13_r03.npz")
+    x = torch.from_numpy(g["ffhq_x"]).cuda()
+    unet, _, _ = build_unet("ffhq", dtype)
+    smp = _sampler_for(unet, 4)
+    prev = smp.install()
+    try:
+        base = smp.run(x, load=False)
+        tol = 1e-3 if dtype == torch.float32 else 5e-2
+        assert rel_rms(base.float(), g["ffhq_equiv_base"]) <= tol
+        for k, tj in enumerate((0.375, 1.0)):
+            xs, mask = ImageShifter("ideal_crop", 8).shift(x, 0, tj)
+            ref, _ = ImageShifter("ideal_crop", 8).shift(base, 0, tj)
+            den = smp.run(xs, load=True)
+            assert rel_rms(den.float(), g[f"ffhq_equiv_lat_{k}"]) <= tol
+            mse, want = float(mask_mse(den, ref, mask)), float(g[f"ffhq_equiv_mse_{k}"])
+            db = 10 * np.log10(mse / want)
+            print(f"[equivariance vs oracle, graph path] {dtype} tj={tj}: mask_mse {mse:.4e}, oracle {want:.4e} ({db:+.3f} dB)")
+            assert abs(db) <= budget_db, (tj, mse, want)
+        assert len(smp.engines) == 2                      # one STORE graph, one LOAD graph (replayed for the second offset)
+        # a second STORE replay (new noise) refreshes what the LOAD graph reads: same as a fresh sampler would give
+        x2 = torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(77)).cuda()
+        base2 = smp.run(x2, load=False)
+        den2 = smp.run(ImageShifter("ideal_crop", 8).shift(x2, 0, 0.375)[0], load=True)
+        assert len(smp.engines) == 2
+    finally:
+        set_unet_attn_processor(unet, dict(prev))
+    fresh = _sampler_for(unet, 4)
+    prev = fresh.install()
+    try:
+        assert torch.equal(fresh.run(x2, load=False), base2)
+        assert torch.equal(fresh.run(ImageShifter("ideal_crop", 8).shift(x2, 0, 0.375)[0], load=True), den2)
+    finally:
+        set_unet_attn_processor(unet, dict(prev))
+    assert all(type(p).__name__ == "AttnProcessor2_0" for p in get_unet_attn_processors(unet).values())
+
+
+@pytest.mark.parametrize("dtype,db_tol", [(torch.float32, 0.2), (torch.bfloat16, 1.0)])
+def test_shift_equivariance_harness_graph_path(golden, dtype, db_tol):
+    """test_shift_equivariance_harness (tests/test_gpu_unet.py: tiny model, oracle fixture g6) on the graph path, the LOAD
+    passes both one by one and as one batch of two."""
+    from test_gpu_unet import build
+    from afldm_amd.pipelines.cross_frame_attn import set_unet_attn_processor
+    from afldm_amd.shift_utils.metrics import mask_mse
+    from afldm_amd.shift_utils.shifters import ImageShifter
+    g = golden("g6_tiny_unet.npz")
+    unet, cfg, _ = build("tiny", dtype)
+    smp = _sampler_for(unet, 4)
+    prev = smp.install()
+    try:
+        x = torch.from_numpy(g["x"])[:1].cuda()
+        base = smp.run(x, load=False)
+        assert rel_rms(base, g["equiv_base"]) <= (1e-3 if dtype == torch.float32 else 5e-2)
+        shifter = ImageShifter("ideal_crop", 8)
+        pairs = [shifter.shift(x, 0, tj) for tj in (0.375, 1.0)]
+        both = smp.run(torch.cat([p[0] for p in pairs], 0), load=True)
+        for k, tj in enumerate((0.375, 1.0)):
+            xs, mask = pairs[k]
+            den = smp.run(xs, load=True)
+            ref, _ = ImageShifter("ideal_crop", 8).shift(base, 0, tj)
+            want = float(g[f"equiv_mse_{k}"])
+            for name, d in (("one by one", den), ("batched", both[k:k + 1])):
+                mse = float(mask_mse(d, ref, mask))
+                assert abs(10 * np.log10(mse / want)) <= db_tol, (name, tj, mse, want)
+    finally:
+        set_unet_attn_processor(unet, dict(prev))
+
+
+def test_shift_ldm_graph_path_matches_eager_loop_and_replays():
+    """afldm_amd.harness.shift_ldm: the default (graph) path against use_graph=False (the loop that follows reference
+    shift_ldm_ffhq.py:85-108 statement by statement) on tiny models - frames and errors agree; a second call with another
+    seed replays the cached graphs and still agrees with the eager loop; the timings dict is filled."""
+    from test_gpu_vae import build_vae
+    from afldm_amd.af_modules.af_api import make_af_unet
+    from afldm_amd.harness import shift_ldm
+    from afldm_amd.models.unet_2d import UNet2DModel
+    from afldm_amd.pipelines.ldm_pipeline import MyLDMPipeline
+    from afldm_amd.schedulers.ddim import ffhq_ddim_scheduler
+    from oracle import configs as oc, unet as ou
+    vae, _, _ = build_vae(torch.float32)
+    ucfg = oc.tiny_unet()
+    unet = UNet2DModel.from_config(ucfg)
+    unet.load_state_dict(ou.randomize_norm_affine(ou.init_unet_params(ucfg, seed=0, conv_out_scale=0.1)))
+    make_af_unet(unet)
+    pipe = MyLDMPipeline(vae, unet.cuda(), ffhq_ddim_scheduler())
+    for seed in (1, 2):
+        tm = {}
+        fr_g, er_g = shift_ldm(pipe, num_inference_steps=3, num_shift_steps=3, output_path=None,
+                               generator=torch.Generator().manual_seed(seed), reference_exact=False, timings=tm)
+        fr_e, er_e = shift_ldm(pipe, num_inference_steps=3, num_shift_steps=3, output_path=None,
+                               generator=torch.Generator().manual_seed(seed), reference_exact=False, use_graph=False)
+        assert len(fr_g) == 3 and tm["unet_s"] > 0 and tm["vae_s"] > 0 and tm["total_s"] >= tm["unet_s"] + tm["vae_s"]
+        for a, b in zip(fr_g, fr_e):
+            assert (a - b).abs().max() <= 2e-4
+        assert np.allclose(er_g, er_e, rtol=2e-3, atol=1e-9), (er_g, er_e)
+        smp = pipe._xframe_sampler
+        assert sorted(smp.engines) == [(False, 1), (True, 3)]
+    # new weights: the sampler notices and re-captures instead of replaying the old model
+    with torch.no_grad():
+        pipe.unet.conv_in.weight.mul_(1.5)
+    fr_g, er_g = shift_ldm(pipe, num_inference_steps=3, num_shift_steps=3, output_path=None,
+                           generator=torch.Generator().manual_seed(2), reference_exact=False)
+    fr_e, er_e = shift_ldm(pipe, num_inference_steps=3, num_shift_steps=3, output_path=None,
+                           generator=torch.Generator().manual_seed(2), reference_exact=False, use_graph=False)
+    for a, b in zip(fr_g, fr_e):
+        assert (a - b).abs().max() <= 2e-4

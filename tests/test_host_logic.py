@@ -23,6 +23,28 @@ def test_library_exports_every_symbol_the_header_declares():
         assert hasattr(_lib.lib, name), f"{name} declared in afldm_hip.h but not exported"
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
     assert _lib.lib.afldm_version() >= 100
+    # the product library carries no experiment: everything it exports is declared in the product header
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in nm.splitlines() if " T afldm_" in l}
+    assert exported == declared, (exported ^ declared)
+
+
+def test_experimental_library_is_separate_and_matches_its_header():
+    """include/afldm_hip_experimental.h <-> libafldm_exp.so (measured-slower designs kept for A/B work): same symbols, none of
+    them in the product header, and importing the package does not load the library."""
+    from afldm_amd import _exp, _lib
+    hdr = open(os.path.join(ROOT, "include", "afldm_hip_experimental.h")).read()
+    decl = r"^(?:int|size_t|const char\s*\*)\s+(afldm_[a-z0-9_]+)\s*\("        # (the prose of the comments cites product calls)
+    declared = set(re.findall(decl, hdr, re.M))
+    product = open(os.path.join(ROOT, "include", "afldm_hip.h")).read()
+    assert len(declared) >= 8 and not (declared & set(re.findall(decl, product, re.M)))
+    assert _exp.available(), "python -m afldm_amd.build also links libafldm_exp.so"
+    code = ("import sys; sys.path.insert(0, %r); import afldm_amd, afldm_amd.ops, afldm_amd.models.unet_2d, afldm_amd.harness; "
+            "print(any('libafldm_exp' in l for l in open('/proc/self/maps')))" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True)
+    assert r.stdout.strip().splitlines()[-1] == "False", r.stdout
+    assert declared == set(_exp.exports()), (declared ^ set(_exp.exports()))
 
 
 def test_filter_matrices_match_oracle_and_reject_bad_sizes():

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch  # noqa: E402
 
-from afldm_amd import _lib, ops  # noqa: E402
+from afldm_amd import _exp, _lib, ops  # noqa: E402
 from bench_actconv import CASES  # noqa: E402
 
 NAMES = {(0, 1): "pre: prologue (constants, statistics, first tile requested)", (1, 2): "pre: activation items",
@@ -43,13 +43,13 @@ def main():
         assert run() is not None
     nwg = B * (N * N // (256 if N == 32 else 128)) * (Cout // 192)
     buf = torch.zeros(nwg, 16, dtype=torch.int64, device=dev)
-    _lib.lib.afldm_af_act_conv2d_trace(buf.data_ptr())
+    _exp.lib().afldm_af_act_conv2d_trace(buf.data_ptr())
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     run()
     e1.record()
     torch.cuda.synchronize()
-    _lib.lib.afldm_af_act_conv2d_trace(None)
+    _exp.lib().afldm_af_act_conv2d_trace(None)
     st = buf.cpu().double()
     used = [i for i in range(12) if float(st[:, i].min()) > 0]
     pre_, post_ = pre, post

@@ -9,7 +9,7 @@ sys.path.insert(0, R)
 sys.path.insert(0, os.path.join(R, "tests"))
 import torch  # noqa: E402
 
-from afldm_amd import _lib, ops, trunk  # noqa: E402
+from afldm_amd import _exp, _lib, ops, trunk  # noqa: E402
 from test_gpu_r02 import build_unet  # noqa: E402
 
 B = int(os.environ.get("B", "64"))
@@ -19,14 +19,14 @@ for _ in range(2):
     unet(x, 501)
 tr = next(v for k, v in unet._afldm_cache.items() if isinstance(k, tuple) and k[0] == "trunk2")
 buf = torch.zeros(tr.nphases, 4, dtype=torch.int64, device="cuda")
-_lib.lib.afldm_trunk_trace(buf.data_ptr())
+_exp.lib().afldm_trunk_trace(buf.data_ptr())
 unet(x, 501)
 torch.cuda.synchronize()
-_lib.lib.afldm_trunk_trace(None)
+_exp.lib().afldm_trunk_trace(None)
 t = buf.cpu().double()
 names = {1: "GEMM", 2: "RED ", 3: "ATTN"}
 prog = bytes(tr.program.cpu().numpy())
-psz = _lib.lib.afldm_trunk_phase_bytes()
+psz = _exp.lib().afldm_trunk_phase_bytes()
 tot_body = tot_bar = 0.0
 for i in range(tr.nphases):
     ph = trunk.Phase.from_buffer_copy(prog[i * psz:(i + 1) * psz])
