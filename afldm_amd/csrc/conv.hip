@@ -531,7 +531,8 @@ __global__ void __launch_bounds__((WGM * WGN + NPROD) * 64, MINW) k_igemm2(ConvP
     for (int i = 0; i < WPW; ++i) {
       const int j = wave + NW * i;
       lds_ptr_t dst = (lds_ptr_t)(sbase + X_STAGE + j * 1024);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, dst, 16, (int)woff[i], (int)wsoff, 0, 0);
+      if (p.w_nt) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, dst, 16, (int)woff[i], (int)wsoff, 0, 2);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, dst, 16, (int)woff[i], (int)wsoff, 0, 0);
     }
     // advance the cursor
     ++is_kt;
@@ -1040,7 +1041,8 @@ __global__ void __launch_bounds__(512, 1) k_igemm3(ConvP p) {
       for (int i = 0; i < WPW; ++i) {
         const int j = wave + NW * i;
         lds_ptr_t dst = (lds_ptr_t)(sbase + X_STAGE + j * 1024);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, dst, 16, (int)woff[i], (int)wsoff, 0, 0);
+        if (p.w_nt) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, dst, 16, (int)woff[i], (int)wsoff, 0, 2);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, dst, 16, (int)woff[i], (int)wsoff, 0, 0);
       }
       if (!live) return;
       ++is_kt;
@@ -2095,6 +2097,7 @@ static void fill_convp(const afldm_conv_args* a, ConvP& p) {
   p.y_norm = nullptr; p.ngamma = nullptr; p.nbeta = nullptr; p.ncpg = 1; p.neps = 0.f;
   p.x_c8 = a->x_layout == 1 ? 1 : 0;
   p.y_c8 = a->y_layout == 1 ? 1 : 0;
+  p.w_nt = 0;       // set per plan (conv_dispatch: a single row tile)
 }
 
 // 8-channel-block operands (afldm_conv_args.x_layout / y_layout = 1): only where afldm_conv2d is ONE halo-patch launch with the
@@ -2179,6 +2182,11 @@ static int conv_dispatch(const afldm_conv_args* a, hipStream_t st) {
       AFLDM_REQUIRE(ver >= 2 && ver <= 4 && p.splitk == 1 && (a->H * a->W) % kVariants[ex.vid].bm == 0, AFLDM_ESHAPE,
                     "afldm_conv2d: w_batch_stride needs H*W a multiple of the %d-row tile of variant %d and no split-K",
                     kVariants[ex.vid].bm, ex.vid);
+    }
+    {
+      // weights that exactly one workgroup per (cout tile, K slice) reads - a single row tile - stream non-temporally
+      static const bool s_nt = !(getenv("AFLDM_NT_WEIGHTS") && atoi(getenv("AFLDM_NT_WEIGHTS")) == 0);
+      p.w_nt = (s_nt && !a->w_batch_stride && p.M <= kVariants[ex.vid].bm) ? 1 : 0;
     }
     launch_variant<T>(ex.vid, p, st);
     rc = check_launch("afldm_conv2d(igemm)");

@@ -46,6 +46,10 @@ struct ConvP {
   // y_c8 for the output rows.  The tensors between the alias-free activations and the 3x3 convolutions of a ResnetBlock2D
   // travel in this layout: an activation item (8 / 16 channels of one sample) is then one / two contiguous runs.
   int x_c8, y_c8;
+  // 1: the weight stream of this launch is read by exactly ONE workgroup per slice (a single row tile: the small batches, the
+  // 2x2 / 4x4 levels) - requested non-temporal (LDS-DMA aux = 2 / `nt` loads) so that it does not displace the activations the
+  // next launches re-read from the L2s (MI355X_MICROARCH "nt-weights"; AFLDM_NT_WEIGHTS=0: off, A/B)
+  int w_nt;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;

@@ -30,6 +30,7 @@ struct SkP {
   float* stats;      // [B][S][N][2] or NULL
   int M, K, C1, N, HW, temb_stride, temb_mod, res_ld, y_ld, stats_S;
   int ns;            // K slices per workgroup (8 / ns cout tiles of 16)
+  int w_nt;          // 1: one 64-row block - every weight byte is read exactly once: non-temporal loads (ConvP::w_nt)
 };
 
 constexpr int SK_WAVES = 8, SK_ROWS = 64, SK_MT = SK_ROWS / 16, SK_U = 4;
@@ -37,7 +38,7 @@ constexpr int SK_WAVES = 8, SK_ROWS = 64, SK_MT = SK_ROWS / 16, SK_U = 4;
 // MTT: row tiles a workgroup can hold (4, or 1 for launches of <= 16 rows); U: K steps per register group - the
 // one-tile form fetches 12 steps at once (a 3072-wide K slice of 384 = ONE load round trip instead of two or three;
 // at batch 1 a dense layer is launch + load latency and little else).
-template <typename T, int MTT, int U>
+template <typename T, int MTT, int U, bool WNT = false>
 __global__ void __launch_bounds__(SK_WAVES * 64) k_skinny(SkP p) {
   typedef Mma<T> MM;
   typedef typename MM::Chunk Chunk;
@@ -80,7 +81,8 @@ __global__ void __launch_bounds__(SK_WAVES * 64) k_skinny(SkP p) {
 #if defined(AFLDM_SK_NOW)                                 // (timing decomposition builds: no weight / no x loads; garbage results)
         a[buf][u] = ld16<Chunk>(xrow[0] + off);
 #else
-        a[buf][u] = ld16<Chunk>(wrow + off);
+        if constexpr (WNT) a[buf][u] = __builtin_nontemporal_load(reinterpret_cast<const Chunk*>(wrow + off));
+        else a[buf][u] = ld16<Chunk>(wrow + off);
 #endif
 #pragma unroll
         for (int mt = 0; mt < MTT; ++mt) {
@@ -228,12 +230,16 @@ int skinny_launch(const afldm_conv_args* a, hipStream_t st) {
   p.temb_stride = a->temb_stride; p.temb_mod = a->temb_mod ? a->temb_mod : a->Cout; p.res_ld = a->res_ld; p.y_ld = a->y_ld;
   p.stats_S = skinny_stats_splits(a);
   p.ns = skinny_slices(a);
+  static const bool s_nt = !(getenv("AFLDM_NT_WEIGHTS") && atoi(getenv("AFLDM_NT_WEIGHTS")) == 0);
+  p.w_nt = (s_nt && p.M <= SK_ROWS) ? 1 : 0;
   const dim3 grid(p.N / (16 * (SK_WAVES / p.ns)), (p.M + SK_ROWS - 1) / SK_ROWS);
   if (p.M <= 16) {
     if (a->dtype == AFLDM_F32) k_skinny<float, 1, 12><<<grid, SK_WAVES * 64, 0, st>>>(p);
+    else if (p.w_nt) k_skinny<bf16, 1, 12, true><<<grid, SK_WAVES * 64, 0, st>>>(p);
     else k_skinny<bf16, 1, 12><<<grid, SK_WAVES * 64, 0, st>>>(p);
   } else {
     if (a->dtype == AFLDM_F32) k_skinny<float, SK_MT, SK_U><<<grid, SK_WAVES * 64, 0, st>>>(p);
+    else if (p.w_nt) k_skinny<bf16, SK_MT, SK_U, true><<<grid, SK_WAVES * 64, 0, st>>>(p);
     else k_skinny<bf16, SK_MT, SK_U><<<grid, SK_WAVES * 64, 0, st>>>(p);
   }
   return check_launch("afldm_conv2d(skinny)");

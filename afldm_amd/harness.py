@@ -176,7 +176,8 @@ def shift_ldm(pipeline, num_inference_steps=50, num_shift_steps=16, output_path=
     synchronisation, no per-site clone launches, the LOAD passes attend to the stored pass's projected K / V); the graphs
     are cached on the pipeline, so the first call pays their capture and later calls (more seeds / images) replay.
     use_graph=False is the eager loop that follows reference shift_ldm_ffhq.py:85-108 statement by statement.
-    timings: a dict that receives the wall time of the UNet passes ('unet_s'), the VAE calls ('vae_s'), everything else
+    timings: a dict that receives the wall time of the UNet passes ('unet_s'), the VAE calls ('vae_s'), the latent / image
+    shifters ('shift_s'), the masked metrics ('metric_s'), frame assembly + device-to-host copies ('frames_s'), everything else
     ('other_s') and 'total_s' (synchronises at the phase boundaries; off when None).
 
     reference_exact=True (the default) follows the reference flow to the letter; reference_exact=False
@@ -246,7 +247,7 @@ def shift_ldm(pipeline, num_inference_steps=50, num_shift_steps=16, output_path=
         mine = parallel.interleaved(num_shift_steps, rank, world)
         frames, errors = {}, {}
         shifted = {i: latent_shifter.shift(init_latent, 0, float(offsets[i])) for i in mine}
-        clock.lap("other_s")
+        clock.lap("shift_s")
         if batch_offsets and len(mine) > 1:
             den_all = denoise(torch.cat([shifted[i][0] for i in mine], 0), load=True)
             dens = {i: den_all[k:k + 1] for k, i in enumerate(mine)}
@@ -257,15 +258,16 @@ def shift_ldm(pipeline, num_inference_steps=50, num_shift_steps=16, output_path=
             tj = float(offsets[i])
             den, mask = dens[i], shifted[i][1]
             ref_lat, _ = latent_shifter.shift(denoised, 0, tj)
+            clock.lap("shift_s")
             errors[i] = float(mask_mse(den, ref_lat, mask))
-            clock.lap("other_s")
+            clock.lap("metric_s")
             if vae is not None:
                 gt, _ = image_shifter.shift(rec_img, 0, tj * ratio)
-                clock.lap("other_s")
+                clock.lap("shift_s")
                 img = vae_decode(vae, den * mask)
                 clock.lap("vae_s")
                 frames[i] = torch.cat((img, gt, torch.abs(img - gt)), -2).float().cpu()
-                clock.lap("other_s")
+                clock.lap("frames_s")
     finally:
         set_unet_attn_processor(unet, dict(previous))
 

@@ -441,7 +441,10 @@ class ResnetBlock2D(nn.Module):
                 and isinstance(self.nonlinearity, WarpedNonlinearity) and self.nonlinearity.fused_silu
                 and tuple(self.conv1.kernel_size) == (3, 3) and tuple(self.conv2.kernel_size) == (3, 3)
                 and x1.shape[-1] % 8 == 0 and (x2 is None or x2.shape[-1] % 8 == 0) and self.out_channels % 8 == 0
-                and self.out_channels % self.norm2.num_groups == 0)
+                and self.out_channels % self.norm2.num_groups == 0
+                # K of the two dense layers = Cin / Cout: whole K steps of the GEMM kernels (128 bytes of elements)
+                and (x1.shape[-1] + (0 if x2 is None else x2.shape[-1])) % (128 // x1.element_size()) == 0
+                and self.out_channels % (128 // x1.element_size()) == 0)
 
     def _forward_const2(self, input_tensor, temb_proj, temb_stride, next_gn):
         """The block on 2x2 planes: both alias-free activations are plane-constant there, so they are stored once per plane

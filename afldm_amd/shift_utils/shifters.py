@@ -34,7 +34,9 @@ def gen_valid_mask(shape, ti, tj):
     _, _, h, w = shape
     ti = int(np.ceil(ti)) if ti >= 0 else int(np.floor(ti))
     tj = int(np.ceil(tj)) if tj >= 0 else int(np.floor(tj))
-    mask = torch.ones(shape, dtype=torch.float32)
+    # (numpy, not torch: a torch CPU op on a 1 MB tensor fans out over every host core - milliseconds per op on the 256-thread
+    #  hosts of the MI355X boxes, and the harness builds ~100 masks per run: 0.4 s of its 0.8 s, profiles/r06/harness_c1.txt)
+    mask = np.ones(tuple(shape), dtype=np.float32)
     if ti >= 0:
         mask[:, :, 0:ti, :] = 0
     else:
@@ -43,7 +45,7 @@ def gen_valid_mask(shape, ti, tj):
         mask[:, :, :, 0:tj] = 0
     else:
         mask[:, :, :, tj:w] = 0
-    return mask
+    return torch.from_numpy(mask)
 
 
 def gen_random_offset(max_offset_i, max_offset_j, int_offset, int_stride, bs=1, min_offset_i=0, min_offset_j=0):

@@ -491,7 +491,9 @@ def harness_c1(dtype=torch.bfloat16, steps=50, offsets=16):
             recs.append(tm)
         best = min(recs[1:], key=lambda r: r["total_s"])
         out[name] = dict(total_s=round(best["total_s"], 4), unet_s=round(best["unet_s"], 4), vae_s=round(best["vae_s"], 4),
-                         other_s=round(best.get("other_s", 0.0), 4), first_call_s=round(recs[0]["total_s"], 3),
+                         shift_s=round(best.get("shift_s", 0.0), 4), metric_s=round(best.get("metric_s", 0.0), 4),
+                         frames_s=round(best.get("frames_s", 0.0), 4), other_s=round(best.get("other_s", 0.0), 4),
+                         first_call_s=round(recs[0]["total_s"], 3),
                          mask_mse_first_last=[float(f"{errs[0]:.4e}"), float(f"{errs[-1]:.4e}")])
     # the plain sampler at the two batch sizes of the procedure (no cross-frame processors, graph replay): the yardstick
     plain = {}

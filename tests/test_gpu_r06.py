@@ -60,7 +60,7 @@ def test_af_act_slabs_const2(dtype):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 8e-3)])
-@pytest.mark.parametrize("cin,cout,concat,batch", [(96, 96, False, 64), (96, 192, False, 3), (192, 96, True, 64), (192, 96, True, 1)])
+@pytest.mark.parametrize("cin,cout,concat,batch", [(128, 128, False, 64), (64, 192, False, 3), (384, 128, True, 64), (192, 64, True, 1)])
 def test_resnet_block_on_2x2_planes_const_form_vs_full_form(monkeypatch, dtype, tol, cin, cout, concat, batch):
     """ResnetBlock2D (af_api surgery applied) on 2x2 planes: the plane-constant form against the flattened-plane form
     (AFLDM_NO_CONST2) - same function, weights summed over the taps before the one rounding instead of after the products."""
@@ -76,6 +76,7 @@ def test_resnet_block_on_2x2_planes_const_form_vs_full_form(monkeypatch, dtype, 
     temb = torch.randn(1, cout, generator=g).cuda().to(dtype)
     gn = torch.nn.GroupNorm(8, cout).cuda().to(dtype)
     outs = {}
+    assert blk._const2_ok(inp)
     for form in (True, False):
         monkeypatch.setattr(blocks, "_CONST2", form)
         blocks.invalidate_packed(blk)
