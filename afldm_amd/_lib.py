@@ -74,6 +74,8 @@ def _load():
         "afldm_af_act": ([vp, ip, vp, ip, vp, ip, vp, ip, vp, vp, ip, fp, vp, vp, vp, vp, ip, ip, ip, vp], c_int),
         "afldm_af_act_c8": ([vp, ip, vp, ip, vp, ip, vp, ip, vp, vp, ip, fp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp], c_int),
         "afldm_af_act_const2": ([vp, ip, vp, ip, vp, ip, vp, ip, vp, vp, ip, fp, vp, vp, vp, ip, ip, vp], c_int),
+        "afldm_conv2x2_const_norm_act_supported": ([ip, ip, ip, ip], c_int),
+        "afldm_conv2x2_const_norm_act": ([vp, vp, vp, vp, ip, vp, vp, ip, fp, vp, vp, vp, ip, ip, ip, ip, vp], c_int),
         "afldm_af_act_slabs": ([vp, ip, vp, vp, ip, vp, vp, vp, vp, ip, fp, ip, vp, vp, vp, ip, ip, ip, ip, vp], c_int),
         "afldm_conv_out_fused": ([vp, vp, ip, vp, vp, ip, fp, vp, vp, vp, ip, ip, ip, ip, ip, vp], c_int),
         "afldm_af_pack_bytes": ([ip, ip], c_size_t),

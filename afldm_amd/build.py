@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(OUT_DIR, "libafldm_hip.so")
-SOURCES = ["api.hip", "misc.hip", "gn.hip", "af.hip", "sep.hip", "conv.hip", "conv3h.hip", "attn.hip", "attnf.hip", "fir.hip", "lin.hip", "skinny.hip", "convout.hip"]
+SOURCES = ["api.hip", "misc.hip", "gn.hip", "af.hip", "sep.hip", "conv.hip", "conv3h.hip", "attn.hip", "attnf.hip", "fir.hip", "lin.hip", "skinny.hip", "convout.hip", "dense2.hip"]
 # Experiments (include/afldm_hip_experimental.h): built, bit-identical to the launches they replace, measured slower - a library of
 # their own that links against the product library and that the default path never loads
 EXP_LIB = os.path.join(OUT_DIR, "libafldm_exp.so")

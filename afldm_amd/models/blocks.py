@@ -138,6 +138,20 @@ def packed_conv_dense2x2_const(conv, dtype):
     return cache[key]
 
 
+def packed_conv_dense2x2_const_cm(conv, dtype):
+    """packed_conv_dense2x2_const with its rows ordered channel-major (row = 4 n + pixel instead of pixel * Cout + n): a GroupNorm
+    group of the output - cpg channels x 4 pixels - is then 4 cpg ADJACENT rows, what afldm_conv2x2_const_norm_act tiles over."""
+    cache = conv.__dict__.setdefault("_afldm_cache", {})
+    key = ("dense2x2_const_cm", dtype)
+    if key not in cache:
+        W = conv.weight.detach().double()
+        Cout = W.shape[0]
+        blocks = [W[:, :, 1 - oh:3 - oh, 1 - ow:3 - ow].sum((2, 3)) for oh in (0, 1) for ow in (0, 1)]      # [pixel][Cout, Cin]
+        ws = torch.stack(blocks, 1).reshape(4 * Cout, -1).float().contiguous()                             # row = 4 n + pixel
+        cache[key] = ops.pack_weight(ws, dtype)
+    return cache[key]
+
+
 def conv_forward(conv: nn.Conv2d, x, **kw):
     """F.conv2d(x, conv.weight, conv.bias, stride 1, 'same') on NHWC (or a virtual concat)."""
     x1, x2 = _pair(x)
@@ -453,11 +467,19 @@ class ResnetBlock2D(nn.Module):
         x1, x2 = _pair(input_tensor)
         B, dt, Cout = x1.shape[0], x1.dtype, self.out_channels
         a = self._norm_act(self.norm1, input_tensor, out_const=True)                 # [B, Cin]
-        w1, b1 = packed_conv_dense2x2_const(self.conv1, dt)
         g2, be2 = packed_norm(self.norm2)
         h = None
-        got = None if os.environ.get("AFLDM_NO_FUSED_ACT") else ops.conv2d_slabs(a, w1)
-        if got is not None:                                                          # the plan splits K: the slabs' consumer finishes them
+        got = None
+        if ops.conv2x2_const_norm_act_ok(a.shape[-1], Cout, self.norm2.num_groups, dt) and not os.environ.get("AFLDM_NO_FUSED_ACT"):
+            # conv1 + temb -> norm2 -> activation in ONE launch: a workgroup owns a whole GroupNorm group of the dense layer's columns
+            h = ops.conv2x2_const_norm_act(a, packed_conv_dense2x2_const_cm(self.conv1, dt), _bias_f32(self.conv1), temb_proj,
+                                           temb_stride, g2, be2, self.norm2.num_groups, self.norm2.eps)
+        else:
+            w1, b1 = packed_conv_dense2x2_const(self.conv1, dt)
+            got = None if os.environ.get("AFLDM_NO_FUSED_ACT") else ops.conv2d_slabs(a, w1)
+        if h is not None:
+            pass
+        elif got is not None:                                                          # the plan splits K: the slabs' consumer finishes them
             slabs, nslab = got
             h = ops.af_act_slabs(slabs, nslab, _bias_f32(self.conv1), temb_proj, temb_stride, g2, be2, self.norm2.num_groups,
                                  self.norm2.eps, B, 2, Cout, dt, act=2)

@@ -1008,6 +1008,29 @@ def af_act_slabs(slabs, nslab, bias, temb, temb_stride, gamma, beta, G, eps, B, 
     return (out, raw) if want_raw else out
 
 
+def conv2x2_const_norm_act_ok(Cin, Cout, G, dtype):
+    return bool(lib.afldm_conv2x2_const_norm_act_supported(int(Cin), int(Cout), int(G), DTYPE_CODE[dtype]))
+
+
+def conv2x2_const_norm_act(a, w_cm, bias, temb, temb_stride, gamma, beta, G, eps):
+    """conv1 + temb -> norm2 -> WarpedNonlinearity of a ResnetBlock2D on 2x2 planes in ONE launch (afldm_conv2x2_const_norm_act):
+    a [B, Cin] the plane-constant first activation, w_cm [4 Cout, 1, 1, Cin] the tap-summed dense weights with channel-major rows
+    (row = 4 n + pixel), bias [Cout] fp32, temb the block's time_emb_proj slice.  Returns the plane-constant second activation
+    [B, Cout] (tagged `.const2`)."""
+    _dev(a, "a")
+    B, Cin = a.shape
+    Cout = w_cm.shape[0] // 4
+    out = torch.empty((B, Cout), dtype=a.dtype, device=a.device)
+    U, D = filter_matrices(2, a.device)
+    tok = _begin()
+    check(lib.afldm_conv2x2_const_norm_act(ptr(a), ptr(w_cm), ptr(bias), ptr(temb), int(temb_stride), ptr(gamma), ptr(beta), int(G),
+                                           float(eps), ptr(U), ptr(D), ptr(out), B, Cin, Cout, _code(a), stream_ptr()),
+          "conv2x2_const_norm_act")
+    _end(tok, "linear", 2.0 * B * 4 * Cout * Cin, (B * Cin + 4 * Cout * Cin + B * Cout) * a.element_size())
+    out.const2 = True
+    return out
+
+
 def conv_out_fused(x, w, bias, gamma, beta, G, eps):
     """conv_norm_out -> SiLU -> conv_out (3x3, <= 4 couts) of the UNet tail in one launch (afldm_conv_out_fused);
     returns None when the shape is not covered (the caller runs gn_apply + conv2d)."""

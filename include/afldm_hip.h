@@ -139,6 +139,18 @@ int afldm_af_act_c8(const void* x1, int C1, const void* x2, int C2, const float*
 int afldm_af_act_const2(const void* x1, int C1, const void* x2, int C2, const float* stats1, int S1, const float* stats2,
                         int S2, const float* gamma, const float* beta, int G, float eps, const float* U, const float* D,
                         void* y, int B, int dtype, afldm_stream_t stream);
+/* conv1 -> (+ time embedding) -> norm2 -> WarpedNonlinearity of diffusers ResnetBlock2D.forward on 2 x 2 planes as ONE launch, for a
+ * plane-constant input (the block's first WarpedNonlinearity, afldm_af_act_const2): a [B][Cin] is that activation, w [4 Cout][Cin] the
+ * tap-summed dense form of conv1 with its rows ordered channel-major (row = 4 n + pixel, pixel = 2 oh + ow), bias [Cout], temb the
+ * time_emb_proj row(s) (temb_stride elements between samples, 0 = one row for all), gamma / beta / G / eps norm2, U [4x2] / D [2x4]
+ * the N = 2 filter matrices; y [B][Cout] = the plane-constant second activation (input of conv2's dense form).  A workgroup owns
+ * one GroupNorm group x 16 samples, so statistics, normalisation and activation need no exchange (csrc/dense2.hip).  Rounding points
+ * as afldm_conv2d + afldm_af_act_const2: the convolution output is rounded to `dtype` once before it is normalised.
+ * _supported: 1 when there is a kernel (Cout / G in {8, 12, 24}, Cin a multiple of 8 MFMA K steps). */
+int afldm_conv2x2_const_norm_act_supported(int Cin, int Cout, int G, int dtype);
+int afldm_conv2x2_const_norm_act(const void* a, const void* w, const float* bias, const void* temb, int temb_stride,
+                                 const float* gamma, const float* beta, int G, float eps, const float* U, const float* D, void* y,
+                                 int B, int Cin, int Cout, int dtype, afldm_stream_t stream);
 /* A convolution's split-K slabs straight into the GroupNorm that follows it, on the 2x2 / 4x4 planes (diffusers
  * resnet.py / attention_processor.py): the slabs a deferred afldm_conv2d left in its workspace ([nslab][B*N*N][C]
  * fp32) are summed in slab order, + bias[c] + temb[b*temb_stride + c] + residual, rounded to `dtype` (the value the

@@ -95,6 +95,48 @@ def test_resnet_block_on_2x2_planes_const_form_vs_full_form(monkeypatch, dtype, 
     assert torch.allclose(s[..., 0], y.double().sum((1, 2)), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-6), (torch.bfloat16, 6e-3)])
+@pytest.mark.parametrize("B,Cin,Cout,G,per_sample_temb", [(64, 768, 768, 32, False), (3, 1536, 768, 32, True), (17, 256, 96, 8, False),
+                                                          (1, 256, 64, 8, True), (16, 512, 192, 8, False)])
+def test_conv2x2_const_norm_act_vs_separate_launches(dtype, tol, B, Cin, Cout, G, per_sample_temb):
+    """afldm_conv2x2_const_norm_act (conv1 + temb -> norm2 -> activation in one launch, csrc/dense2.hip) against the launches it
+    replaces - afldm_conv2d on the tap-summed weights, afldm_af_act_const2 on its output and statistics - and against a plain
+    fp64 evaluation of the same chain."""
+    from afldm_amd import ops
+    from afldm_amd.models import blocks
+    assert ops.conv2x2_const_norm_act_ok(Cin, Cout, G, dtype)
+    g = torch.Generator().manual_seed(B * 7 + Cin)
+    conv = torch.nn.Conv2d(Cin, Cout, 3, padding=1).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (9 * Cin)) ** 0.5)
+        conv.bias.copy_(torch.randn(Cout, generator=g) * 0.2)
+    a = torch.randn(B, Cin, generator=g).cuda().to(dtype)
+    temb = torch.randn(B if per_sample_temb else 1, Cout, generator=g).cuda().to(dtype)
+    ts = Cout if per_sample_temb else 0
+    gamma, beta = (torch.rand(Cout, generator=g) + 0.5).cuda(), (torch.randn(Cout, generator=g) * 0.3).cuda()
+    got = ops.conv2x2_const_norm_act(a, blocks.packed_conv_dense2x2_const_cm(conv, dtype), blocks._bias_f32(conv), temb.view(-1) if ts == 0 else temb,
+                                     ts, gamma, beta, G, 1e-5)
+    assert got.shape == (B, Cout)
+    # the separate launches
+    w1, b1 = blocks.packed_conv_dense2x2_const(conv, dtype)
+    y = ops.conv2d(a, w1, b1, temb=temb.view(-1) if ts == 0 else temb, temb_stride=ts, temb_mod=Cout, want_stats=True)
+    y4 = blocks._plane2_view(y, B, Cout)
+    ref = ops.af_act(y4, None, ops.gn_stats(y4, G), gamma, beta, G, 1e-5, out_const=True)
+    assert rel_rms(got.float(), ref.float().cpu().numpy()) <= tol
+    # fp64 on the host: full 3x3 convolution of the constant planes, GroupNorm, up x2 -> SiLU -> mean
+    from oracle import ideal_filters as idf
+    xa = a.double().cpu()[:, :, None, None].expand(B, Cin, 2, 2)
+    conv_out = torch.nn.functional.conv2d(xa, conv.weight.double().cpu(), conv.bias.double().cpu(), padding=1) + \
+        temb.double().cpu().expand(B, Cout)[:, :, None, None]
+    if dtype == torch.bfloat16:
+        conv_out = conv_out.to(torch.bfloat16).double()
+    hn = torch.nn.functional.group_norm(conv_out, G, gamma.double().cpu(), beta.double().cpu(), 1e-5)
+    Um = torch.from_numpy(np.asarray(idf.up_matrix(2, 2))).double()
+    up = torch.einsum("ph,bchw,qw->bcpq", Um, hn, Um)
+    want = torch.nn.functional.silu(up).mean((2, 3))
+    assert rel_rms(got.float(), want.numpy()) <= (1e-5 if dtype == torch.float32 else 1.5e-2)
+
+
 def test_ffhq_forward_runs_the_const_form(monkeypatch):
     """The FFHQ forward takes the plane-constant form for all 14 3x3 convolutions of the 2x2 level (7 ResnetBlock2D)."""
     from afldm_amd import ops
