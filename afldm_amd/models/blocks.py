@@ -470,7 +470,7 @@ class ResnetBlock2D(nn.Module):
         g2, be2 = packed_norm(self.norm2)
         h = None
         got = None
-        if ops.conv2x2_const_norm_act_ok(a.shape[-1], Cout, self.norm2.num_groups, dt) and not os.environ.get("AFLDM_NO_FUSED_ACT"):
+        if ops.conv2x2_const_norm_act_ok(a.shape[-1], Cout, self.norm2.num_groups, dt, batch=B) and not os.environ.get("AFLDM_NO_FUSED_ACT"):
             # conv1 + temb -> norm2 -> activation in ONE launch: a workgroup owns a whole GroupNorm group of the dense layer's columns
             h = ops.conv2x2_const_norm_act(a, packed_conv_dense2x2_const_cm(self.conv1, dt), _bias_f32(self.conv1), temb_proj,
                                            temb_stride, g2, be2, self.norm2.num_groups, self.norm2.eps)

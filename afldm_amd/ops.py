@@ -1008,7 +1008,16 @@ def af_act_slabs(slabs, nslab, bias, temb, temb_stride, gamma, beta, G, eps, B, 
     return (out, raw) if want_raw else out
 
 
-def conv2x2_const_norm_act_ok(Cin, Cout, G, dtype):
+# smallest batch the fused conv1 -> norm2 -> activation launch of the 2x2 level is used for: a workgroup owns a whole GroupNorm group
+# (96 weight rows x all of K), i.e. 32 workgroups per 16 samples - at batch 64 (128 workgroups) 4.637 -> 4.610 ms/step, at batch 1 / 8
+# (32 workgroups streaming 147 - 295 KB each against k_skinny's 192 x 24 KB) 2.002 -> 2.026 / 2.290 -> 2.298: profiles/r06/ab_dense2_r06c.log
+_DENSE2_MIN_B = int(os.environ.get("AFLDM_DENSE2_MIN_B", "32"))
+
+
+def conv2x2_const_norm_act_ok(Cin, Cout, G, dtype, batch=None):
+    """True when afldm_conv2x2_const_norm_act has a kernel for the shape and (batch given) the policy picks it."""
+    if batch is not None and batch < _DENSE2_MIN_B:
+        return False
     return bool(lib.afldm_conv2x2_const_norm_act_supported(int(Cin), int(Cout), int(G), DTYPE_CODE[dtype]))
 
 
