@@ -26,6 +26,9 @@ def parse_args():
     p.add_argument("--seed", type=int, default=1234)
     p.add_argument("--sequential", action="store_true",
                    help="one B = 1 sampler run per offset like the reference loop (default: all offsets of a rank in one batch)")
+    p.add_argument("--eager", action="store_true",
+                   help="run the STORE / LOAD passes as the eager per-step loop that follows the reference statement by statement "
+                        "instead of replayed HIP graphs (afldm_amd.harness.CrossFrameSampler)")
     p.add_argument("--fixed_resize", action="store_true",
                    help="opt OUT of the reference-exact flow: resize --input_path to sample_size x VAE ratio (256) before the VAE "
                         "(the reference resizes to sample_size = 32 and inverts a 4 x 4 latent) and draw the noise on the CPU")
@@ -69,7 +72,7 @@ def main():
     make_af_vae_from_config(pipe.vae)
     frames, errs = shift_ldm(pipe, args.num_inference_steps, args.shift_steps, args.output_path, args.input_path,
                              generator=torch.Generator().manual_seed(args.seed), rank=rank, world=world, batch_offsets=not args.sequential,
-                             reference_exact=not args.fixed_resize)
+                             reference_exact=not args.fixed_resize, use_graph=not args.eager)
     if rank == 0:
         print(f"wrote {args.output_path}: {len(frames)} frames; latent equivariance mask-MSE per offset:",
               " ".join(f"{e:.3e}" for e in errs))
