@@ -1009,9 +1009,11 @@ def af_act_slabs(slabs, nslab, bias, temb, temb_stride, gamma, beta, G, eps, B, 
 
 
 # smallest batch the fused conv1 -> norm2 -> activation launch of the 2x2 level is used for: a workgroup owns a whole GroupNorm group
-# (96 weight rows x all of K), i.e. 32 workgroups per 16 samples - at batch 64 (128 workgroups) 4.637 -> 4.610 ms/step, at batch 1 / 8
-# (32 workgroups streaming 147 - 295 KB each against k_skinny's 192 x 24 KB) 2.002 -> 2.026 / 2.290 -> 2.298: profiles/r06/ab_dense2_r06c.log
-_DENSE2_MIN_B = int(os.environ.get("AFLDM_DENSE2_MIN_B", "32"))
+# (96 weight rows x all of K = 147 - 295 KB, which one CU pulls at ~30 GB/s whatever the order of the workgroups), i.e. 32 workgroups
+# per 16 samples.  Same-box, alternating, ms/step with / without: batch 64 4.610 / 4.637, 4.628 / 4.664, 4.823 / 4.843 (three boxes);
+# batch 32 3.217 / 3.202, 3.268 / 3.247; batch 16 2.620 / 2.600; batch 8 2.298 / 2.290; batch 1 2.026 / 2.002
+# (profiles/r06/ab_dense2_r06c.log, ab_skinny_dense2_policy_r06d.log, ab_dense2_xcd_r06e.log): k_skinny's 192 x 24 KB wins below 64
+_DENSE2_MIN_B = int(os.environ.get("AFLDM_DENSE2_MIN_B", "64"))
 
 
 def conv2x2_const_norm_act_ok(Cin, Cout, G, dtype, batch=None):

@@ -17,7 +17,7 @@ out, tag = sys.argv[1], sys.argv[2]
 
 
 def fam(n):
-    for k in ("k_conv3h", "k_igemm3", "k_igemm2", "k_igemm", "k_skinny", "k_lin_wreg", "k_attn_fused", "k_attn", "k_af_act_plane", "k_af_act_kron",
+    for k in ("k_conv3h", "k_igemm3", "k_igemm2", "k_igemm", "k_skinny", "k_dense2_gn_act", "k_lin_wreg", "k_attn_fused", "k_attn", "k_af_act_plane", "k_af_act_kron",
               "k_af_act_small", "k_af_act_slabs", "k_resample_plane", "k_axis_contract", "k_splitk", "k_gn_apply", "k_gn_partial",
               "k_conv_cin4", "k_conv_out_fused"):
         if k in n:

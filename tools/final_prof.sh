@@ -16,4 +16,6 @@ bash profiles/run_pmc_sq.sh $TAG > gpurun_out/pmc_sq_$TAG.log 2>&1
 bash profiles/run_vae_profile.sh $TAG > gpurun_out/prof_vae_$TAG.log 2>&1
 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
 python bench.py --workload vae --no-cpu-baseline > gpurun_out/bench_vae_$TAG.json 2> gpurun_out/bench_vae_$TAG.err
+python bench.py --workload harness > gpurun_out/bench_harness_$TAG.json 2> gpurun_out/bench_harness_$TAG.err
+timeout 1500 python -m pytest tests -q -m gpu > gpurun_out/gputests_$TAG.log 2>&1; tail -3 gpurun_out/gputests_$TAG.log
 tail -c 600 gpurun_out/pmc_$TAG.log; tail -c 300 gpurun_out/bench_$TAG.json

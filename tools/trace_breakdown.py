@@ -20,7 +20,8 @@ def short(n):
     if "k_igemm" in n:
         m = re.search(r"Li(\d+)ELi(\d+)ELi\d+ELi\d+ELi\d+E(?:Li(\d+)E)?", n) or re.search(r"<\w+, (\d+), (\d+), \d+, \d+, \d+(?:, (\d+))?", n)
         return f"igemm{'2' if 'igemm2' in n else ''}_{m.group(1)}x{m.group(2)}" + (f"s{m.group(3)}" if m.group(3) else "")
-    for k in ["k_attn_fused", "k_attn", "gn_partial", "gn_apply", "af_act_mfma", "af_act_kron", "af_act_small", "splitk", "axis_contract",
+    for k in ["k_attn_fused", "k_attn", "k_dense2_gn_act", "k_skinny", "k_af_act_plane", "k_af_act_p8", "k_af_act_slabs", "k_resample_small",
+              "k_resample_plane", "k_conv_out_fused", "gn_partial", "gn_apply", "af_act_mfma", "af_act_kron", "af_act_small", "splitk", "axis_contract",
               "cin4", "small_cout", "silu", "ddim", "nchw", "timestep", "select", "advance"]:
         if k in n:
             return k
