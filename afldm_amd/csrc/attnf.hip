@@ -631,23 +631,26 @@ __global__ void __launch_bounds__(NW * 64, LEAN ? 2 : 1) k_attn_fused(AttnFP p) 
     }
     __syncthreads();
     stamp(10);
-    // The siblings' o rows: published by plain stores acknowledged by the XCD's L2 and awaited through relaxed atomics, so the
-    // loads are the ACQUIRE side - sc1 (agent scope: never served by this CU's vector L1) instead of relying on the L1 not
-    // having seen those lines yet in this kernel.  The L2 serves them as before.
+    // The siblings' o rows: published by plain stores acknowledged by the XCD's L2 and awaited through relaxed atomics.  The loads below
+    // are the ACQUIRE side.  INVARIANT they rely on: nothing in this kernel reads p.o before this point (it is write-only up to the
+    // hand-over), so this CU's vector L1 cannot hold a stale line of it and the lines come from the L2 the siblings wrote through.
+    // A change that touches p.o earlier (a prefetch, a second token block per workgroup) MUST switch to the sc1 form
+    // (-DAFLDM_ATTNF_ACQUIRE_SC1: agent-scope loads that are never served by the L1).  That form is not the default because it is
+    // measurably slower: a lane's 12 pieces share their 128-byte lines with the other half-row's lanes, through the L1 one miss
+    // serves eight pieces, with sc1 every piece is its own L2 request - 7.70 against 6.39 us for this phase, +2.8 us per launch,
+    // +0.013 ms/step (profiles/r06/attnf_sc1_ab.txt).
     const bf16* orow = p.o + ((size_t)b * T + trow) * C + hi * 8;
     bf16x8 of[CK];
-    {
-      typedef __attribute__((ext_vector_type(4))) unsigned int u4;
-      u4 raw[CK];
+#if !defined(AFLDM_ATTNF_ACQUIRE_SC1)      // (default: plain loads - see the comment above)
 #pragma unroll
-      for (int kk = 0; kk < CK; ++kk) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(raw[kk]) : "v"(orow + kk * 16) : "memory");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int kk = 0; kk < CK; ++kk) of[kk] = ld16<bf16x8>(orow + kk * 16);
+#else
+    typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+    u4 oraw[CK];
 #pragma unroll
-      for (int kk = 0; kk < CK; ++kk) {
-        asm volatile("" : "+v"(raw[kk]));                     // (ties every use to the wait above)
-        of[kk] = __builtin_bit_cast(bf16x8, raw[kk]);
-      }
-    }
+    for (int kk = 0; kk < CK; ++kk) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(oraw[kk]) : "v"(orow + kk * 16) : "memory");
+#endif
+    // (sc1 form: the bias loads go out behind the o rows and share their round trip; the wait sits after the accumulator set-up)
     f32x16 acc[NTL];
 #pragma unroll
     for (int tl = 0; tl < NTL; ++tl) {
@@ -659,6 +662,14 @@ __global__ void __launch_bounds__(NW * 64, LEAN ? 2 : 1) k_attn_fused(AttnFP p) 
         for (int e = 0; e < 8; ++e) acc[tl][8 * c + e] = (float)rx[tl][c][e] + (e < 4 ? b0[e] : b1[e - 4]);
       }
     }
+#if defined(AFLDM_ATTNF_ACQUIRE_SC1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int kk = 0; kk < CK; ++kk) {
+      asm volatile("" : "+v"(oraw[kk]));                      // (ties every use to the wait above)
+      of[kk] = __builtin_bit_cast(bf16x8, oraw[kk]);
+    }
+#endif
 #pragma unroll
     for (int kk = 0; kk < CK; ++kk) {
 #pragma unroll
