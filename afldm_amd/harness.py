@@ -121,10 +121,13 @@ class CrossFrameSampler:
         return out
 
 
-def _sampler(pipeline, steps):
+def _sampler(pipeline, steps, sched=None):
+    """The pipeline's cached CrossFrameSampler for `steps` evaluations of `sched` (default: a fresh DDIMScheduler of the pipeline's
+    configuration; the SR harness passes its I2SB ODE schedule)."""
     from .schedulers.ddim import DDIMScheduler
     unet = pipeline.unet
-    sched = DDIMScheduler.from_config(pipeline.scheduler.config)
+    if sched is None:
+        sched = DDIMScheduler.from_config(pipeline.scheduler.config)
     smp = getattr(pipeline, "_xframe_sampler", None)
     probe = (unet.dtype, str(unet.device), steps, tuple(sorted((k, repr(v)) for k, v in dict(sched.config).items())))
     if smp is None or smp.unet is not unet or smp.key != probe or smp.names != list(get_unet_attn_processors(unet)):
@@ -287,12 +290,14 @@ def vae_encode_mode(vae, x):
 
 @torch.no_grad()
 def shift_ldm_sr(pipeline, num_inference_steps=50, num_shift_steps=16, output_path="results/shift_ldm_sr.gif",
-                 input_path=None, image=None, rank=0, world=1, batch_offsets=True):
+                 input_path=None, image=None, rank=0, world=1, batch_offsets=True, use_graph=True):
     """Fractional-shift equivariance of x4 super-resolution with I2SB - the flow of reference
     scripts/shift_ldm_sr.py:43-150: degrade (bicubic x1/4, nearest x4), VAE-encode, denoise with
     cross-frame attention STORE, then for every offset shift the initial latent, denoise in LOAD mode
     and compare with the shifted reconstruction.  `image` ([1,3,H,W] in [-1,1]) replaces
-    `input_path` when given; the offsets are sharded across ranks."""
+    `input_path` when given; the offsets are sharded across ranks.  use_graph (default): the STORE / LOAD passes replay HIP
+    graphs (CrossFrameSampler over the scheduler's ODE schedule) when the scheduler does not clip x0; otherwise - and with
+    use_graph=False - the eager loop below, which follows the reference statement by statement."""
     from .af_libs.superresolution import build_sr4x
     device = pipeline.device
     vae, unet, scheduler = pipeline.vae, pipeline.unet, pipeline.scheduler
@@ -303,40 +308,51 @@ def shift_ldm_sr(pipeline, num_inference_steps=50, num_shift_steps=16, output_pa
     latent_shifter = ImageShifter("ideal_crop", ratio)
     image_shifter = ImageShifter()
 
-    attn_state = AttnState()
-    previous = get_unet_attn_processors(unet)
-    set_unet_attn_processor(unet, {k: CrossFrameAttnProcessor(attn_state) for k in previous})
+    ode = scheduler.ode_schedule(num_inference_steps) if (use_graph and num_inference_steps >= 2) else None
+    if ode is not None:
+        sampler = _sampler(pipeline, ode.evaluations, ode)
+        attn_state = sampler.attn_state
+        previous = sampler.install()
 
-    def denoise(latents):
-        latents = latents.to(device)
-        scheduler.set_timesteps(num_inference_steps, device=device)
-        ts = scheduler.timesteps
-        for i, t in enumerate(ts):
-            if i == num_inference_steps - 1:
-                break
-            attn_state.set_timestep(t)
-            eps = unet(scheduler.scale_model_input(latents, t), t, return_dict=False)[0]
-            latents = scheduler.step(eps, t, latents, is_ode=True, generator=None).prev_sample
-        return latents
+        def denoise(latents, load):
+            return sampler.run(latents, load).to(latents.dtype)
+    else:
+        attn_state = AttnState()
+        previous = get_unet_attn_processors(unet)
+        set_unet_attn_processor(unet, {k: CrossFrameAttnProcessor(attn_state) for k in previous})
+
+        def denoise(latents, load):
+            if load:
+                attn_state.to_load()
+            else:
+                attn_state.reset()
+            latents = latents.to(device)
+            scheduler.set_timesteps(num_inference_steps, device=device)
+            ts = scheduler.timesteps
+            for i, t in enumerate(ts):
+                if i == num_inference_steps - 1:
+                    break
+                attn_state.set_timestep(t)
+                eps = unet(scheduler.scale_model_input(latents, t), t, return_dict=False)[0]
+                latents = scheduler.step(eps, t, latents, is_ode=True, generator=None).prev_sample
+            return latents
 
     try:
         if image is None:
             image = image_to_tensor(input_path, (size, size))
         tensor = sr_func(image.to(device).float()).clip(-1, 1)
         init_latent = vae_encode_mode(vae, tensor.to(vae.dtype)).to(unet.dtype)
-        attn_state.reset()
-        denoised = denoise(init_latent)
-        attn_state.to_load()
+        denoised = denoise(init_latent, load=False)
         rec_img = vae_decode(vae, denoised)
         offsets = torch.linspace(1 / ratio, num_shift_steps / ratio, num_shift_steps)
         frames, errors = {}, {}
         mine = parallel.interleaved(num_shift_steps, rank, world)
         shifts = {i: latent_shifter.shift(init_latent, 0, float(offsets[i])) for i in mine}
         if batch_offsets and len(mine) > 1:      # one batched LOAD pass for this rank's offsets (see shift_ldm)
-            den_all = denoise(torch.cat([shifts[i][0] for i in mine], 0))
+            den_all = denoise(torch.cat([shifts[i][0] for i in mine], 0), load=True)
             dens = {i: den_all[k:k + 1] for k, i in enumerate(mine)}
         else:
-            dens = {i: denoise(shifts[i][0]) for i in mine}
+            dens = {i: denoise(shifts[i][0], load=True) for i in mine}
         for i in mine:
             tj = float(offsets[i])
             (shifted, mask), den = shifts[i], dens[i]

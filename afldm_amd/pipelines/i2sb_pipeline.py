@@ -13,7 +13,7 @@ class I2SBLDMPipeline(MyLDMPipeline):
 
     @torch.no_grad()
     def __call__(self, images, generator=None, is_ode=False, num_inference_steps=50, output_type="pil",
-                 return_dict=True, reference_exact=True, latent_dtype=torch.float32, **kwargs):
+                 return_dict=True, reference_exact=True, latent_dtype=torch.float32, use_graph=True, **kwargs):
         """images: [B, 3, H, W] tensor in [-1, 1] (the reference's VaeImageProcessor.preprocess leaves
         such tensors unchanged).  Like the reference (i2sb_pipeline.py:43) the posterior sample of the start latent is
         drawn by latent_dist.sample() WITHOUT the caller's generator; reference_exact=False opts into drawing it from
@@ -29,13 +29,31 @@ class I2SBLDMPipeline(MyLDMPipeline):
         start = self.vae.encode(images.to(device=self.device, dtype=self.unet.dtype)).latent_dist.sample(
             None if reference_exact else generator)
         latents = self._bridge(start * self.vae.config.scaling_factor, num_inference_steps, is_ode, generator,
-                               latent_dtype=latent_dtype)
+                               latent_dtype=latent_dtype, use_graph=use_graph)
         return self._deliver(latents, output_type, return_dict)
 
-    def _bridge(self, latents, steps, is_ode, generator, latent_dtype=torch.float32):
+    def _ode_engine(self, batch, steps):
+        """DenoiseEngine over the deterministic bridge (scheduler.ode_schedule): the same captured-graph loop the DDIM sampler
+        uses - the unclipped ODE update is the DDIM kernel's linear form with another coefficient row per evaluation."""
+        from ..engine import DenoiseEngine
+        ode = self.scheduler.ode_schedule(steps)
+        cfg_key = tuple(sorted((k, repr(v)) for k, v in dict(ode.config).items()))
+        key = (batch, steps, self.unet.dtype, str(self.unet.device), cfg_key)
+        cache = self.__dict__.setdefault("_ode_engines", {})
+        if key not in cache:
+            cache.clear()
+            cache[key] = DenoiseEngine(self.unet, ode, batch, ode.evaluations, use_graph=True)
+        return cache[key]
+
+    def _bridge(self, latents, steps, is_ode, generator, latent_dtype=torch.float32, use_graph=True):
         """steps - 1 UNet evaluations from the encoded degraded image towards the clean latent: the reference loop
-        leaves before its last timestep (i2sb_pipeline.py:48-50)."""
+        leaves before its last timestep (i2sb_pipeline.py:48-50).  The deterministic, unclipped bridge with the latent carried
+        in fp32 (is_ode, clip_sample off - what scripts/shift_ldm_sr.py runs) replays captured HIP graphs (use_graph); the
+        stochastic / clipped forms and latent_dtype=None run the eager loop below."""
         sched, unet = self.scheduler, self.unet
+        if (use_graph and is_ode and not sched.config.clip_sample and latent_dtype == torch.float32 and latents.is_cuda
+                and steps >= 2):
+            return self._ode_engine(latents.shape[0], steps).run(latents).to(latents.dtype)
         sched.set_timesteps(steps)
         # The latent is carried in fp32 BETWEEN evaluations whatever the UNet's dtype (as DenoiseEngine does for DDIM): a
         # step of the 100-step bridge moves the latent by about one bf16 ulp, and a latent stored in bf16 - what the

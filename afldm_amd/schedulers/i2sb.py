@@ -24,6 +24,26 @@ class I2SBSchedulerOutput:
     pred_original_sample: torch.Tensor = None
 
 
+class _OdeSchedule:
+    """Scheduler-shaped view of an I2SBScheduler's deterministic bridge for the graph-replayed engines (afldm_amd/engine.py): the
+    timesteps of its evaluations and one (c0, c1, c2, c3) row per evaluation for afldm_ddim_step."""
+
+    def __init__(self, sched, steps):
+        self.sched, self.steps = sched, steps
+        self.evaluations = steps - 1
+        self.init_noise_sigma = 1.0
+        self.config = FrozenConfig(dict(sched.config, _i2sb_ode_steps=steps))
+        self._timesteps_host = []
+
+    def set_timesteps(self, num_evaluations=None, device=None):
+        assert num_evaluations in (None, self.evaluations), "the schedule is fixed by ode_schedule(num_inference_steps)"
+        self.sched.set_timesteps(self.steps)
+        self._timesteps_host = list(self.sched._timesteps_host[:self.evaluations])
+
+    def coefficient_table(self, device):
+        return torch.tensor([self.sched.ode_coefficients(t) for t in self._timesteps_host], dtype=torch.float32).to(device)
+
+
 class I2SBScheduler:
     order = 1
 
@@ -106,6 +126,22 @@ class I2SBScheduler:
         n = self.num_inference_steps if self.num_inference_steps else self.config.num_train_timesteps
         return t - self.config.num_train_timesteps // n
 
+    def ode_coefficients(self, timestep):
+        """(c0, c1, c2, c3) of the deterministic, unclipped update in the linear form the DDIM kernels take -
+        x0 = (x - c1 eps) / c0, x_prev = c2 x0 + c3 eps - i.e. x0 = x - s_t eps, x_prev = (mu_x0 + mu_xt) x0 + mu_xt s_t eps
+        (reference i2sb_scheduler.py:382-459 with is_ode and without clip_sample)."""
+        t, prev_t = int(timestep), self.previous_timestep(timestep)
+        std_fwd, std_prev = self.std_fwd[t], self.std_fwd[prev_t]
+        std_delta = (std_fwd ** 2 - std_prev ** 2).sqrt()
+        mu_x0, mu_xt, _ = compute_gaussian_product_coef(std_prev, std_delta)
+        return (1.0, float(std_fwd), float(mu_x0 + mu_xt), float(mu_xt * std_fwd))
+
+    def ode_schedule(self, num_inference_steps):
+        """The ODE bridge of `num_inference_steps` (num_inference_steps - 1 UNet evaluations: the reference loop leaves before
+        its last timestep, i2sb_pipeline.py:48-50) as the (timesteps, coefficient table) object DenoiseEngine / the harness's
+        CrossFrameSampler replay as HIP graphs; None when the configuration clips x0 (the clamp breaks the linear form)."""
+        return None if self.config.clip_sample else _OdeSchedule(self, int(num_inference_steps))
+
     def step(self, model_output, timestep, sample, is_ode=False, generator=None, return_dict=True):
         if not sample.is_cuda:
             raise RuntimeError("afldm_amd.I2SBScheduler.step runs on MI355X tensors only (no CPU path)")
@@ -122,7 +158,7 @@ class I2SBScheduler:
             prev = float(mu_x0) * x0 + float(mu_xt) * x
         else:
             x0 = None
-            prev = ops.ddim_step_flat(x, e, (1.0, float(std_fwd), float(mu_x0 + mu_xt), float(mu_xt * std_fwd)))
+            prev = ops.ddim_step_flat(x, e, self.ode_coefficients(timestep))
         if t > 0 and not is_ode:
             prev = prev + randn_tensor(e.shape, generator=generator, device=e.device, dtype=e.dtype) * float(var.sqrt())
         prev = prev.to(sample.dtype)

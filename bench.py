@@ -524,6 +524,40 @@ def harness_c1(dtype=torch.bfloat16, steps=50, offsets=16):
     return out
 
 
+def i2sb_c5(batch=32, dtype=torch.bfloat16, steps=100):
+    """BASELINE configs[4]'s sampler, per-GPU share (batch 256 over 8 GPUs = 32 per GPU): the 99 UNet evaluations of the 100-step
+    I2SB bridge (deterministic, unclipped - what scripts/shift_ldm_sr.py runs; reference i2sb_pipeline.py:48-56) on the FFHQ-size AF-UNet,
+    replayed as HIP graphs (I2SBLDMPipeline._bridge -> DenoiseEngine over scheduler.ode_schedule) and as the eager loop."""
+    from afldm_amd.configs import FFHQ_DDIM_CONFIG
+    from afldm_amd.pipelines.i2sb_pipeline import I2SBLDMPipeline
+    from afldm_amd.schedulers.i2sb import I2SBScheduler
+    dev = torch.device("cuda", torch.cuda.current_device())
+    unet = build_unet(dtype, dev)
+    cfg = {k: v for k, v in FFHQ_DDIM_CONFIG.items() if k != "set_alpha_to_one"}
+    pipe = I2SBLDMPipeline(None, unet, I2SBScheduler.from_config(cfg))
+    pipe.set_progress_bar_config(disable=True)
+    start = (torch.randn(batch, 4, 32, 32, generator=torch.Generator().manual_seed(3)) * 0.5).to(dev).to(dtype)
+    out = {}
+    for name, graph, reps in (("graph", True, 3), ("eager", False, 1)):
+        pipe._bridge(start, steps, True, None, use_graph=graph)
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            y = pipe._bridge(start, steps, True, None, use_graph=graph)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        out[name] = median(ts)
+        finite = bool(torch.isfinite(y.float()).all().item())
+    del pipe, unet
+    torch.cuda.empty_cache()
+    ev = steps - 1
+    return dict(workload=f"I2SB ODE bridge, {ev} UNet evaluations, batch {batch} (BASELINE configs[4], per-GPU share), FFHQ-size AF-UNet",
+                dtype="bf16" if dtype == torch.bfloat16 else "fp32", seconds=round(out["graph"], 4),
+                ms_per_evaluation=round(1e3 * out["graph"] / ev, 4), value=round(batch * ev / out["graph"], 1), unit="evaluations/s",
+                eager_seconds=round(out["eager"], 4), outputs_finite=finite)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -660,6 +694,7 @@ def main():
             out["concurrent_jobs"] = [concurrent_engines(2), concurrent_engines(3)]
             out["vae_c4"] = vae_workload()
             out["harness_c1"] = harness_c1()
+            out["i2sb_c5"] = i2sb_c5()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

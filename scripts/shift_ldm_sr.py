@@ -26,6 +26,8 @@ def parse_args():
     p.add_argument("--seed", type=int, default=1234)
     p.add_argument("--sequential", action="store_true",
                    help="one B = 1 sampler run per offset like the reference loop (default: all offsets of a rank in one batch)")
+    p.add_argument("--eager", action="store_true",
+                   help="run the STORE / LOAD passes as the eager per-step loop instead of replayed HIP graphs")
     return p.parse_args()
 
 
@@ -68,7 +70,7 @@ def main():
     make_af_unet(pipe.unet)
     make_af_vae_from_config(pipe.vae)
     frames, errs = shift_ldm_sr(pipe, args.num_inference_steps, args.shift_steps, args.output_path, args.input_path,
-                                image=image, rank=rank, world=world, batch_offsets=not args.sequential)
+                                image=image, rank=rank, world=world, batch_offsets=not args.sequential, use_graph=not args.eager)
     if rank == 0:
         print(f"wrote {args.output_path}: {len(frames)} frames; latent equivariance mask-MSE per offset:",
               " ".join(f"{e:.3e}" for e in errs))

@@ -271,3 +271,60 @@ def test_shift_ldm_graph_path_matches_eager_loop_and_replays():
                            generator=torch.Generator().manual_seed(2), reference_exact=False, use_graph=False)
     for a, b in zip(fr_g, fr_e):
         assert (a - b).abs().max() <= 2e-4
+
+
+# ----------------------------------------------------------------------------- (c) the I2SB ODE bridge on replayed graphs
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 2e-3)])
+def test_i2sb_ode_bridge_graph_path_matches_eager_loop(golden, dtype, tol):
+    """I2SBLDMPipeline._bridge (deterministic, unclipped, latent carried in fp32: what scripts/shift_ldm_sr.py runs; reference
+    i2sb_pipeline.py:48-56 + i2sb_scheduler.py:382-459) on the captured-graph engine against its own eager loop - same kernels,
+    same coefficients - at FFHQ size, 12 evaluations, batch 2; the full-length oracle comparisons of test_gpu_r02 / r04 / r05 run
+    through the graph path by default."""
+    from afldm_amd.configs import FFHQ_DDIM_CONFIG
+    from afldm_amd.pipelines.i2sb_pipeline import I2SBLDMPipeline
+    from afldm_amd.schedulers.i2sb import I2SBScheduler
+    g = golden("g14_r03.npz")
+    cfg = {k: v for k, v in FFHQ_DDIM_CONFIG.items() if k != "set_alpha_to_one"}
+    unet, _, _ = build_unet("ffhq", dtype)
+    pipe = I2SBLDMPipeline(None, unet, I2SBScheduler.from_config(cfg))
+    pipe.set_progress_bar_config(disable=True)
+    start = torch.from_numpy(g["i2sb_start"]).cuda().to(dtype)
+    start = torch.cat([start, start.flip(-1)], 0)
+    a = pipe._bridge(start, 13, True, None)
+    b = pipe._bridge(start, 13, True, None, use_graph=False)
+    assert "_ode_engines" in pipe.__dict__ and len(pipe._ode_engines) == 1
+    assert rel_rms(a.float(), b.float().cpu().numpy()) <= tol
+    assert torch.equal(a, pipe._bridge(start, 13, True, None))                 # replay: bit-identical
+    # the clipped configuration (the reference scheduler's default) keeps the eager loop
+    clip = I2SBLDMPipeline(None, unet, I2SBScheduler.from_config(dict(cfg, clip_sample=True)))
+    clip.set_progress_bar_config(disable=True)
+    assert clip.scheduler.ode_schedule(13) is None
+    assert torch.isfinite(clip._bridge(start, 4, True, None)).all() and "_ode_engines" not in clip.__dict__
+
+
+def test_shift_ldm_sr_graph_path_matches_eager_loop():
+    """harness.shift_ldm_sr (reference scripts/shift_ldm_sr.py:43-150) on replayed graphs against use_graph=False, tiny models."""
+    from afldm_amd.af_modules.af_api import make_af_unet, make_af_vae_from_config
+    from afldm_amd.configs import tiny_unet_config
+    from afldm_amd.harness import shift_ldm_sr
+    from afldm_amd.models.unet_2d import UNet2DModel
+    from afldm_amd.models.vae import AutoencoderKL
+    from afldm_amd.pipelines.i2sb_pipeline import I2SBLDMPipeline
+    from afldm_amd.schedulers.i2sb import I2SBScheduler
+    torch.manual_seed(0)
+    unet = UNet2DModel.from_config(tiny_unet_config(sample_size=8))
+    vae = AutoencoderKL(in_channels=3, out_channels=3, down_block_types=["DownEncoderBlock2D"] * 4,
+                        up_block_types=["UpDecoderBlock2D"] * 4, block_out_channels=[32, 32, 64, 64],
+                        layers_per_block=1, latent_channels=4, norm_num_groups=8, scaling_factor=0.6, mid_act=True,
+                        down_filtered_act=[False, True, True, True], up_filtered_act=[True, True, True, False],
+                        up_rescale=[True, True, True])
+    pipe = I2SBLDMPipeline(vae, unet, I2SBScheduler(clip_sample=False)).to("cuda")
+    make_af_unet(pipe.unet)
+    make_af_vae_from_config(pipe.vae)
+    img = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(5)) * 2 - 1
+    fg, eg = shift_ldm_sr(pipe, num_inference_steps=5, num_shift_steps=3, output_path=None, image=img)
+    fe, ee = shift_ldm_sr(pipe, num_inference_steps=5, num_shift_steps=3, output_path=None, image=img, use_graph=False)
+    assert sorted(pipe._xframe_sampler.engines) == [(False, 1), (True, 3)]
+    for x, y in zip(fg, fe):
+        assert (x - y).abs().max() <= 5e-4
+    assert np.allclose(eg, ee, rtol=5e-3, atol=1e-9), (eg, ee)
