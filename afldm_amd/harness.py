@@ -197,7 +197,18 @@ def shift_ldm(pipeline, num_inference_steps=50, num_shift_steps=16, output_path=
     image_shifter = ImageShifter()
     clock = _Clock(timings)
 
+    init_latent = None
     if use_graph:
+        if input_path is not None:
+            # The reference inverts with its processors installed in their initial STORE state (shift_ldm_ffhq.py:110-116); what
+            # that stores is overwritten by the STORE pass, so the inversion runs here, on the plain processors and the captured-graph
+            # loop (MyLDMPipeline.ddim_inversion, latent carried in fp32): same procedure, no side effects to undo
+            size = unet.config.sample_size * (1 if reference_exact else ratio)
+            tensor = vae_encode(vae, image_to_tensor(input_path, (size, size)).to(device))
+            clock.lap("vae_s")
+            scheduler.set_timesteps(num_inference_steps, device=device)
+            init_latent = pipeline.ddim_inversion(tensor.float(), bar=False)
+            clock.lap("unet_s")
         sampler = _sampler(pipeline, num_inference_steps)
         attn_state = sampler.attn_state
         previous = sampler.install()
@@ -223,14 +234,14 @@ def shift_ldm(pipeline, num_inference_steps=50, num_shift_steps=16, output_path=
             return latents
 
     try:
-        if input_path is not None:
+        if init_latent is not None:
+            pass
+        elif input_path is not None:
             size = unet.config.sample_size * (1 if reference_exact else ratio)
             tensor = vae_encode(vae, image_to_tensor(input_path, (size, size)).to(device))
             clock.lap("vae_s")
             scheduler.set_timesteps(num_inference_steps, device=device)
-            if use_graph:
-                attn_state.to_idle()      # (the reference inverts in the processors' initial STORE state; what that stores is
-            init_latent = pipeline.ddim_inversion(tensor, bar=False)      #  overwritten by the STORE pass below: same numbers)
+            init_latent = pipeline.ddim_inversion(tensor, bar=False)
             clock.lap("unet_s")
         else:
             # CPU-side draw (seedable, device independent) — the reference draws on the GPU

@@ -82,21 +82,56 @@ class MyLDMPipeline(DiffusionPipeline):
         images = self.numpy_to_pil(arrays) if output_type == "pil" else arrays
         return ImagePipelineOutput(images=images) if return_dict else (images,)
 
-    @torch.no_grad()
-    def ddim_inversion(self, latent, bar=True):
-        """Deterministic DDIM inversion over reversed timesteps (reference ldm_pipeline.py:133-160)."""
-        from .. import ops
+    def _inversion_rows(self):
+        """(timestep, (mu_prev, sigma_prev, mu, sigma)) per step of the inversion over the scheduler's current timesteps, reversed:
+        latent <- mu (latent - sigma_prev eps) / mu_prev + sigma eps (reference ldm_pipeline.py:133-160) - the DDIM update kernel's
+        linear form with (sqrt a_t, sqrt(1 - a_t)) := (mu_prev, sigma_prev) and (sqrt a_prev, sqrt(1 - a_prev)) := (mu, sigma)."""
         ts = list(reversed(self.scheduler._timesteps_host))
-        it = self.progress_bar(ts) if bar else ts
         ac = self.scheduler.alphas_cumprod
-        for i, t in enumerate(it):
+        rows = []
+        for i, t in enumerate(ts):
             a_t = ac[t]
             a_prev = ac[ts[i - 1]] if i > 0 else self.scheduler.final_alpha_cumprod
-            mu, mu_prev = a_t ** 0.5, a_prev ** 0.5
-            sigma, sigma_prev = (1 - a_t) ** 0.5, (1 - a_prev) ** 0.5
+            rows.append((t, (float(a_prev ** 0.5), float((1 - a_prev) ** 0.5), float(a_t ** 0.5), float((1 - a_t) ** 0.5))))
+        return rows
+
+    @torch.no_grad()
+    def ddim_inversion(self, latent, bar=True, use_graph=True):
+        """Deterministic DDIM inversion over reversed timesteps (reference ldm_pipeline.py:133-160).  use_graph (fp32 latents on the
+        GPU, plain attention processors): the loop replays DenoiseEngine's captured graphs over the inversion's coefficient rows;
+        otherwise - bf16 latents, which the reference carries in their own dtype between steps, or a UNet with cross-frame
+        processors installed - the eager loop below."""
+        from .. import ops
+        rows = self._inversion_rows()
+        if (use_graph and latent.is_cuda and latent.dtype == torch.float32 and len(rows) >= 1
+                and tuple(latent.shape[1:]) == (self.unet.config.in_channels, self.unet.config.sample_size, self.unet.config.sample_size)
+                and all(type(m.processor).__name__ == "AttnProcessor2_0" for m in self.unet.modules() if hasattr(m, "processor"))):
+            sched = _InversionSchedule(self.scheduler, rows)
+            cfg_key = tuple(sorted((k, repr(v)) for k, v in dict(sched.config).items()))
+            key = (latent.shape[0], len(rows), self.unet.dtype, str(self.unet.device), cfg_key)
+            cache = self.__dict__.setdefault("_inv_engines", {})
+            if key not in cache:
+                cache.clear()
+                cache[key] = DenoiseEngine(self.unet, sched, latent.shape[0], len(rows), use_graph=True)
+            return cache[key].run(latent).to(latent.dtype)
+        it = self.progress_bar(rows) if bar else rows
+        for t, coef in it:
             eps = self.unet(latent, t).sample
-            # latent <- mu * (latent - sigma_prev eps) / mu_prev + sigma eps : the DDIM update kernel
-            # with (sqrt a_t, sqrt(1-a_t)) := (mu_prev, sigma_prev) and (sqrt a_prev, ..) := (mu, sigma)
-            latent = ops.ddim_step_flat(latent.float().contiguous(), eps.float().contiguous(),
-                                        (float(mu_prev), float(sigma_prev), float(mu), float(sigma))).to(latent.dtype)
+            latent = ops.ddim_step_flat(latent.float().contiguous(), eps.float().contiguous(), coef).to(latent.dtype)
         return latent
+
+
+class _InversionSchedule:
+    """Scheduler-shaped view of a DDIM inversion for DenoiseEngine: its timesteps (ascending) and one coefficient row per step."""
+
+    def __init__(self, scheduler, rows):
+        self.rows = rows
+        self.init_noise_sigma = 1.0
+        self.config = dict(scheduler.config, _inversion_timesteps=tuple(t for t, _ in rows))
+        self._timesteps_host = [t for t, _ in rows]
+
+    def set_timesteps(self, n=None, device=None):
+        assert n in (None, len(self.rows))
+
+    def coefficient_table(self, device):
+        return torch.tensor([c for _, c in self.rows], dtype=torch.float32).to(device)

@@ -328,3 +328,40 @@ def test_shift_ldm_sr_graph_path_matches_eager_loop():
     for x, y in zip(fg, fe):
         assert (x - y).abs().max() <= 5e-4
     assert np.allclose(eg, ee, rtol=5e-3, atol=1e-9), (eg, ee)
+
+
+def test_ddim_inversion_graph_path_and_harness_with_input_image(tmp_path):
+    """MyLDMPipeline.ddim_inversion (reference ldm_pipeline.py:133-160) on the captured-graph engine against its eager loop (fp32
+    latents; the oracle comparisons of test_gpu_r02 run through the graph path by default), and harness.shift_ldm with an input
+    IMAGE (VAE-encode -> inversion -> STORE -> LOAD; reference shift_ldm_ffhq.py:110-116) on graphs against use_graph=False."""
+    from PIL import Image
+    from test_gpu_vae import build_vae
+    from afldm_amd.af_modules.af_api import make_af_unet
+    from afldm_amd.harness import shift_ldm
+    from afldm_amd.models.unet_2d import UNet2DModel
+    from afldm_amd.pipelines.ldm_pipeline import MyLDMPipeline
+    from afldm_amd.schedulers.ddim import ffhq_ddim_scheduler
+    from oracle import configs as oc, unet as ou
+    vae, _, _ = build_vae(torch.float32)
+    ucfg = oc.tiny_unet()
+    unet = UNet2DModel.from_config(ucfg)
+    unet.load_state_dict(ou.randomize_norm_affine(ou.init_unet_params(ucfg, seed=0, conv_out_scale=0.1)))
+    make_af_unet(unet)
+    pipe = MyLDMPipeline(vae, unet.cuda(), ffhq_ddim_scheduler())
+    pipe.set_progress_bar_config(disable=True)
+    s = ucfg["sample_size"]
+    x = torch.randn(2, 4, s, s, generator=torch.Generator().manual_seed(9)).cuda()
+    pipe.scheduler.set_timesteps(5, device="cuda")
+    a = pipe.ddim_inversion(x, bar=False)
+    b = pipe.ddim_inversion(x, bar=False, use_graph=False)
+    assert "_inv_engines" in pipe.__dict__ and rel_rms(a, b.cpu().numpy()) <= 2e-6
+    assert torch.equal(a, pipe.ddim_inversion(x, bar=False))
+    rng = np.random.default_rng(0)
+    path = str(tmp_path / "in.png")
+    Image.fromarray((rng.random((96, 96, 3)) * 255).astype(np.uint8)).save(path)
+    fg, eg = shift_ldm(pipe, num_inference_steps=3, num_shift_steps=2, output_path=None, input_path=path, reference_exact=False)
+    fe, ee = shift_ldm(pipe, num_inference_steps=3, num_shift_steps=2, output_path=None, input_path=path, reference_exact=False,
+                       use_graph=False)
+    for u, v in zip(fg, fe):
+        assert (u - v).abs().max() <= 5e-4
+    assert np.allclose(eg, ee, rtol=5e-3, atol=1e-9), (eg, ee)
