@@ -359,7 +359,9 @@ def test_ddim_inversion_graph_path_and_harness_with_input_image(tmp_path):
     rng = np.random.default_rng(0)
     path = str(tmp_path / "in.png")
     Image.fromarray((rng.random((96, 96, 3)) * 255).astype(np.uint8)).save(path)
+    torch.manual_seed(123)           # (vae_encode draws the posterior sample from the global generator, as the reference does)
     fg, eg = shift_ldm(pipe, num_inference_steps=3, num_shift_steps=2, output_path=None, input_path=path, reference_exact=False)
+    torch.manual_seed(123)
     fe, ee = shift_ldm(pipe, num_inference_steps=3, num_shift_steps=2, output_path=None, input_path=path, reference_exact=False,
                        use_graph=False)
     for u, v in zip(fg, fe):
