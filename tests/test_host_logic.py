@@ -415,3 +415,52 @@ def test_integration_doc_lists_every_entry_point():
     assert len(names) >= 36
     missing = [n for n in names if n not in doc]
     assert not missing, missing
+
+
+def test_graph_schedules_are_the_oracles_updates_in_linear_form():
+    """The (c0, c1, c2, c3) rows the captured-graph engine replays - x0 = (x - c1 eps) / c0, x_prev = c2 x0 + c3 eps, the DDIM
+    kernel's form - for the I2SB ODE bridge (I2SBScheduler.ode_schedule; reference i2sb_scheduler.py:382-459, i2sb_pipeline.py:48-50)
+    and for DDIM inversion (MyLDMPipeline._inversion_rows; reference ldm_pipeline.py:133-160) against the oracle's scheduler
+    arithmetic on random tensors: no GPU involved, only the host tables."""
+    from afldm_amd.configs import FFHQ_DDIM_CONFIG
+    from afldm_amd.pipelines.ldm_pipeline import MyLDMPipeline, _InversionSchedule
+    from afldm_amd.schedulers.ddim import ffhq_ddim_scheduler
+    from afldm_amd.schedulers.i2sb import I2SBScheduler
+    from oracle import ddim as od, i2sb as oi
+    g = torch.Generator().manual_seed(0)
+    x, e = torch.randn(2, 4, 8, 8, generator=g), torch.randn(2, 4, 8, 8, generator=g)
+
+    def linear(c):
+        x0 = (x - c[1] * e) / c[0]
+        return c[2] * x0 + c[3] * e
+
+    cfg = {k: v for k, v in FFHQ_DDIM_CONFIG.items() if k != "set_alpha_to_one"}
+    sched = I2SBScheduler.from_config(cfg)
+    assert I2SBScheduler.from_config(dict(cfg, clip_sample=True)).ode_schedule(100) is None      # the clamp is not linear
+    ode = sched.ode_schedule(100)
+    ode.set_timesteps(99)
+    ref = oi.I2SB()
+    ref.set_timesteps(100)
+    assert ode.evaluations == 99 and ode._timesteps_host == [int(t) for t in ref.timesteps[:99]]
+    table = ode.coefficient_table("cpu")
+    assert table.shape == (99, 4)
+    for i in (0, 1, 50, 98):
+        t = ode._timesteps_host[i]
+        want = ref.step(e, t, x, is_ode=True)
+        assert (linear([float(v) for v in table[i]]) - want).abs().max() <= 2e-6 * want.abs().max()
+    # DDIM inversion over a 6-step schedule
+    pipe = MyLDMPipeline.__new__(MyLDMPipeline)
+    pipe.scheduler = ffhq_ddim_scheduler()
+    pipe.scheduler.set_timesteps(6)
+    rows = pipe._inversion_rows()
+    ref = od.DDIM()
+    ref.set_timesteps(6)
+    ts = ref.timesteps.flip(0)
+    assert [t for t, _ in rows] == [int(t) for t in ts]
+    for i, (t, c) in enumerate(rows):
+        a_t = ref.alphas_cumprod[int(ts[i])]
+        a_prev = ref.alphas_cumprod[int(ts[i - 1])] if i > 0 else ref.final_alpha_cumprod
+        want = a_t ** 0.5 * ((x - (1 - a_prev) ** 0.5 * e) / a_prev ** 0.5) + (1 - a_t) ** 0.5 * e
+        assert (linear(c) - want).abs().max() <= 2e-6 * want.abs().max()
+    inv = _InversionSchedule(pipe.scheduler, rows)
+    assert inv.coefficient_table("cpu").shape == (6, 4) and inv._timesteps_host == [t for t, _ in rows]
